@@ -1,0 +1,278 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE -- see orb_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_LEVELS = 16
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CORNER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+
+
+class OrcExtractor(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scaleFactor", C.c_double), ("nlevels", C.c_int),
+                ("iniThFAST", C.c_int), ("minThFAST", C.c_int),
+                ("mvScaleFactor", C.c_float * MAX_LEVELS), ("mvInvScaleFactor", C.c_float * MAX_LEVELS),
+                ("mvLevelSigma2", C.c_float * MAX_LEVELS), ("mvInvLevelSigma2", C.c_float * MAX_LEVELS),
+                ("mnFeaturesPerLevel", C.c_int * MAX_LEVELS), ("umax", C.c_int * 16)]
+
+
+class OrcGridParams(C.Structure):
+    _fields_ = [("minX", C.c_float), ("minY", C.c_float), ("invW", C.c_float), ("invH", C.c_float),
+                ("cols", C.c_int), ("rows", C.c_int)]
+
+
+class OrcFeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("node_id", C.c_void_p), ("start", C.c_void_p), ("idx", C.c_void_p)]
+
+
+class OrcProjParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("nnratio", C.c_float), ("check_ori", C.c_int), ("th_dist", C.c_int)]
+
+
+def build(march_native=False, out_dir=None):
+    """compile the oracle; returns the path of the .so"""
+    out_dir = out_dir or _HERE
+    so = os.path.join(out_dir, "liborb_oracle_native.so" if march_native else "liborb_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orb_extract.c", "orb_match.c")]
+    deps = srcs + [os.path.join(_HERE, f) for f in ("orb_oracle.h", "brief_pattern.inc")]
+    if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps):
+        return so
+    cmd = ["gcc", "-O3", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math"]
+    if march_native:
+        cmd.append("-march=native")
+    cmd += ["-shared", "-o", so] + srcs + ["-lm"]
+    subprocess.check_call(cmd)
+    return so
+
+
+_lib = None
+
+
+def lib(path=None):
+    global _lib
+    if _lib is None or path is not None:
+        so = path or os.path.join(_HERE, "liborb_oracle.so")
+        if not os.path.exists(so):
+            so = build()
+        L = C.CDLL(so)
+        L.orc_extractor_init.restype = C.c_int
+        L.orc_extract.restype = C.c_int
+        L.orc_fast9_16.restype = C.c_int
+        L.orc_level_candidates.restype = C.c_int
+        L.orc_distribute.restype = C.c_int
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_descriptor_distance.restype = C.c_int
+        L.orc_rot_bin.restype = C.c_int
+        L.orc_rot_bin.argtypes = [C.c_float, C.c_float]
+        L.orc_match_bruteforce.restype = C.c_int
+        L.orc_features_in_area.restype = C.c_int
+        L.orc_search_by_bow.restype = C.c_int
+        L.orc_search_by_projection.restype = C.c_int
+        if path is not None:
+            return L
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Extractor:
+    """mirror of ORBextractor (reference include/ORBextractor.h:45-111) on the oracle"""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, L=None):
+        self.L = L or lib()
+        self.ex = OrcExtractor()
+        rc = self.L.orc_extractor_init(C.byref(self.ex), int(nfeatures), C.c_float(scaleFactor),
+                                       int(nlevels), int(iniThFAST), int(minThFAST))
+        if rc != 0:
+            raise ValueError("bad extractor parameters")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def scale_factors(self):
+        return np.array(self.ex.mvScaleFactor[:self.nlevels], dtype=np.float32)
+
+    def features_per_level(self):
+        return list(self.ex.mnFeaturesPerLevel[:self.nlevels])
+
+    def umax(self):
+        return list(self.ex.umax)
+
+    def level_size(self, w, h, level):
+        lw, lh = C.c_int(), C.c_int()
+        self.L.orc_level_size(C.byref(self.ex), w, h, level, C.byref(lw), C.byref(lh))
+        return lw.value, lh.value
+
+    def __call__(self, img, want_pyramid=False):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 8 * self.nlevels + 64
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        cand = np.zeros(MAX_LEVELS, dtype=np.int32)
+        kept = np.zeros(MAX_LEVELS, dtype=np.int32)
+        pyr = None
+        if want_pyramid:
+            tot = sum(a * b for a, b in (self.level_size(w, h, l) for l in range(self.nlevels)))
+            pyr = np.zeros(tot, dtype=np.uint8)
+        n = self.L.orc_extract(C.byref(self.ex), _p(img), w, h, w, _p(kps), _p(desc), cap,
+                               _p(pyr), _p(cand), _p(kept))
+        if n < 0:
+            raise RuntimeError("orc_extract failed: %d" % n)
+        out = dict(kps=kps[:n].copy(), desc=desc[:n].copy(), cand_counts=cand[:self.nlevels].copy(),
+                   kept_counts=kept[:self.nlevels].copy())
+        if want_pyramid:
+            out["pyramid"] = pyr
+        return out
+
+    def level_candidates(self, level_img):
+        level_img = np.ascontiguousarray(level_img, dtype=np.uint8)
+        h, w = level_img.shape
+        cap = w * h // 4 + 16
+        out = np.zeros(cap, dtype=CORNER_DTYPE)
+        n = self.L.orc_level_candidates(C.byref(self.ex), _p(level_img), w, h, w, _p(out), cap)
+        if n < 0:
+            raise RuntimeError("candidate overflow")
+        return out[:n].copy()
+
+
+def resize(src, dw, dh, L=None):
+    L = L or lib()
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.zeros((dh, dw), dtype=np.uint8)
+    L.orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+    return dst
+
+
+def fast(img, threshold, L=None):
+    L = L or lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros(w * h // 4 + 16, dtype=CORNER_DTYPE)
+    n = L.orc_fast9_16(_p(img), w, h, w, int(threshold), _p(out), out.shape[0])
+    return out[:n].copy()
+
+
+def gaussian7(img, L=None):
+    L = L or lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    dst = np.zeros_like(img)
+    L.orc_gaussian7_u8(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(dst), img.shape[1])
+    return dst
+
+
+def distribute(cands, minX, maxX, minY, maxY, N, L=None):
+    L = L or lib()
+    cands = np.ascontiguousarray(cands, dtype=CORNER_DTYPE)
+    out = np.zeros(N + 64, dtype=CORNER_DTYPE)
+    n = L.orc_distribute(_p(cands), cands.shape[0], minX, maxX, minY, maxY, N, _p(out), out.shape[0])
+    if n < 0:
+        raise RuntimeError("orc_distribute failed %d" % n)
+    return out[:n].copy()
+
+
+def descriptor_distance(a, b, L=None):
+    L = L or lib()
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return L.orc_descriptor_distance(_p(a), _p(b))
+
+
+def match_bruteforce(qdesc, qangle, tdesc, tangle, nnratio=0.7, th_low=50, check_ori=True, L=None):
+    L = L or lib()
+    qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+    tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+    qangle = np.ascontiguousarray(qangle, dtype=np.float32)
+    tangle = np.ascontiguousarray(tangle, dtype=np.float32)
+    nq, nt = qdesc.shape[0], tdesc.shape[0]
+    match = np.full(max(nq, 1), -1, dtype=np.int32)
+    n = L.orc_match_bruteforce(_p(qdesc), _p(qangle), nq, _p(tdesc), _p(tangle), nt,
+                               C.c_float(nnratio), int(th_low), int(bool(check_ori)), _p(match))
+    return match[:nq], n
+
+
+def make_grid_params(minX, minY, maxX, maxY, cols=64, rows=48):
+    gp = OrcGridParams()
+    gp.minX, gp.minY = minX, minY
+    gp.invW = np.float32(cols) / np.float32(np.float32(maxX) - np.float32(minX))
+    gp.invH = np.float32(rows) / np.float32(np.float32(maxY) - np.float32(minY))
+    gp.cols, gp.rows = cols, rows
+    return gp
+
+
+def grid_build(gp, keys_un, L=None):
+    L = L or lib()
+    keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)
+    n = keys_un.shape[0]
+    start = np.zeros(gp.cols * gp.rows + 1, dtype=np.int32)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    L.orc_grid_build(C.byref(gp), _p(keys_un), n, _p(start), _p(idx))
+    return start, idx
+
+
+def features_in_area(gp, keys_un, start, idx, x, y, r, minLevel=-1, maxLevel=-1, L=None):
+    L = L or lib()
+    keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)
+    out = np.zeros(max(keys_un.shape[0], 1), dtype=np.int32)
+    n = L.orc_features_in_area(C.byref(gp), _p(keys_un), _p(start), _p(idx), C.c_float(x), C.c_float(y),
+                               C.c_float(r), int(minLevel), int(maxLevel), _p(out), out.shape[0])
+    return out[:n].copy()
+
+
+def _featvec(node_id, start, idx):
+    fv = OrcFeatVec()
+    keep = (np.ascontiguousarray(node_id, dtype=np.uint32), np.ascontiguousarray(start, dtype=np.int32),
+            np.ascontiguousarray(idx, dtype=np.int32))
+    fv.n_nodes = keep[0].shape[0]
+    fv.node_id, fv.start, fv.idx = (k.ctypes.data for k in keep)
+    return fv, keep
+
+
+def search_by_bow(qdesc, qangle, qvalid, qfv, tdesc, tangle, tvalid, tfv, nnratio, check_ori,
+                  out_by_train, L=None):
+    """qfv / tfv: (node_id, start, idx) CSR triples"""
+    L = L or lib()
+    qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+    tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+    qangle = np.ascontiguousarray(qangle, dtype=np.float32)
+    tangle = np.ascontiguousarray(tangle, dtype=np.float32)
+    qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+    tv = None if tvalid is None else np.ascontiguousarray(tvalid, dtype=np.uint8)
+    nq, nt = qdesc.shape[0], tdesc.shape[0]
+    fq, kq = _featvec(*qfv)
+    ft, kt = _featvec(*tfv)
+    match = np.full(max(nt if out_by_train else nq, 1), -1, dtype=np.int32)
+    n = L.orc_search_by_bow(_p(qdesc), _p(qangle), _p(qv), nq, C.byref(fq),
+                            _p(tdesc), _p(tangle), _p(tv), nt, C.byref(ft),
+                            C.c_float(nnratio), int(bool(check_ori)), int(bool(out_by_train)), _p(match))
+    return match[:(nt if out_by_train else nq)], n
+
+
+def search_by_projection(mode, nnratio, check_ori, th_dist, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos,
+                         gp, t_keys_un, start, idx, tdesc, t_occ, assign, L=None):
+    L = L or lib()
+    pp = OrcProjParams(int(mode), float(nnratio), int(bool(check_ori)), int(th_dist))
+    q_uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
+    q_lvl = np.ascontiguousarray(q_lvl, dtype=np.int8)
+    qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+    qangle = np.ascontiguousarray(qangle, dtype=np.float32)
+    qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+    qo = None if q_obs_pos is None else np.ascontiguousarray(q_obs_pos, dtype=np.uint8)
+    t_keys_un = np.ascontiguousarray(t_keys_un, dtype=KP_DTYPE)
+    tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+    t_occ = np.ascontiguousarray(t_occ, dtype=np.uint8).copy()
+    assign = np.ascontiguousarray(assign, dtype=np.int32).copy()
+    n = L.orc_search_by_projection(C.byref(pp), _p(q_uvr), _p(q_lvl), _p(qdesc), _p(qangle), _p(qv), _p(qo),
+                                   q_uvr.shape[0], C.byref(gp), _p(t_keys_un), _p(start), _p(idx),
+                                   _p(tdesc), t_keys_un.shape[0], _p(t_occ), _p(assign))
+    return assign, t_occ, n

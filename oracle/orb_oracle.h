@@ -1,0 +1,168 @@
+/*
+ * orb_oracle.h -- CPU ORACLE for the ORBSLAMM per-frame hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is a plain-C restatement of the reference algorithm
+ *   /root/reference/SingleRobotScenario/src/ORBextractor.cc   (extractor)
+ *   /root/reference/SingleRobotScenario/src/ORBmatcher.cc     (matchers)
+ *   /root/reference/SingleRobotScenario/src/Frame.cc:230-245,327-392 (grid)
+ * Each function cites the file:line it follows.
+ *
+ * !! PARITY UNPINNED !!  The arithmetic of five extractor stages lives in OpenCV
+ * (cv::FAST, cv::resize, cv::GaussianBlur, cv::fastAtan2, cvRound), which is NOT
+ * vendored in the reference and NOT installed in this image.  The
+ * reference target is OpenCV 3.0.0 (CMake asks for >=3.0, fallback
+ * 2.4.3); its published generic C++ algorithm is restated here.
+ * The reference holds no tests / golden vectors for this path, and
+ * the reference cannot be built here without writing stand-ins for OpenCV, so
+ * there is no oracle/_ref.  What IS pinned: the BRIEF pattern (sha256), the umax
+ * table, the per-level feature split, the matcher arithmetic (fully visible in
+ * the reference source) -- see tests/test_oracle_*.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * anything in this directory.  The product (orbslamm_amd/) never links it.
+ *
+ * Deterministic refinements of reference behaviour that is undefined/UB:
+ *  - DistributeOctTree sorts pair<int,ExtractorNode*>; ties on size are broken by
+ *    heap pointer (ORBextractor.cc:684).  Oracle: tie -> node creation sequence
+ *    number, ascending (so walking from the back expands the latest-created first).
+ *  - floating point: strict IEEE binary32, no FMA contraction (-ffp-contract=off).
+ *  - levels whose FAST window is narrower/lower than 30 px (nCols or nRows == 0;
+ *    float division by zero in the reference, :785-786) yield no keypoints.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 16
+
+/* layout-identical to cv::KeyPoint as filled by the reference (28 bytes) */
+typedef struct {
+    float x, y;      /* pt */
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} OrcKeyPoint;
+
+typedef struct {
+    int nfeatures;
+    double scaleFactor;           /* member is double, initialised from a float (ORBextractor.h:93) */
+    int nlevels;
+    int iniThFAST, minThFAST;
+    float mvScaleFactor[ORC_MAX_LEVELS];
+    float mvInvScaleFactor[ORC_MAX_LEVELS];
+    float mvLevelSigma2[ORC_MAX_LEVELS];
+    float mvInvLevelSigma2[ORC_MAX_LEVELS];
+    int mnFeaturesPerLevel[ORC_MAX_LEVELS];
+    int umax[16];
+} OrcExtractor;
+
+/* FAST candidate in level (window-relative) coordinates, before distribution */
+typedef struct {
+    int32_t x, y;
+    int32_t score;
+} OrcCorner;
+
+/* ---- extractor ---- */
+int  orc_extractor_init(OrcExtractor* ex, int nfeatures, float scaleFactor, int nlevels,
+                        int iniThFAST, int minThFAST);
+void orc_level_size(const OrcExtractor* ex, int w, int h, int level, int* lw, int* lh);
+
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
+                          uint8_t* dst, int dw, int dh, int dstride);
+int  orc_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold,
+                  OrcCorner* out, int cap);
+void orc_gaussian7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+float orc_fast_atan2(float y, float x);
+float orc_ic_angle(const uint8_t* img, int stride, int x, int y, const int* umax);
+void orc_brief(const uint8_t* blurred, int stride, int x, int y, float angle_deg, uint8_t desc[32]);
+
+/* candidates of one level, in reference order (cells row-major, inside a cell row-major);
+ * coordinates are window-relative (minBorder not added).  returns count (<= cap) */
+int  orc_level_candidates(const OrcExtractor* ex, const uint8_t* img, int w, int h, int stride,
+                          OrcCorner* out, int cap);
+/* DistributeOctTree: in = candidates (window-relative), out = kept, list order */
+int  orc_distribute(const OrcCorner* in, int n, int minX, int maxX, int minY, int maxY,
+                    int N, OrcCorner* out, int cap);
+
+/* whole operator(): returns number of keypoints (or <0 on error).  desc is N x 32.
+ * If pyr_out != NULL it receives the concatenated (tight, stride = level width)
+ * pyramid levels 0..nlevels-1; if cand_counts != NULL it receives the per-level
+ * number of FAST candidates; kept_counts the per-level kept keypoints. */
+int  orc_extract(const OrcExtractor* ex, const uint8_t* img, int w, int h, int stride,
+                 OrcKeyPoint* kps, uint8_t* desc, int cap,
+                 uint8_t* pyr_out, int* cand_counts, int* kept_counts);
+
+/* ---- matcher ---- */
+int  orc_descriptor_distance(const uint8_t a[32], const uint8_t b[32]);
+void orc_three_maxima(const int* hist_sizes, int L, int* ind1, int* ind2, int* ind3);
+int  orc_rot_bin(float angle_q, float angle_t);
+
+/* headline brute force "match vs previous frame" (SURVEY.md 8d): for every query
+ * (current frame) best/second over ALL train descriptors in index order, accept
+ * best<=th_low && (float)best < nnratio*(float)second, rotation histogram + top-3
+ * pruning.  match[q] = train index or -1.  returns number of matches. */
+int  orc_match_bruteforce(const uint8_t* qdesc, const float* qangle, int nq,
+                          const uint8_t* tdesc, const float* tangle, int nt,
+                          float nnratio, int th_low, int check_ori, int32_t* match);
+
+/* Frame grid (Frame.cc:230-245, 382-392) as CSR: cell = ix*rows+iy */
+typedef struct {
+    float minX, minY, invW, invH;  /* mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv */
+    int cols, rows;                /* 64, 48 */
+} OrcGridParams;
+void orc_grid_build(const OrcGridParams* gp, const OrcKeyPoint* keys_un, int n,
+                    int32_t* cell_start /* cols*rows+1 */, int32_t* cell_idx /* n */);
+int  orc_features_in_area(const OrcGridParams* gp, const OrcKeyPoint* keys_un,
+                          const int32_t* cell_start, const int32_t* cell_idx,
+                          float x, float y, float r, int minLevel, int maxLevel,
+                          int32_t* out, int cap);
+
+/* SearchByBoW, flattened (ORBmatcher.cc:159-290 when out_by_train=1, :524-657 when 0).
+ * Feature vectors are CSR: node ids ascending, per-node index lists in stored order. */
+typedef struct {
+    int n_nodes;
+    const uint32_t* node_id;   /* ascending */
+    const int32_t* start;      /* n_nodes+1 */
+    const int32_t* idx;        /* feature indices */
+} OrcFeatVec;
+int  orc_search_by_bow(const uint8_t* qdesc, const float* qangle, const uint8_t* qvalid, int nq,
+                       const OrcFeatVec* qfv,
+                       const uint8_t* tdesc, const float* tangle, const uint8_t* tvalid, int nt,
+                       const OrcFeatVec* tfv,
+                       float nnratio, int check_ori, int out_by_train,
+                       int32_t* match /* nt if out_by_train else nq */);
+
+/* SearchByProjection family, flattened (projection itself stays in the caller).
+ * mode 3: ORBmatcher.cc:45-129   (Frame, vector<MapPoint*>)  best+second w/ levels
+ * mode 4: ORBmatcher.cc:1330-1472 (Cur, Last)                best only, rot-hist
+ * mode 5: ORBmatcher.cc:1474-1601 (Cur, KF, set)             best<=ORBdist, rot-hist
+ * mode 6: ORBmatcher.cc:292-405   (KF, Scw)                  best<=TH_LOW
+ * per query: u,v,r,minLevel,maxLevel, valid, obs_pos (MapPoint::Observations()>0).
+ * t_occ in: initial "skip" flag per train feature.  assign[t] (in/out): query index
+ * now held by train feature t, -1 if none / unchanged initial.  returns nmatches. */
+typedef struct {
+    int mode;
+    float nnratio;
+    int check_ori;
+    int th_dist;   /* TH_HIGH=100 (3,4), ORBdist (5), TH_LOW=50 (6) */
+} OrcProjParams;
+int  orc_search_by_projection(const OrcProjParams* pp,
+                              const float* q_uvr /* nq x 3 */, const int8_t* q_lvl /* nq x 2 */,
+                              const uint8_t* qdesc, const float* qangle,
+                              const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                              const OrcGridParams* gp, const OrcKeyPoint* t_keys_un,
+                              const int32_t* cell_start, const int32_t* cell_idx,
+                              const uint8_t* tdesc, int nt,
+                              uint8_t* t_occ, int32_t* assign);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,48 @@
+"""Deterministic synthetic camera streams: a static scene of random
+rectangles and discs on a canvas, a slowly panning viewport, additive noise.
+Pure numpy so that the CPU oracle and the GPU harness see identical bytes."""
+import numpy as np
+
+
+def _tri(a, m):
+    a = a % (2 * m)
+    return a if a <= m else 2 * m - a
+
+
+def make_scene(w, h, stream=0, nshapes=None):
+    cw, ch = w + 64, h + 16
+    if nshapes is None:
+        nshapes = max(200, int(4000 * (w * h) / (1241.0 * 376.0)))
+    rng = np.random.Generator(np.random.PCG64(0x0B5A4000 + stream))
+    canvas = np.full((ch, cw), 128, dtype=np.uint8)
+    cx = rng.integers(0, cw, nshapes)
+    cy = rng.integers(0, ch, nshapes)
+    sz = rng.integers(4, 41, nshapes)
+    sz2 = rng.integers(4, 41, nshapes)
+    val = rng.integers(0, 256, nshapes)
+    kind = rng.integers(0, 2, nshapes)
+    for i in range(nshapes):
+        x0, y0 = int(cx[i]), int(cy[i])
+        if kind[i] == 0:
+            canvas[max(0, y0 - sz2[i] // 2):y0 + sz2[i] // 2 + 1, max(0, x0 - sz[i] // 2):x0 + sz[i] // 2 + 1] = val[i]
+        else:
+            r = int(sz[i]) // 2
+            ya, yb = max(0, y0 - r), min(ch, y0 + r + 1)
+            xa, xb = max(0, x0 - r), min(cw, x0 + r + 1)
+            yy, xx = np.ogrid[ya:yb, xa:xb]
+            m = (yy - y0) ** 2 + (xx - x0) ** 2 <= r * r
+            canvas[ya:yb, xa:xb][m] = val[i]
+    return canvas
+
+
+def frame_from_scene(canvas, w, h, t, stream=0):
+    ox, oy = _tri(2 * t, 64), _tri(t, 16)
+    view = canvas[oy:oy + h, ox:ox + w].astype(np.int16)
+    rng = np.random.Generator(np.random.PCG64((0x5EED0000 + stream) * 100003 + t))
+    noise = rng.integers(-4, 5, size=(h, w), dtype=np.int16)
+    return np.clip(view + noise, 0, 255).astype(np.uint8)
+
+
+def make_frames(w, h, nframes, stream=0, t0=0):
+    canvas = make_scene(w, h, stream)
+    return np.stack([frame_from_scene(canvas, w, h, t0 + t, stream) for t in range(nframes)])
