@@ -1,0 +1,221 @@
+/*
+ * orbslamm_hip.h -- C ABI of the MI355X-native ORB front-end (liborbslamm_hip.so).
+ *
+ * Drop-in boundary for the per-frame hot path of HDaoud/ORBSLAMM.  Every entry
+ * point names the reference interface it replaces (paths under
+ * /root/reference/SingleRobotScenario/).  Plain pointers and sizes only; no
+ * exceptions cross the ABI; every function returns 0 on success or a negative
+ * ORBX_E_* code (orbx_last_error() gives the text).  All compute runs in HIP
+ * kernels on gfx950 -- there is no CPU fallback; without a GPU every compute
+ * entry returns ORBX_E_NO_DEVICE.
+ *
+ * Threading (mirrors the reference): one handle = one HIP stream;
+ * calls on one handle must be serialised by the caller, distinct handles are
+ * fully concurrent and may live on different devices.
+ */
+#ifndef ORBSLAMM_HIP_H
+#define ORBSLAMM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_MAX_LEVELS 16
+
+enum {
+    ORBX_OK = 0,
+    ORBX_E_INVALID = -1,      /* bad argument */
+    ORBX_E_NO_DEVICE = -2,    /* no HIP device / extension unusable: fail loudly, never fall back */
+    ORBX_E_HIP = -3,          /* HIP runtime error (text in orbx_last_error) */
+    ORBX_E_CAPACITY = -4,     /* caller buffer too small; nothing written past cap */
+    ORBX_E_UNSUPPORTED = -5   /* image shape the reference itself cannot handle */
+};
+
+const char* orbx_last_error(void);
+/* number of visible HIP devices (0 when none); never fails */
+int orbx_device_count(void);
+
+/* ---------------------------------------------------------------- extractor
+ * replaces class ORBextractor (include/ORBextractor.h:45-111). */
+
+/* ORBextractor::ORBextractor(int nfeatures, float scaleFactor, int nlevels,
+ *                            int iniThFAST, int minThFAST)  src/ORBextractor.cc:410-470 */
+typedef struct {
+    int32_t nfeatures;
+    float scaleFactor;
+    int32_t nlevels;
+    int32_t iniThFAST;
+    int32_t minThFAST;
+} OrbxParams;
+
+/* layout-identical to cv::KeyPoint as the reference fills it (28 bytes):
+ * pt.x, pt.y, size, angle, response, octave, class_id (=-1)   src/ORBextractor.cc:841-847,1094-1103 */
+typedef struct {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} OrbxKeyPoint;
+
+typedef struct orbx_handle orbx_t;
+
+/* Allocates every device buffer once (no allocation on the per-frame path).
+ * max_w/max_h: largest frame; max_batch: frames in flight per call. */
+int orbx_create(const OrbxParams* params, int max_w, int max_h, int max_batch, int device, orbx_t** out);
+void orbx_destroy(orbx_t* h);
+
+/* GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors /
+ * GetScaleSigmaSquares / GetInverseScaleSigmaSquares  (include/ORBextractor.h:60-83).
+ * Each array receives nlevels floats; NULL pointers are skipped.  Works without a GPU. */
+int orbx_levels(const orbx_t* h);
+float orbx_scale_factor(const orbx_t* h);
+int orbx_scale_tables(const orbx_t* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:435-446) and umax[16] (:452-469) */
+int orbx_features_per_level(const orbx_t* h, int32_t* out);
+int orbx_umax(const orbx_t* h, int32_t out[16]);
+/* upper bound of keypoints one frame can yield (sum over levels of N_l + slack) */
+int orbx_max_keypoints(const orbx_t* h);
+
+/* void ORBextractor::operator()(InputArray image, InputArray mask,
+ *        vector<KeyPoint>& keypoints, OutputArray descriptors)   src/ORBextractor.cc:1043-1105
+ * image: 8-bit single channel, host memory (mask is ignored by the reference).
+ * kps[cap], desc[cap*32]; *n_out = number of keypoints.  Empty image (w<=0||h<=0||!img):
+ * returns ORBX_OK with outputs untouched, like the reference (:1046-1047) but *n_out = 0. */
+int orbx_extract(orbx_t* h, const uint8_t* img, int w, int h_, int stride,
+                 OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Batched form: B independent frames of identical shape, host memory.
+ * kps[B*cap], desc[B*cap*32], n_out[B]. */
+int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int h_, int stride,
+                       OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Device-resident form: frames already in HBM (d_imgs + f*frame_pitch, rows `stride`
+ * bytes apart; base, stride and frame_pitch must be multiples of 4).  Results stay
+ * in handle-owned HBM (see orbx_device_results); asynchronous on the handle's stream. */
+int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int B, int w, int h_,
+                              int stride, size_t frame_pitch);
+/* device pointers of the last batch: kps[B][cap], desc[B][cap][32], counts[B] */
+int orbx_device_results(orbx_t* h, OrbxKeyPoint** d_kps, uint8_t** d_desc, int32_t** d_counts, int* cap);
+/* blocking D2H copy of one frame of the last batch */
+int orbx_download(orbx_t* h, int frame, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* std::vector<cv::Mat> mvImagePyramid (include/ORBextractor.h:85): lazy D2H of one
+ * level (tight rows, no 19 px border -- the border is never read on the mono path).
+ * dst may be NULL to query the size.  blurred!=0 returns the 7x7 Gaussian-smoothed
+ * working image the descriptors were sampled from (src/ORBextractor.cc:1085-1086). */
+int orbx_pyramid_level(orbx_t* h, int frame, int level, int blurred, uint8_t* dst, int* w, int* h_);
+/* per-stage dump for parity tests: FAST candidates of one level, packed records
+ * (see DESIGN.md "candidate record"), unordered; returns count in *n */
+int orbx_level_candidates(orbx_t* h, int frame, int level, uint64_t* dst, int cap, int* n);
+
+int orbx_sync(orbx_t* h);
+
+/* "match vs previous frame" for the stream held by this handle:
+ * frame f of the last extracted batch is matched against frame f-1 (frame 0 against
+ * the last frame of the previous batch; no previous frame -> no matches).
+ * Brute-force best/second Hamming over ALL previous-frame descriptors in index order,
+ * accept best<=th_low && (float)best < nnratio*(float)second, rotation histogram and
+ * three-maxima pruning exactly as ORBmatcher::SearchByBoW does (src/ORBmatcher.cc:230-287).
+ * Results stay in HBM: match[B][cap] (int32, -1 = none), nmatch[B]. */
+int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low, int check_ori);
+int orbx_device_matches(orbx_t* h, int32_t** d_match, int32_t** d_nmatch);
+int orbx_download_matches(orbx_t* h, int frame, int32_t* match, int cap, int* nmatch);
+/* forget the previous frame (start of a new stream) */
+int orbx_reset_stream(orbx_t* h);
+
+/* per-kernel timing with HIP events on the handle's stream.  enable=1 starts
+ * collecting (adds two event records per launch); orbx_profile_read returns the
+ * accumulated milliseconds and launch count per kernel since the last reset. */
+#define ORBX_PROF_MAX 16
+typedef struct {
+    int32_t n;
+    const char* name[ORBX_PROF_MAX];
+    double ms[ORBX_PROF_MAX];
+    int64_t launches[ORBX_PROF_MAX];
+} OrbxProfile;
+int orbx_profile_enable(orbx_t* h, int enable);
+int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset);
+
+/* ---------------------------------------------------------------- matcher
+ * replaces class ORBmatcher (include/ORBmatcher.h:37-102).  The object-graph
+ * walking (MapPoint flags, mutex-guarded getters, camera projection) stays in the
+ * C++ adapter; these entry points take the flattened arrays (host memory). */
+typedef struct orbm_handle orbm_t;
+int orbm_create(int device, orbm_t** out);
+void orbm_destroy(orbm_t* h);
+
+/* static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)
+ * src/ORBmatcher.cc:1649-1665.  dist[nq*nt], row-major. */
+int orbm_distance_matrix(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* dist);
+
+/* brute-force matcher on host arrays (same rule as orbx_match_prev_batch_device) */
+int orbm_match_bruteforce(orbm_t* h, const uint8_t* qdesc, const float* qangle, int nq,
+                          const uint8_t* tdesc, const float* tangle, int nt,
+                          float nnratio, int th_low, int check_ori, int32_t* match, int* nmatches);
+
+/* DBoW2::FeatureVector flattened to CSR (Thirdparty/DBoW2/DBoW2/FeatureVector.h:21-47):
+ * node ids ascending, per-node feature-index lists in stored order. */
+typedef struct {
+    int32_t n_nodes;
+    const uint32_t* node_id;
+    const int32_t* start;   /* n_nodes + 1 */
+    const int32_t* idx;
+} OrbmFeatVec;
+
+/* int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)     src/ORBmatcher.cc:159-290 (out_by_train=1)
+ * int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)  src/ORBmatcher.cc:524-657 (out_by_train=0)
+ * qvalid: query feature has a good MapPoint; tvalid (KF-KF form only): train feature has one.
+ * match: nt entries (query index per train feature) if out_by_train else nq entries. */
+int orbm_search_by_bow(orbm_t* h,
+                       const uint8_t* qdesc, const float* qangle, const uint8_t* qvalid, int nq,
+                       const OrbmFeatVec* qfv,
+                       const uint8_t* tdesc, const float* tangle, const uint8_t* tvalid, int nt,
+                       const OrbmFeatVec* tfv,
+                       float nnratio, int check_ori, int out_by_train,
+                       int32_t* match, int* nmatches);
+
+/* Frame grid: Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea
+ * src/Frame.cc:230-245, 382-392, 327-380 (KeyFrame::GetFeaturesInArea src/KeyFrame.cc:618-657) */
+typedef struct {
+    float minX, minY;   /* mnMinX, mnMinY */
+    float invW, invH;   /* mfGridElementWidthInv, mfGridElementHeightInv */
+    int32_t cols, rows; /* FRAME_GRID_COLS 64, FRAME_GRID_ROWS 48 */
+} OrbmGrid;
+
+/* SearchByProjection family (projection done by the caller):
+ * mode 3: SearchByProjection(Frame&, const vector<MapPoint*>&, th)        src/ORBmatcher.cc:45-129
+ * mode 4: SearchByProjection(Frame& Cur, const Frame& Last, th, bMono)    src/ORBmatcher.cc:1330-1472
+ * mode 5: SearchByProjection(Frame&, KeyFrame*, set<MapPoint*>&, th, ORBdist) src/ORBmatcher.cc:1474-1601
+ * mode 6: SearchByProjection(KeyFrame*, cv::Mat Scw, ...)                 src/ORBmatcher.cc:292-405
+ * Per query: (u, v, radius), level window [minLevel,maxLevel] with GetFeaturesInArea's
+ * convention, descriptor, angle (modes 4/5), valid, obs_pos (MapPoint::Observations()>0).
+ * t_occ (in/out, nt): train feature must be skipped.  assign (in/out, nt): query index
+ * holding train feature t, -1 = NULL. */
+typedef struct {
+    int32_t mode;
+    float nnratio;
+    int32_t check_ori;
+    int32_t th_dist;
+} OrbmProjParams;
+int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
+                              const float* q_uvr, const int8_t* q_lvl,
+                              const uint8_t* qdesc, const float* qangle,
+                              const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                              const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un,
+                              const uint8_t* tdesc, int nt,
+                              uint8_t* t_occ, int32_t* assign, int* nmatches);
+
+/* GetFeaturesInArea on the device grid, for tests: out[cap] indices in reference order */
+int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const OrbxKeyPoint* keys_un, int n,
+                          float x, float y, float r, int minLevel, int maxLevel,
+                          int32_t* out, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,104 @@
+"""ctypes loader for liborbslamm_hip.so (the C ABI of include/orbslamm_hip.h).
+
+The library is the product: there is no Python/CPU compute path behind it.  If
+the shared object is missing this module raises -- loudly -- instead of falling
+back to anything."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+SO_PATH = os.path.join(_PKG, "liborbslamm_hip.so")
+SRC = os.path.join(_PKG, "csrc", "orbslamm_hip.hip")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+ORBX_MAX_LEVELS = 16
+ORBX_PROF_MAX = 16
+ORBX_OK, ORBX_E_INVALID, ORBX_E_NO_DEVICE, ORBX_E_HIP, ORBX_E_CAPACITY, ORBX_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class OrbxParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scaleFactor", C.c_float), ("nlevels", C.c_int32),
+                ("iniThFAST", C.c_int32), ("minThFAST", C.c_int32)]
+
+
+class OrbxProfile(C.Structure):
+    _fields_ = [("n", C.c_int32), ("name", C.c_char_p * ORBX_PROF_MAX), ("ms", C.c_double * ORBX_PROF_MAX),
+                ("launches", C.c_int64 * ORBX_PROF_MAX)]
+
+
+class OrbmFeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("start", C.c_void_p), ("idx", C.c_void_p)]
+
+
+class OrbmGrid(C.Structure):
+    _fields_ = [("minX", C.c_float), ("minY", C.c_float), ("invW", C.c_float), ("invH", C.c_float),
+                ("cols", C.c_int32), ("rows", C.c_int32)]
+
+
+class OrbmProjParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("nnratio", C.c_float), ("check_ori", C.c_int32), ("th_dist", C.c_int32)]
+
+
+# every symbol include/orbslamm_hip.h declares (tests check that all of them resolve)
+EXPORTS = [
+    "orbx_last_error", "orbx_device_count", "orbx_create", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
+    "orbx_scale_tables", "orbx_features_per_level", "orbx_umax", "orbx_max_keypoints", "orbx_extract",
+    "orbx_extract_batch", "orbx_extract_batch_device", "orbx_device_results", "orbx_download",
+    "orbx_pyramid_level", "orbx_level_candidates", "orbx_sync", "orbx_match_prev_batch_device",
+    "orbx_device_matches", "orbx_download_matches", "orbx_reset_stream", "orbx_profile_enable",
+    "orbx_profile_read", "orbm_create", "orbm_destroy", "orbm_distance_matrix", "orbm_match_bruteforce",
+    "orbm_search_by_bow", "orbm_search_by_projection", "orbm_features_in_area",
+]
+
+
+def build(force=False):
+    """hipcc the extension in-tree for gfx950 (cross-compiles without a GPU)."""
+    deps = [os.path.join(_PKG, "csrc", f) for f in os.listdir(os.path.join(_PKG, "csrc"))]
+    deps.append(os.path.join(_ROOT, "include", "orbslamm_hip.h"))
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", SO_PATH, SRC]
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError("liborbslamm_hip.so is missing (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                               "there is no CPU fallback for the ORB front-end")
+        L = C.CDLL(SO_PATH)
+        L.orbx_last_error.restype = C.c_char_p
+        L.orbx_scale_factor.restype = C.c_float
+        for name in EXPORTS:
+            getattr(L, name)
+        L.orbx_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+class OrbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbslamm_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise OrbError(rc, lib().orbx_last_error().decode(errors="replace"))
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None

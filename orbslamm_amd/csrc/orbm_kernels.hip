@@ -1,0 +1,504 @@
+// orbm_kernels.hip -- gfx950 kernels of the ORBmatcher hot path (Hamming search).
+//
+// Reference: /root/reference/SingleRobotScenario/src/ORBmatcher.cc
+//   DescriptorDistance :1649-1665, acceptance/ratio :230-232, rotation histogram
+//   :238-248, ComputeThreeMaxima :1603-1644, pruning :269-287.
+// 256-bit descriptors are 8 dwords; distance = 8 x (v_xor + v_bcnt).  One lane owns
+// one query and keeps (best, second, index); the train descriptor is wave-uniform
+// and comes in through scalar loads, so the inner loop is pure VALU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace orbm {
+
+constexpr int kHistoLength = 30;  // ORBmatcher.cc:39
+
+struct MatchIO {
+    const uint8_t* desc;     // slot s at desc + s*descPitch, rows of 32 bytes
+    int64_t descPitch;
+    const float* ang;        // angle of feature i in slot s: ang[s*angPitch + i*angStride]
+    int64_t angPitch;
+    int32_t angStride;
+    const int32_t* count;    // features per slot
+};
+
+__device__ __forceinline__ int hamming256(const uint32_t q[8], const uint32_t* __restrict__ t)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d += __popc(q[i] ^ t[i]);
+    return d;
+}
+
+// ORBmatcher.cc:238-245: factor = 1.0f/HISTO_LENGTH (sic), round() half away from zero
+__device__ __forceinline__ int rot_bin(float aq, float at)
+{
+    constexpr float factor = 1.0f / kHistoLength;
+    float rot = __fsub_rn(aq, at);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin == kHistoLength) bin = 0;
+    return bin;
+}
+
+// query slot = qslot0 + blockIdx.y, train slot = tslot0 + blockIdx.y
+__global__ __launch_bounds__(256) void k_match_best2(MatchIO q, MatchIO t, int qslot0, int tslot0,
+                                                    float nnratio, int thLow, int checkOri,
+                                                    int32_t* __restrict__ match, int64_t matchPitch,
+                                                    uint8_t* __restrict__ binOf,
+                                                    int32_t* __restrict__ hist /* [frames][32] */)
+{
+    const int f = blockIdx.y;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int nq = q.count[qslot0 + f], nt = t.count[tslot0 + f];
+    if (blockIdx.x * 256 >= nq) return;
+    const uint8_t* qd = q.desc + (int64_t)(qslot0 + f) * q.descPitch;
+    const uint32_t* td = (const uint32_t*)(t.desc + (int64_t)(tslot0 + f) * t.descPitch);
+    uint32_t qw[8];
+    {
+        const int qq = qi < nq ? qi : nq - 1;
+        const uint4 a = ((const uint4*)(qd + (int64_t)qq * 32))[0];
+        const uint4 b = ((const uint4*)(qd + (int64_t)qq * 32))[1];
+        qw[0] = a.x; qw[1] = a.y; qw[2] = a.z; qw[3] = a.w;
+        qw[4] = b.x; qw[5] = b.y; qw[6] = b.z; qw[7] = b.w;
+    }
+    int best1 = 256, best2 = 256, bestIdx = -1;
+    for (int j = 0; j < nt; j++) {
+        const int d = hamming256(qw, td + 8 * j);
+        if (d < best1) { best2 = best1; best1 = d; bestIdx = j; }
+        else if (d < best2) best2 = d;
+    }
+    if (qi >= nq) return;
+    int m = -1;
+    if (best1 <= thLow && (float)best1 < __fmul_rn(nnratio, (float)best2)) {  // :230-232
+        m = bestIdx;
+        if (checkOri) {
+            const float aq = q.ang[(int64_t)(qslot0 + f) * q.angPitch + (int64_t)qi * q.angStride];
+            const float at = t.ang[(int64_t)(tslot0 + f) * t.angPitch + (int64_t)bestIdx * t.angStride];
+            const int bin = rot_bin(aq, at);
+            binOf[(int64_t)f * matchPitch + qi] = (uint8_t)bin;
+            atomicAdd(&hist[f * 32 + bin], 1);
+        }
+    }
+    match[(int64_t)f * matchPitch + qi] = m;
+}
+
+// ComputeThreeMaxima + pruning, one workgroup per frame; leaves hist zeroed for the next call
+__global__ __launch_bounds__(256) void k_match_prune(MatchIO q, int qslot0, int checkOri,
+                                                    int32_t* __restrict__ match, int64_t matchPitch,
+                                                    const uint8_t* __restrict__ binOf,
+                                                    int32_t* __restrict__ hist, int32_t* __restrict__ nmatch)
+{
+    __shared__ int sh[32];
+    __shared__ int sInd[3];
+    __shared__ int sCnt;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int nq = q.count[qslot0 + f];
+    if (tid < 32) { sh[tid] = hist[f * 32 + tid]; hist[f * 32 + tid] = 0; }
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < kHistoLength; i++) {  // :1609-1633
+            const int s = sh[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+    }
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < nq; i += 256) {
+        int m = match[(int64_t)f * matchPitch + i];
+        if (m >= 0 && checkOri) {
+            const int bin = binOf[(int64_t)f * matchPitch + i];
+            if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) {
+                m = -1;
+                match[(int64_t)f * matchPitch + i] = -1;
+            }
+        }
+        local += m >= 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if ((tid & 63) == 0) atomicAdd(&sCnt, local);
+    __syncthreads();
+    if (tid == 0) nmatch[f] = sCnt;
+}
+
+// full distance matrix (DescriptorDistance for every pair)
+__global__ __launch_bounds__(256) void k_distance_matrix(const uint8_t* __restrict__ qd, int nq,
+                                                        const uint8_t* __restrict__ td, int nt,
+                                                        int32_t* __restrict__ out)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= nq) return;
+    const int qq = qi < nq ? qi : nq - 1;
+    uint32_t qw[8];
+    const uint32_t* qp = (const uint32_t*)(qd + (int64_t)qq * 32);
+#pragma unroll
+    for (int i = 0; i < 8; i++) qw[i] = qp[i];
+    const uint32_t* tp = (const uint32_t*)td;
+    for (int j = blockIdx.y; j < nt; j += gridDim.y) {
+        const int d = hamming256(qw, tp + 8 * j);
+        if (qi < nq) out[(int64_t)qi * nt + j] = d;
+    }
+}
+
+
+// ------------------------------------------------------------------ SearchByBoW (greedy inside a vocabulary node)
+// A train feature sits in exactly one node of its FeatureVector, so matched node
+// pairs are independent; inside a pair the reference walks the query list in order
+// and skips train features matched earlier in the call (ORBmatcher.cc:205-211,
+// :574-579).  One wave per node pair: queries sequential, candidates lane-parallel,
+// top-2 by (distance, scan position) so ties resolve like the serial scan.
+struct BowArgs {
+    const uint8_t* qdesc; const float* qang; const uint8_t* qvalid;
+    const uint8_t* tdesc; const float* tang; const uint8_t* tvalid;
+    const int32_t* qstart; const int32_t* qidx;   // CSR of the query feature vector
+    const int32_t* tstart; const int32_t* tidx;   // CSR of the train feature vector
+    const int32_t* pairQ; const int32_t* pairT;   // matched node pairs (host lock-step walk :180-266)
+    uint8_t* matched;                              // per train feature, zero-initialised
+    int32_t* match; uint8_t* binOf; int32_t* hist; // outputs
+    float nnratio; int32_t thLow; int32_t checkOri; int32_t outByTrain;
+};
+
+__device__ __forceinline__ void top2_merge(uint32_t& k1, uint32_t& k2, uint32_t o1, uint32_t o2)
+{
+    const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+    k2 = min(hi, min(k2, o2));
+    k1 = lo;
+}
+
+__global__ __launch_bounds__(64) void k_bow_pairs(BowArgs a)
+{
+    const int lane = threadIdx.x;
+    const int nodeQ = a.pairQ[blockIdx.x], nodeT = a.pairT[blockIdx.x];
+    const int qs = a.qstart[nodeQ], qe = a.qstart[nodeQ + 1];
+    const int ts = a.tstart[nodeT], te = a.tstart[nodeT + 1];
+    for (int iq = qs; iq < qe; iq++) {
+        const int q = a.qidx[iq];
+        if (a.qvalid && !a.qvalid[q]) continue;  // wave-uniform
+        uint32_t qw[8];
+        const uint32_t* qp = (const uint32_t*)(a.qdesc + (int64_t)q * 32);
+#pragma unroll
+        for (int i = 0; i < 8; i++) qw[i] = qp[i];
+        // key = dist << 22 | scan position (dist <= 256, position < 2^22)
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        for (int it = ts + lane; it < te; it += 64) {
+            const int t = a.tidx[it];
+            if (a.matched[t]) continue;
+            if (a.tvalid && !a.tvalid[t]) continue;
+            const int d = hamming256(qw, (const uint32_t*)(a.tdesc + (int64_t)t * 32));
+            const uint32_t key = ((uint32_t)d << 22) | (uint32_t)(it - ts);
+            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const uint32_t o1 = __shfl_xor(k1, dd), o2 = __shfl_xor(k2, dd);
+            top2_merge(k1, k2, o1, o2);
+        }
+        const int best1 = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 22);
+        const int best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 22);
+        if (best1 <= a.thLow && (float)best1 < __fmul_rn(a.nnratio, (float)best2)) {
+            const int t = a.tidx[ts + (int)(k1 & 0x3FFFFFu)];
+            if (lane == 0) {
+                a.matched[t] = 1;
+                const int o = a.outByTrain ? t : q;
+                a.match[o] = a.outByTrain ? q : t;
+                if (a.checkOri) {
+                    const int bin = rot_bin(a.qang[q], a.tang[t]);
+                    a.binOf[o] = (uint8_t)bin;
+                    atomicAdd(&a.hist[bin], 1);
+                }
+            }
+        }
+        __syncthreads();  // matched[] visible to the whole wave before the next query
+    }
+}
+
+// three maxima + pruning over a flat match array (same rule as k_match_prune), one workgroup
+__global__ __launch_bounds__(256) void k_prune_flat(int32_t* __restrict__ match, int n, int checkOri,
+                                                   const uint8_t* __restrict__ binOf, int32_t* __restrict__ hist,
+                                                   int32_t* __restrict__ nmatch)
+{
+    __shared__ int sh[32];
+    __shared__ int sInd[3];
+    __shared__ int sCnt;
+    const int tid = threadIdx.x;
+    if (tid < 32) { sh[tid] = hist[tid]; hist[tid] = 0; }
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < kHistoLength; i++) {
+            const int s = sh[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+    }
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < n; i += 256) {
+        int m = match[i];
+        if (m >= 0 && checkOri) {
+            const int bin = binOf[i];
+            if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) { m = -1; match[i] = -1; }
+        }
+        local += m >= 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if ((tid & 63) == 0) atomicAdd(&sCnt, local);
+    __syncthreads();
+    if (tid == 0) *nmatch = sCnt;
+}
+
+// ------------------------------------------------------------------ Frame grid (Frame.cc:230-245, 327-392)
+struct GridDev { float minX, minY, invW, invH; int32_t cols, rows; };
+struct KeyDev { float x, y, size, angle, response; int32_t octave, class_id; };
+
+__device__ __forceinline__ bool pos_in_grid(const GridDev& g, float x, float y, int& px, int& py)
+{
+    px = (int)roundf(__fmul_rn(__fsub_rn(x, g.minX), g.invW));  // Frame.cc:384-385
+    py = (int)roundf(__fmul_rn(__fsub_rn(y, g.minY), g.invH));
+    return !(px < 0 || px >= g.cols || py < 0 || py >= g.rows);
+}
+
+__global__ void k_grid_count(GridDev g, const KeyDev* __restrict__ keys, int n, int32_t* __restrict__ cellCnt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int px, py;
+    if (pos_in_grid(g, keys[i].x, keys[i].y, px, py)) atomicAdd(&cellCnt[px * g.rows + py], 1);
+}
+
+// exclusive scan of cellCnt (ncell entries) into cellStart (ncell+1), one workgroup of 1024
+__global__ __launch_bounds__(1024) void k_scan_small(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? in[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; w++) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+        if (i < n) out[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 0) carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+__global__ void k_grid_fill(GridDev g, const KeyDev* __restrict__ keys, int n, const int32_t* __restrict__ cellStart,
+                            int32_t* __restrict__ cellFill, int32_t* __restrict__ cellIdx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int px, py;
+    if (pos_in_grid(g, keys[i].x, keys[i].y, px, py)) {
+        const int c = px * g.rows + py;
+        cellIdx[cellStart[c] + atomicAdd(&cellFill[c], 1)] = i;
+    }
+}
+
+// restore insertion order (ascending feature index) inside every cell
+__global__ void k_grid_sort(int ncell, const int32_t* __restrict__ cellStart, int32_t* __restrict__ cellIdx)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const int s = cellStart[c], e = cellStart[c + 1];
+    for (int i = s + 1; i < e; i++) {
+        const int v = cellIdx[i];
+        int j = i - 1;
+        while (j >= s && cellIdx[j] > v) { cellIdx[j + 1] = cellIdx[j]; j--; }
+        cellIdx[j + 1] = v;
+    }
+}
+
+// GetFeaturesInArea: calls f(featureIndex) in reference order (ix outer, iy inner, insertion order)
+template <class F>
+__device__ __forceinline__ void for_each_in_area(const GridDev& g, const KeyDev* __restrict__ keys,
+                                                 const int32_t* __restrict__ cellStart, const int32_t* __restrict__ cellIdx,
+                                                 float x, float y, float r, int minLevel, int maxLevel, F f)
+{
+    int nMinCellX = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW));
+    if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= g.cols) return;
+    int nMaxCellX = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW));
+    if (nMaxCellX > g.cols - 1) nMaxCellX = g.cols - 1;
+    if (nMaxCellX < 0) return;
+    int nMinCellY = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH));
+    if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= g.rows) return;
+    int nMaxCellY = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH));
+    if (nMaxCellY > g.rows - 1) nMaxCellY = g.rows - 1;
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * g.rows + iy;
+            for (int j = cellStart[c]; j < cellStart[c + 1]; j++) {
+                const int i = cellIdx[j];
+                const KeyDev& kp = keys[i];
+                if (bCheckLevels) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                const float distx = __fsub_rn(kp.x, x), disty = __fsub_rn(kp.y, y);
+                if (fabsf(distx) < r && fabsf(disty) < r) f(i);
+            }
+        }
+}
+
+// ------------------------------------------------------------------ SearchByProjection family
+struct ProjArgs {
+    GridDev grid;
+    const KeyDev* tkeys; const int32_t* cellStart; const int32_t* cellIdx;
+    const float* quvr; const int8_t* qlvl; const uint8_t* qdesc; const float* qang;
+    const uint8_t* qvalid; const uint8_t* qobs;
+    const uint8_t* tdesc;
+    int32_t nq, nt;
+    int32_t* candCnt;      // [nq]   pass 1
+    int32_t* candOff;      // [nq+1] after scan
+    uint32_t* candKey;     // CSR: dist<<22 | pos<<4 | octave   (pos = rank in the reference's scan order)
+    int32_t* candIdx;      // CSR: train feature index
+    uint8_t* tocc; int32_t* assign; int32_t* nmatch;
+    int32_t* pushT; uint8_t* pushBin;   // rotation-histogram pushes, replayed by the pruning step
+    int32_t mode; float nnratio; int32_t checkOri; int32_t thDist;
+};
+
+// pass 0: count candidates per query; pass 1: fill (index, distance key)
+__global__ void k_proj_candidates(ProjArgs a, int pass)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.nq) return;
+    if (a.qvalid && !a.qvalid[q]) { if (pass == 0) a.candCnt[q] = 0; return; }
+    const float u = a.quvr[3 * q], v = a.quvr[3 * q + 1], r = a.quvr[3 * q + 2];
+    const int minL = a.qlvl[2 * q], maxL = a.qlvl[2 * q + 1];
+    if (pass == 0) {
+        int cnt = 0;
+        for_each_in_area(a.grid, a.tkeys, a.cellStart, a.cellIdx, u, v, r, minL, maxL, [&](int) { cnt++; });
+        a.candCnt[q] = cnt;
+    } else {
+        uint32_t qw[8];
+        const uint32_t* qp = (const uint32_t*)(a.qdesc + (int64_t)q * 32);
+#pragma unroll
+        for (int i = 0; i < 8; i++) qw[i] = qp[i];
+        int pos = 0;
+        const int base = a.candOff[q];
+        for_each_in_area(a.grid, a.tkeys, a.cellStart, a.cellIdx, u, v, r, minL, maxL, [&](int t) {
+            const int d = hamming256(qw, (const uint32_t*)(a.tdesc + (int64_t)t * 32));
+            a.candKey[base + pos] = ((uint32_t)d << 22) | ((uint32_t)(pos & 0x3FFFF) << 4) | (uint32_t)(a.tkeys[t].octave & 15);
+            a.candIdx[base + pos] = t;
+            pos++;
+        });
+    }
+}
+
+// sequential resolve in the reference's query order; one wave, occupancy bitmap in LDS
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a, int bitmapWords)
+{
+    extern __shared__ uint32_t occ[];  // nt bits
+    __shared__ int hist[32];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < bitmapWords; i += 64) {
+        uint32_t w = 0;
+        for (int b = 0; b < 32; b++) { const int t = i * 32 + b; if (t < a.nt && a.tocc[t]) w |= 1u << b; }
+        occ[i] = w;
+    }
+    if (lane < 32) hist[lane] = 0;
+    __syncthreads();
+    const bool useRot = a.checkOri && (a.mode == 4 || a.mode == 5);
+    // pushes into the rotation histogram are replayed for pruning: (train index, bin), one per accepted query
+    int nPush = 0, nmatches = 0;
+    int32_t* pushT = a.pushT;
+    uint8_t* pushBin = a.pushBin;
+    for (int q = 0; q < a.nq; q++) {
+        const int cs = a.candOff[q], ce = a.candOff[q + 1];
+        if (ce == cs) continue;
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        for (int c = cs + lane; c < ce; c += 64) {
+            const int t = a.candIdx[c];
+            if (occ[t >> 5] & (1u << (t & 31))) continue;
+            const uint32_t key = a.candKey[c];
+            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const uint32_t o1 = __shfl_xor(k1, dd), o2 = __shfl_xor(k2, dd);
+            top2_merge(k1, k2, o1, o2);
+        }
+        if (k1 == 0xFFFFFFFFu) continue;  // bestDist stays 256 > every threshold
+        const int best = (int)(k1 >> 22);
+        const int best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 22);
+        const int bestLevel = (int)(k1 & 15), bestLevel2 = k2 == 0xFFFFFFFFu ? -1 : (int)(k2 & 15);
+        if (best <= a.thDist) {
+            if (a.mode == 3 && bestLevel == bestLevel2 && (float)best > __fmul_rn(a.nnratio, (float)best2)) continue;
+            const int t = a.candIdx[cs + (int)((k1 >> 4) & 0x3FFFF)];
+            nmatches++;
+            if (lane == 0) {
+                a.assign[t] = q;
+                const bool block = (a.mode == 3 || a.mode == 4) ? (!a.qobs || a.qobs[q]) : true;
+                if (block) occ[t >> 5] |= 1u << (t & 31);
+                if (useRot) {
+                    const int bin = rot_bin(a.qang[q], a.tkeys[t].angle);
+                    pushT[nPush] = t;
+                    pushBin[nPush] = (uint8_t)bin;
+                    hist[bin]++;
+                }
+            }
+            if (useRot) nPush++;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (useRot && lane == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < kHistoLength; i++) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        for (int p = 0; p < nPush; p++) {
+            const int bin = pushBin[p];
+            if (bin != ind1 && bin != ind2 && bin != ind3) { a.assign[pushT[p]] = -1; nmatches--; }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < bitmapWords; i += 64) {
+        const uint32_t w = occ[i];
+        for (int b = 0; b < 32; b++) { const int t = i * 32 + b; if (t < a.nt) a.tocc[t] = (w >> b) & 1; }
+    }
+    if (lane == 0) *a.nmatch = nmatches;
+}
+
+// one-query GetFeaturesInArea (tests)
+__global__ void k_features_in_area(GridDev g, const KeyDev* keys, const int32_t* cellStart, const int32_t* cellIdx,
+                                   float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap, int32_t* nout)
+{
+    int n = 0;
+    for_each_in_area(g, keys, cellStart, cellIdx, x, y, r, minLevel, maxLevel, [&](int i) { if (n < cap) out[n] = i; n++; });
+    *nout = n;
+}
+
+}  // namespace orbm

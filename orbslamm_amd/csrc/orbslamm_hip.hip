@@ -1,0 +1,1111 @@
+// orbslamm_hip.hip -- C ABI of the MI355X ORB front-end (see include/orbslamm_hip.h).
+//
+// Host side of the extractor: per-instance tables exactly as the reference
+// constructor builds them (/root/reference/SingleRobotScenario/src/ORBextractor.cc:410-470),
+// level / cell / quadtree-root geometry (:765-806, :543-563), cv::resize coefficient
+// tables, one-time device allocation, kernel launches on the handle's stream.
+// No CPU compute path exists: without a HIP device every compute entry fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbslamm_hip.h"
+#include "orbx_common.hpp"
+
+#include "orbx_kernels.hip"
+#include "orbm_kernels.hip"
+
+using namespace orbx;
+
+static_assert(sizeof(OrbxKeyPoint) == 28, "cv::KeyPoint layout");
+static_assert(sizeof(OrbxKeyPointDev) == 28, "cv::KeyPoint layout");
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ORBX_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* orbx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int orbx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline int cv_round(double v) { return (int)lrint(v); }  // cvRound: half to even
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------ profiling
+enum ProfId { P_H2D = 0, P_RESIZE, P_FAST, P_DISTRIBUTE, P_BLUR, P_ORIENT_DESC, P_MATCH_BEST2, P_MATCH_PRUNE, P_D2H, P_COUNT };
+static const char* kProfNames[P_COUNT] = {"h2d", "k_resize", "k_fast", "k_distribute", "k_blur",
+                                          "k_orient_desc", "k_match_best2", "k_match_prune", "d2h"};
+struct ProfSpan { int id; hipEvent_t a, b; };
+
+struct Profiler {
+    bool on = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> pool;
+    double ms[P_COUNT] = {0};
+    int64_t launches[P_COUNT] = {0};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(int id, hipStream_t s)
+    {
+        if (!on) return;
+        ProfSpan sp{id, get(), get()};
+        (void)hipEventRecord(sp.a, s);
+        spans.push_back(sp);
+    }
+    void end(hipStream_t s)
+    {
+        if (!on) return;
+        (void)hipEventRecord(spans.back().b, s);
+    }
+    void collect()
+    {
+        for (auto& sp : spans) {
+            (void)hipEventSynchronize(sp.b);
+            float t = 0;
+            (void)hipEventElapsedTime(&t, sp.a, sp.b);
+            ms[sp.id] += t;
+            launches[sp.id]++;
+            pool.push_back(sp.a);
+            pool.push_back(sp.b);
+        }
+        spans.clear();
+    }
+    void destroy()
+    {
+        collect();
+        for (auto e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+// ------------------------------------------------------------------ handle
+struct orbx_handle {
+    OrbxParams prm;
+    int device = -1;          // -1: host-only handle (tables, no compute)
+    int maxW = 0, maxH = 0, maxB = 0;
+    int nlevels = 0;
+    float mvScaleFactor[ORBX_MAXL], mvInvScaleFactor[ORBX_MAXL], mvLevelSigma2[ORBX_MAXL], mvInvLevelSigma2[ORBX_MAXL];
+    int mnFeaturesPerLevel[ORBX_MAXL];
+    int umax[16];
+
+    // geometry of the currently configured frame shape
+    Geom geom;
+    int curW = 0, curH = 0;
+    std::vector<Cell> cells;
+    int tileStrideDw = 0, tileRows = 0;
+    int nodeCap = 0;
+    BlurTiles blurTiles;
+    KpBlocks kpBlocks;
+    int kpBlocksTotal = 0;
+
+    hipStream_t stream = nullptr;
+    // device buffers (sized for maxW x maxH x maxB at create)
+    Geom* d_geom = nullptr;
+    Cell* d_cells = nullptr; size_t cellsCap = 0;
+    short4* d_tabs = nullptr; size_t tabsCap = 0;
+    ResizeTabs tabs;
+    uint8_t* d_img = nullptr; size_t imgFrameBytes = 0; int imgStride = 0;  // staging for host frames
+    uint8_t* d_pyr = nullptr; size_t pyrCapFrame = 0;
+    uint8_t* d_blur = nullptr; size_t blurCapFrame = 0;
+    uint64_t* d_candRaw = nullptr; uint64_t* d_candA = nullptr; uint64_t* d_candB = nullptr; size_t candCapFrame = 0;
+    int32_t* d_candCount = nullptr;
+    uint64_t* d_kept = nullptr; size_t keptCapFrame = 0;
+    int32_t* d_keptCount = nullptr;
+    int32_t* d_err = nullptr;
+    int maxKp = 0;                       // output slot capacity (fixed at create)
+    OrbxKeyPointDev* d_kps = nullptr;    // [maxB+1][maxKp]  slot 0 = previous frame of the stream
+    uint8_t* d_desc = nullptr;           // [maxB+1][maxKp][32]
+    int32_t* d_count = nullptr;          // [maxB+1]
+    int32_t* d_match = nullptr;          // [maxB][maxKp]
+    uint8_t* d_binOf = nullptr;          // [maxB][maxKp]
+    int32_t* d_hist = nullptr;           // [maxB][32]
+    int32_t* d_nmatch = nullptr;         // [maxB]
+    uint8_t* h_pinned = nullptr; size_t pinnedBytes = 0;
+    int lastB = 0;
+    FrameSrc lastSrc{};
+    bool havePrev = false;
+    Profiler prof;
+};
+
+// ------------------------------------------------------------------ tables, ref :410-470
+static int init_tables(orbx_handle* h)
+{
+    const OrbxParams& p = h->prm;
+    if (p.nlevels < 1 || p.nlevels > ORBX_MAXL || p.nfeatures < 1 || !(p.scaleFactor > 1.0f))
+        return fail(ORBX_E_INVALID, "bad ORBextractor parameters");
+    const int L = p.nlevels;
+    h->nlevels = L;
+    const double scaleFactor = (double)p.scaleFactor;  // member is double (ORBextractor.h:93)
+    h->mvScaleFactor[0] = 1.0f;
+    h->mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < L; i++) {
+        h->mvScaleFactor[i] = (float)((double)h->mvScaleFactor[i - 1] * scaleFactor);
+        h->mvLevelSigma2[i] = h->mvScaleFactor[i] * h->mvScaleFactor[i];
+    }
+    for (int i = 0; i < L; i++) {
+        h->mvInvScaleFactor[i] = 1.0f / h->mvScaleFactor[i];
+        h->mvInvLevelSigma2[i] = 1.0f / h->mvLevelSigma2[i];
+    }
+    const float factor = (float)(1.0 / scaleFactor);
+    float nDesired = (float)p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) {
+        h->mnFeaturesPerLevel[l] = cv_round(nDesired);
+        sum += h->mnFeaturesPerLevel[l];
+        nDesired *= factor;
+    }
+    h->mnFeaturesPerLevel[L - 1] = std::max(p.nfeatures - sum, 0);
+
+    int v, v0;
+    const int vmax = (int)std::floor((double)((float)kHalfPatch * std::sqrt(2.f) / 2 + 1));
+    const int vmin = (int)std::ceil((double)((float)kHalfPatch * std::sqrt(2.f) / 2));
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v < 16; v++) h->umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) h->umax[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+        h->umax[v] = v0;
+        ++v0;
+    }
+    return ORBX_OK;
+}
+
+// geometry for a frame shape; fills geom/cells/tables (host side only)
+struct HostGeom {
+    Geom g;
+    std::vector<Cell> cells;
+    std::vector<short4> tabs;          // all x/y tables back to back
+    int xoff[ORBX_MAXL], yoff[ORBX_MAXL];
+    int tileStrideDw, tileRows, nodeCap;
+    BlurTiles bt;
+    int blurTilesTotal;
+    KpBlocks kb;
+    int kbTotal;
+};
+
+static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
+{
+    Geom& g = out.g;
+    memset(&g, 0, sizeof g);
+    g.nlevels = h->nlevels;
+    g.w0 = w; g.h0 = h0;
+    g.iniTh = h->prm.iniThFAST; g.minTh = h->prm.minThFAST;
+    memcpy(g.umax, h->umax, sizeof g.umax);
+    if (w > 8191 || h0 > 8191) return fail(ORBX_E_UNSUPPORTED, "frame larger than 8191 px");
+    out.cells.clear();
+    out.tabs.clear();
+    int pyrOff = 0, blurOff = 0, candOff = 0, keptOff = 0, maxRoiW = 8, maxRoiH = 8, nodeCap = 16;
+    for (int l = 0; l < g.nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        const float scale = h->mvInvScaleFactor[l];
+        L.w = cv_round((double)((float)w * scale));   // :1111-1112
+        L.h = cv_round((double)((float)h0 * scale));
+        if (L.w < 1 || L.h < 1) return fail(ORBX_E_UNSUPPORTED, "pyramid level %d is empty", l);
+        L.stride = align_up(L.w, 64);
+        L.pyrOff = pyrOff;
+        if (l > 0) pyrOff += align_up(L.stride * L.h, 256);
+        L.blurStride = align_up(L.w, 64);
+        L.blurOff = blurOff;
+        blurOff += align_up(L.blurStride * L.h, 256);
+        L.scale = h->mvScaleFactor[l];
+        L.kpSize = (float)(int)((float)kPatchSize * h->mvScaleFactor[l]);  // :837
+        L.nFeat = h->mnFeaturesPerLevel[l];
+
+        // FAST window and cell grid, :773-787
+        const int minBX = kMinBorder, minBY = kMinBorder;
+        const int maxBX = L.w - kEdgeThreshold + 3, maxBY = L.h - kEdgeThreshold + 3;
+        L.winW = maxBX - minBX; L.winH = maxBY - minBY;
+        const float W = 30;
+        const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+        L.nCols = width > 0 ? (int)(width / W) : 0;
+        L.nRows = height > 0 ? (int)(height / W) : 0;
+        L.cellBase = (int)out.cells.size();
+        L.nCells = 0;
+        int candCap = 0;
+        if (L.nCols >= 1 && L.nRows >= 1) {
+            L.wCell = (int)std::ceil((double)(width / L.nCols));
+            L.hCell = (int)std::ceil((double)(height / L.nRows));
+            uint32_t seq = 0;
+            for (int i = 0; i < L.nRows; i++) {  // :789-806
+                const float iniY = (float)(minBY + i * L.hCell);
+                float maxY = iniY + L.hCell + 6;
+                if (iniY >= maxBY - 3) continue;
+                if (maxY > maxBY) maxY = (float)maxBY;
+                for (int j = 0; j < L.nCols; j++) {
+                    const float iniX = (float)(minBX + j * L.wCell);
+                    float maxX = iniX + L.wCell + 6;
+                    if (iniX >= maxBX - 6) continue;
+                    if (maxX > maxBX) maxX = (float)maxBX;
+                    Cell c;
+                    c.level = (uint16_t)l;
+                    c.x0 = (uint16_t)(int)iniX; c.y0 = (uint16_t)(int)iniY;
+                    c.w = (uint16_t)((int)maxX - (int)iniX); c.h = (uint16_t)((int)maxY - (int)iniY);
+                    c.ci = (uint16_t)i; c.cj = (uint16_t)j;
+                    c.seq = seq++;
+                    if (c.w < 7 || c.h < 7) continue;  // cv::FAST finds nothing in such a ROI
+                    if (c.w > 127 || c.h > 127 || c.seq >= 65536u)
+                        return fail(ORBX_E_UNSUPPORTED, "cell geometry out of range");
+                    out.cells.push_back(c);
+                    L.nCells++;
+                    candCap += ((c.w - 6 + 1) / 2) * ((c.h - 6 + 1) / 2);
+                    maxRoiW = std::max<int>(maxRoiW, c.w);
+                    maxRoiH = std::max<int>(maxRoiH, c.h);
+                }
+            }
+        }
+        L.candOff = candOff;
+        L.candCap = align_up(candCap + 8, 8);
+        candOff += L.candCap;
+        // quadtree roots, :543-545
+        L.nIni = 0; L.hX = 0.f;
+        if (L.winW > 0 && L.winH > 0) {
+            L.nIni = (int)roundf((float)(maxBX - minBX) / (float)(maxBY - minBY));
+            if (L.nIni >= 1) L.hX = (float)(maxBX - minBX) / (float)L.nIni;
+            else if (L.nCells > 0)
+                return fail(ORBX_E_UNSUPPORTED, "level %d: width/height < 0.5, the reference divides by zero (ORBextractor.cc:543-545)", l);
+        }
+        L.keptOff = keptOff;
+        L.keptCap = align_up(std::max(L.nFeat + 4, 4 * L.nIni) + 4, 4);
+        keptOff += L.keptCap;
+        nodeCap = std::max(nodeCap, L.keptCap + 8);
+    }
+    g.totalCells = (int)out.cells.size();
+    g.pyrFrameBytes = std::max(pyrOff, 256);
+    g.blurFrameBytes = blurOff;
+    g.candFrameRecs = candOff;
+    g.keptFrameRecs = keptOff;
+    g.maxKp = keptOff;
+    out.tileStrideDw = ((3 + maxRoiW + 3) / 4 + 1) | 1;  // odd dword stride
+    out.tileRows = maxRoiH;
+    out.nodeCap = align_up(nodeCap, 2);
+
+    // cv::resize INTER_LINEAR coefficient tables, levels >= 1
+    for (int l = 0; l < g.nlevels; l++) { out.xoff[l] = out.yoff[l] = 0; }
+    for (int l = 1; l < g.nlevels; l++) {
+        const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
+        const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+        const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+        if (scale_x == 2.0 && scale_y == 2.0)
+            return fail(ORBX_E_UNSUPPORTED, "scale factor 2: cv::resize switches to INTER_AREA (not on this path)");
+        out.xoff[l] = (int)out.tabs.size();
+        std::vector<short4> xt(dw);
+        int xmax = dw;
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)std::floor(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx + 1 >= sw) {
+                xmax = std::min(xmax, dx);
+                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            }
+            auto sat = [](float v) { long r = lrintf(v); return (short)(r > 32767 ? 32767 : (r < -32768 ? -32768 : r)); };
+            xt[dx] = make_short4((short)sx, sat((1.f - fx) * 2048), sat(fx * 2048), 0);
+        }
+        for (int dx = 0; dx < dw; dx++) xt[dx].w = dx < xmax ? 1 : 0;
+        out.tabs.insert(out.tabs.end(), xt.begin(), xt.end());
+        out.yoff[l] = (int)out.tabs.size();
+        for (int dy = 0; dy < dh; dy++) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = (int)std::floor(fy);
+            fy -= sy;
+            auto clip = [&](int y) { return y < 0 ? 0 : (y < sh ? y : sh - 1); };
+            auto sat = [](float v) { long r = lrintf(v); return (short)(r > 32767 ? 32767 : (r < -32768 ? -32768 : r)); };
+            out.tabs.push_back(make_short4((short)clip(sy), (short)clip(sy + 1), sat((1.f - fy) * 2048), sat(fy * 2048)));
+        }
+    }
+    // blur tiles (64x16) and orient/desc blocks (4 keypoints) per level
+    int tb = 0, kb = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        out.bt.base[l] = tb;
+        out.bt.tilesX[l] = (g.lv[l].w + 63) / 64;
+        tb += out.bt.tilesX[l] * ((g.lv[l].h + 15) / 16);
+        out.kb.base[l] = kb;
+        kb += (g.lv[l].keptCap + 3) / 4;
+    }
+    for (int l = g.nlevels; l <= ORBX_MAXL; l++) { out.bt.base[l] = tb; out.kb.base[l] = kb; }
+    out.blurTilesTotal = tb;
+    out.kbTotal = kb;
+    return ORBX_OK;
+}
+
+static size_t dist_lds_bytes(int cap) { return (size_t)(17 * cap + 8) * 4; }
+
+// ------------------------------------------------------------------ create / destroy
+static void free_device(orbx_handle* h)
+{
+    if (h->device < 0) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->prof.destroy();
+    void* ptrs[] = {h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
+                    h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
+                    h->d_match, h->d_binOf, h->d_hist, h->d_nmatch};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int max_batch, int device, orbx_t** out)
+{
+    if (!params || !out) return fail(ORBX_E_INVALID, "null argument");
+    *out = nullptr;
+    orbx_handle* h = new orbx_handle();
+    h->prm = *params;
+    int rc = init_tables(h);
+    if (rc) { delete h; return rc; }
+    h->device = device;
+    h->maxW = max_w; h->maxH = max_h; h->maxB = max_batch;
+    if (device < 0) { *out = h; return ORBX_OK; }  // host-only handle: tables and geometry queries
+    if (max_w < 1 || max_h < 1 || max_batch < 1) { delete h; return fail(ORBX_E_INVALID, "bad maximum shape"); }
+    int ndev = orbx_device_count();
+    if (ndev == 0) { delete h; return fail(ORBX_E_NO_DEVICE, "no HIP device visible: the ORB front-end has no CPU fallback"); }
+    if (device >= ndev) { delete h; return fail(ORBX_E_INVALID, "device %d out of range (%d visible)", device, ndev); }
+
+    HostGeom hg;
+    rc = build_geometry(h, max_w, max_h, hg);
+    if (rc) { delete h; return rc; }
+#define CRT(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int r_ = fail(ORBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); free_device(h); delete h; return r_; } } while (0)
+    CRT(hipSetDevice(device));
+    CRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t B = (size_t)max_batch;
+    // capacities with head-room so that smaller shapes (different cell layouts) also fit
+    h->cellsCap = hg.cells.size() * 2 + 64;
+    h->tabsCap = hg.tabs.size() * 2 + 64;
+    h->imgStride = align_up(max_w, 64);
+    h->imgFrameBytes = (size_t)h->imgStride * max_h;
+    h->pyrCapFrame = (size_t)hg.g.pyrFrameBytes + 4096;
+    h->blurCapFrame = (size_t)hg.g.blurFrameBytes + 4096;
+    h->candCapFrame = (size_t)hg.g.candFrameRecs + 1024;
+    h->keptCapFrame = (size_t)hg.g.keptFrameRecs + 64;
+    h->maxKp = hg.g.maxKp + 64;
+    CRT(hipMalloc(&h->d_geom, sizeof(Geom)));
+    CRT(hipMalloc(&h->d_cells, h->cellsCap * sizeof(Cell)));
+    CRT(hipMalloc(&h->d_tabs, h->tabsCap * sizeof(short4)));
+    CRT(hipMalloc(&h->d_img, h->imgFrameBytes * B));
+    CRT(hipMalloc(&h->d_pyr, h->pyrCapFrame * B));
+    CRT(hipMalloc(&h->d_blur, h->blurCapFrame * B));
+    CRT(hipMalloc(&h->d_candRaw, h->candCapFrame * B * sizeof(uint64_t)));
+    CRT(hipMalloc(&h->d_candA, h->candCapFrame * B * sizeof(uint64_t)));
+    CRT(hipMalloc(&h->d_candB, h->candCapFrame * B * sizeof(uint64_t)));
+    CRT(hipMalloc(&h->d_candCount, B * ORBX_MAXL * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_kept, h->keptCapFrame * B * sizeof(uint64_t)));
+    CRT(hipMalloc(&h->d_keptCount, B * ORBX_MAXL * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_err, sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_kps, (B + 1) * h->maxKp * sizeof(OrbxKeyPointDev)));
+    CRT(hipMalloc(&h->d_desc, (B + 1) * (size_t)h->maxKp * 32));
+    CRT(hipMalloc(&h->d_count, (B + 1) * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_match, B * h->maxKp * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_binOf, B * (size_t)h->maxKp));
+    CRT(hipMalloc(&h->d_hist, B * 32 * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_nmatch, B * sizeof(int32_t)));
+    CRT(hipMemset(h->d_err, 0, sizeof(int32_t)));
+    CRT(hipMemset(h->d_count, 0, (B + 1) * sizeof(int32_t)));
+    CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
+    CRT(hipMemset(h->d_nmatch, 0, B * sizeof(int32_t)));
+    h->pinnedBytes = std::max(h->imgFrameBytes * B, B * (size_t)h->maxKp * (sizeof(OrbxKeyPointDev) + 32 + 4) + 4096);
+    CRT(hipHostMalloc(&h->h_pinned, h->pinnedBytes));
+#undef CRT
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_destroy(orbx_t* h)
+{
+    if (!h) return;
+    free_device(h);
+    delete h;
+}
+
+extern "C" int orbx_levels(const orbx_t* h) { return h ? h->nlevels : 0; }
+extern "C" float orbx_scale_factor(const orbx_t* h) { return h ? (float)(double)h->prm.scaleFactor : 0.f; }
+extern "C" int orbx_scale_tables(const orbx_t* h, float* s, float* is, float* s2, float* is2)
+{
+    if (!h) return fail(ORBX_E_INVALID, "null handle");
+    for (int i = 0; i < h->nlevels; i++) {
+        if (s) s[i] = h->mvScaleFactor[i];
+        if (is) is[i] = h->mvInvScaleFactor[i];
+        if (s2) s2[i] = h->mvLevelSigma2[i];
+        if (is2) is2[i] = h->mvInvLevelSigma2[i];
+    }
+    return ORBX_OK;
+}
+extern "C" int orbx_features_per_level(const orbx_t* h, int32_t* out)
+{
+    if (!h || !out) return fail(ORBX_E_INVALID, "null argument");
+    for (int i = 0; i < h->nlevels; i++) out[i] = h->mnFeaturesPerLevel[i];
+    return ORBX_OK;
+}
+extern "C" int orbx_umax(const orbx_t* h, int32_t out[16])
+{
+    if (!h || !out) return fail(ORBX_E_INVALID, "null argument");
+    for (int i = 0; i < 16; i++) out[i] = h->umax[i];
+    return ORBX_OK;
+}
+extern "C" int orbx_max_keypoints(const orbx_t* h)
+{
+    if (!h) return 0;
+    if (h->device >= 0) return h->maxKp;
+    HostGeom hg;
+    if (h->maxW < 1 || h->maxH < 1 || build_geometry(h, h->maxW, h->maxH, hg)) return 0;
+    return hg.g.maxKp + 64;
+}
+
+// ------------------------------------------------------------------ shape configuration
+static int configure_shape(orbx_handle* h, int w, int hh)
+{
+    if (h->curW == w && h->curH == hh) return ORBX_OK;
+    if (w > h->maxW || hh > h->maxH) return fail(ORBX_E_INVALID, "frame %dx%d exceeds the handle's maximum %dx%d", w, hh, h->maxW, h->maxH);
+    HostGeom hg;
+    int rc = build_geometry(h, w, hh, hg);
+    if (rc) return rc;
+    if (hg.cells.size() > h->cellsCap || hg.tabs.size() > h->tabsCap || (size_t)hg.g.pyrFrameBytes > h->pyrCapFrame ||
+        (size_t)hg.g.blurFrameBytes > h->blurCapFrame || (size_t)hg.g.candFrameRecs > h->candCapFrame ||
+        (size_t)hg.g.keptFrameRecs > h->keptCapFrame || hg.g.maxKp > h->maxKp)
+        return fail(ORBX_E_INVALID, "frame %dx%d needs more scratch than the handle was created with", w, hh);
+    if (dist_lds_bytes(hg.nodeCap) > 156 * 1024)
+        return fail(ORBX_E_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree (%d nodes)", hg.nodeCap);
+    if (dist_lds_bytes(hg.nodeCap) > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)k_distribute, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dist_lds_bytes(hg.nodeCap)));
+    hg.g.maxKp = h->maxKp;  // output slots keep their create-time pitch
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_geom, &hg.g, sizeof(Geom), hipMemcpyHostToDevice));
+    if (!hg.cells.empty()) HIPCHK(hipMemcpy(h->d_cells, hg.cells.data(), hg.cells.size() * sizeof(Cell), hipMemcpyHostToDevice));
+    if (!hg.tabs.empty()) HIPCHK(hipMemcpy(h->d_tabs, hg.tabs.data(), hg.tabs.size() * sizeof(short4), hipMemcpyHostToDevice));
+    for (int l = 0; l < ORBX_MAXL; l++) {
+        h->tabs.xtab[l] = h->d_tabs + (l < hg.g.nlevels ? hg.xoff[l] : 0);
+        h->tabs.ytab[l] = h->d_tabs + (l < hg.g.nlevels ? hg.yoff[l] : 0);
+    }
+    h->geom = hg.g;
+    h->cells = hg.cells;
+    h->tileStrideDw = hg.tileStrideDw; h->tileRows = hg.tileRows; h->nodeCap = hg.nodeCap;
+    h->blurTiles = hg.bt; h->kpBlocks = hg.kb; h->kpBlocksTotal = hg.kbTotal;
+    h->geom.totalCells = hg.g.totalCells;
+    h->curW = w; h->curH = hh;
+    // a new shape starts a new stream
+    h->havePrev = false;
+    HIPCHK(hipMemset(h->d_count, 0, sizeof(int32_t)));
+    return ORBX_OK;
+}
+
+static int check_device(orbx_handle* h)
+{
+    if (!h) return fail(ORBX_E_INVALID, "null handle");
+    if (h->device < 0) return fail(ORBX_E_NO_DEVICE, "host-only handle: no HIP device bound, and there is no CPU fallback");
+    HIPCHK(hipSetDevice(h->device));
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------ the pipeline
+static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int hh, int stride, size_t pitch)
+{
+    int rc = configure_shape(h, w, hh);
+    if (rc) return rc;
+    if (B < 1 || B > h->maxB) return fail(ORBX_E_INVALID, "batch %d outside [1,%d]", B, h->maxB);
+    if (((uintptr_t)d_imgs & 3) || (stride & 3) || (pitch & 3) || stride < w)
+        return fail(ORBX_E_INVALID, "device frames need 4-byte aligned base/stride/pitch and stride >= width");
+    const Geom& g = h->geom;
+    hipStream_t s = h->stream;
+    FrameSrc src;
+    src.img0 = d_imgs; src.stride0 = stride; src.pitch0 = (int64_t)pitch;
+    src.pyr = h->d_pyr; src.blur = h->d_blur;
+    // the pyramid/blur buffers use the geometry's per-frame sizes as pitch
+    HIPCHK(hipMemsetAsync(h->d_candCount, 0, (size_t)B * g.nlevels * sizeof(int32_t), s));
+
+    for (int l = 1; l < g.nlevels; l++) {
+        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, B), block(64, 4, 1);
+        h->prof.begin(P_RESIZE, s);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, s, h->d_geom, src, h->tabs, l);
+        h->prof.end(s);
+    }
+    if (g.totalCells > 0) {
+        const size_t lds = (size_t)2 * h->tileRows * h->tileStrideDw * 4;
+        h->prof.begin(P_FAST, s);
+        hipLaunchKernelGGL(k_fast, dim3(g.totalCells, B), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
+                           h->d_candCount, h->d_err, h->tileStrideDw, h->tileRows);
+        h->prof.end(s);
+    }
+    h->prof.begin(P_DISTRIBUTE, s);
+    hipLaunchKernelGGL(k_distribute, dim3(g.nlevels, B), dim3(kDistThreads), dist_lds_bytes(h->nodeCap), s, h->d_geom,
+                       h->d_candRaw, h->d_candA, h->d_candB, h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->nodeCap);
+    h->prof.end(s);
+    h->prof.begin(P_BLUR, s);
+    hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], B), dim3(256), 0, s, h->d_geom, src, h->blurTiles);
+    h->prof.end(s);
+    h->prof.begin(P_ORIENT_DESC, s);
+    hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, B), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
+                       h->d_keptCount, h->d_kps + h->maxKp, h->d_desc + (size_t)h->maxKp * 32, h->d_count + 1);
+    h->prof.end(s);
+    HIPCHK(hipGetLastError());
+    h->lastB = B;
+    h->lastSrc = src;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int B, int w, int hh, int stride, size_t pitch)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!d_imgs || w < 1 || hh < 1) return fail(ORBX_E_INVALID, "empty device frame");
+    return run_extract(h, d_imgs, B, w, hh, stride, pitch);
+}
+
+extern "C" int orbx_device_results(orbx_t* h, OrbxKeyPoint** d_kps, uint8_t** d_desc, int32_t** d_counts, int* cap)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (d_kps) *d_kps = (OrbxKeyPoint*)(h->d_kps + h->maxKp);
+    if (d_desc) *d_desc = h->d_desc + (size_t)h->maxKp * 32;
+    if (d_counts) *d_counts = h->d_count + 1;
+    if (cap) *cap = h->maxKp;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_sync(orbx_t* h)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int32_t err = 0;
+    HIPCHK(hipMemcpy(&err, h->d_err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+        (void)hipMemset(h->d_err, 0, sizeof err);
+        return fail(ORBX_E_CAPACITY, "device scratch overflow (flags 0x%x)", err);
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_download(orbx_t* h, int frame, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    int rc = orbx_sync(h);
+    if (rc) return rc;
+    if (frame < 0 || frame >= h->lastB) return fail(ORBX_E_INVALID, "frame %d not in the last batch", frame);
+    int32_t n = 0;
+    HIPCHK(hipMemcpy(&n, h->d_count + 1 + frame, sizeof n, hipMemcpyDeviceToHost));
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(ORBX_E_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
+    if (n > 0) {
+        if (kps) HIPCHK(hipMemcpy(kps, h->d_kps + (size_t)(frame + 1) * h->maxKp, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy(desc, h->d_desc + (size_t)(frame + 1) * h->maxKp * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int hh, int stride,
+                                  OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!imgs || B < 1) return fail(ORBX_E_INVALID, "no frames");
+    if (B > h->maxB) return fail(ORBX_E_INVALID, "batch %d exceeds %d", B, h->maxB);
+    if (w < 1 || hh < 1) { for (int f = 0; f < B; f++) if (n_out) n_out[f] = 0; return ORBX_OK; }  // :1046-1047
+    if (w > h->maxW || hh > h->maxH) return fail(ORBX_E_INVALID, "frame exceeds the handle's maximum");
+    if (stride < w) return fail(ORBX_E_INVALID, "stride < width");
+    // stage through pinned memory into the aligned device frames
+    const int dstride = align_up(w, 64);
+    const size_t dpitch = (size_t)dstride * hh;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int f = 0; f < B; f++) {
+        if (!imgs[f]) return fail(ORBX_E_INVALID, "null frame %d", f);
+        for (int y = 0; y < hh; y++) memcpy(h->h_pinned + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
+    }
+    h->prof.begin(P_H2D, h->stream);
+    HIPCHK(hipMemcpyAsync(h->d_img, h->h_pinned, dpitch * B, hipMemcpyHostToDevice, h->stream));
+    h->prof.end(h->stream);
+    rc = run_extract(h, h->d_img, B, w, hh, dstride, dpitch);
+    if (rc) return rc;
+    rc = orbx_sync(h);
+    if (rc) return rc;
+    // one D2H of counts, then per-frame payloads
+    std::vector<int32_t> counts(B);
+    h->prof.begin(P_D2H, h->stream);
+    HIPCHK(hipMemcpyAsync(counts.data(), h->d_count + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int over = 0;
+    for (int f = 0; f < B; f++) {
+        const int n = counts[f];
+        if (n_out) n_out[f] = n;
+        if (n > cap) { over = 1; continue; }
+        if (n > 0) {
+            if (kps) HIPCHK(hipMemcpyAsync(kps + (size_t)f * cap, h->d_kps + (size_t)(f + 1) * h->maxKp, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost, h->stream));
+            if (desc) HIPCHK(hipMemcpyAsync(desc + (size_t)f * cap * 32, h->d_desc + (size_t)(f + 1) * h->maxKp * 32, (size_t)n * 32, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    h->prof.end(h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (over) return fail(ORBX_E_CAPACITY, "a frame produced more keypoints than cap=%d", cap);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract(orbx_t* h, const uint8_t* img, int w, int hh, int stride,
+                            OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!img || w < 1 || hh < 1) { if (n_out) *n_out = 0; return ORBX_OK; }  // empty image: silent return (:1046-1047)
+    const uint8_t* one[1] = {img};
+    return orbx_extract_batch(h, one, 1, w, hh, stride, kps, desc, cap, n_out);
+}
+
+extern "C" int orbx_pyramid_level(orbx_t* h, int frame, int level, int blurred, uint8_t* dst, int* w, int* hh)
+{
+    int rc = orbx_sync(h);
+    if (rc) return rc;
+    if (h->curW == 0) return fail(ORBX_E_INVALID, "no frame extracted yet");
+    if (level < 0 || level >= h->geom.nlevels || frame < 0 || frame >= h->lastB) return fail(ORBX_E_INVALID, "bad frame/level");
+    const LevelGeom& L = h->geom.lv[level];
+    if (w) *w = L.w;
+    if (hh) *hh = L.h;
+    if (!dst) return ORBX_OK;
+    const uint8_t* srcp; size_t sp;
+    if (blurred) { srcp = h->d_blur + (size_t)frame * h->geom.blurFrameBytes + L.blurOff; sp = L.blurStride; }
+    else if (level == 0) { srcp = h->lastSrc.img0 + (size_t)frame * h->lastSrc.pitch0; sp = h->lastSrc.stride0; }
+    else { srcp = h->d_pyr + (size_t)frame * h->geom.pyrFrameBytes + L.pyrOff; sp = L.stride; }
+    HIPCHK(hipMemcpy2D(dst, L.w, srcp, sp, L.w, L.h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_level_candidates(orbx_t* h, int frame, int level, uint64_t* dst, int cap, int* n)
+{
+    int rc = orbx_sync(h);
+    if (rc) return rc;
+    if (h->curW == 0 || level < 0 || level >= h->geom.nlevels || frame < 0 || frame >= h->lastB) return fail(ORBX_E_INVALID, "bad frame/level");
+    int32_t cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, h->d_candCount + frame * h->geom.nlevels + level, sizeof cnt, hipMemcpyDeviceToHost));
+    if (n) *n = cnt;
+    if (!dst) return ORBX_OK;
+    if (cnt > cap) return fail(ORBX_E_CAPACITY, "%d candidates, capacity %d", cnt, cap);
+    HIPCHK(hipMemcpy(dst, h->d_candRaw + (size_t)frame * h->geom.candFrameRecs + h->geom.lv[level].candOff, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------ stream matching
+static orbm::MatchIO slots_io(orbx_handle* h)
+{
+    orbm::MatchIO io;
+    io.desc = h->d_desc; io.descPitch = (int64_t)h->maxKp * 32;
+    io.ang = &((const float*)h->d_kps)[3]; io.angStride = 7; io.angPitch = (int64_t)h->maxKp * 7;
+    io.count = h->d_count;
+    return io;
+}
+
+extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low, int check_ori)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    const int B = h->lastB;
+    if (B < 1) return fail(ORBX_E_INVALID, "no extracted batch to match");
+    hipStream_t s = h->stream;
+    orbm::MatchIO io = slots_io(h);
+    h->prof.begin(P_MATCH_BEST2, s);
+    hipLaunchKernelGGL(orbm::k_match_best2, dim3((h->maxKp + 255) / 256, B), dim3(256), 0, s, io, io, 1, 0, nnratio, th_low,
+                       check_ori, h->d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist);
+    h->prof.end(s);
+    h->prof.begin(P_MATCH_PRUNE, s);
+    hipLaunchKernelGGL(orbm::k_match_prune, dim3(B), dim3(256), 0, s, io, 1, check_ori, h->d_match, (int64_t)h->maxKp,
+                       h->d_binOf, h->d_hist, h->d_nmatch);
+    h->prof.end(s);
+    // last frame of this batch becomes the stream's previous frame (slot 0)
+    HIPCHK(hipMemcpyAsync(h->d_kps, h->d_kps + (size_t)B * h->maxKp, (size_t)h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_desc, h->d_desc + (size_t)B * h->maxKp * 32, (size_t)h->maxKp * 32, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_count, h->d_count + B, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    h->havePrev = true;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_device_matches(orbx_t* h, int32_t** d_match, int32_t** d_nmatch)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (d_match) *d_match = h->d_match;
+    if (d_nmatch) *d_nmatch = h->d_nmatch;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_download_matches(orbx_t* h, int frame, int32_t* match, int cap, int* nmatch)
+{
+    int rc = orbx_sync(h);
+    if (rc) return rc;
+    if (frame < 0 || frame >= h->lastB) return fail(ORBX_E_INVALID, "frame %d not in the last batch", frame);
+    int32_t n = 0, nm = 0;
+    HIPCHK(hipMemcpy(&n, h->d_count + 1 + frame, sizeof n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&nm, h->d_nmatch + frame, sizeof nm, hipMemcpyDeviceToHost));
+    if (nmatch) *nmatch = nm;
+    if (n > cap) return fail(ORBX_E_CAPACITY, "%d queries, caller capacity %d", n, cap);
+    if (match && n > 0) HIPCHK(hipMemcpy(match, h->d_match + (size_t)frame * h->maxKp, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_reset_stream(orbx_t* h)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(h->d_count, 0, sizeof(int32_t), h->stream));
+    h->havePrev = false;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_profile_enable(orbx_t* h, int enable)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    h->prof.on = enable != 0;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!out) return fail(ORBX_E_INVALID, "null argument");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->prof.collect();
+    out->n = P_COUNT;
+    for (int i = 0; i < P_COUNT; i++) {
+        out->name[i] = kProfNames[i];
+        out->ms[i] = h->prof.ms[i];
+        out->launches[i] = h->prof.launches[i];
+        if (reset) { h->prof.ms[i] = 0; h->prof.launches[i] = 0; }
+    }
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------ matcher handle
+struct orbm_handle {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    // growable scratch
+    void* d_buf[32] = {nullptr};
+    size_t d_cap[32] = {0};
+};
+
+static int orbm_reserve(orbm_handle* h, int slot, size_t bytes)
+{
+    if (bytes <= h->d_cap[slot]) return ORBX_OK;
+    if (h->d_buf[slot]) HIPCHK(hipFree(h->d_buf[slot]));
+    h->d_buf[slot] = nullptr; h->d_cap[slot] = 0;
+    const size_t want = std::max<size_t>(bytes * 3 / 2, 4096);
+    HIPCHK(hipMalloc(&h->d_buf[slot], want));
+    h->d_cap[slot] = want;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_create(int device, orbm_t** out)
+{
+    if (!out) return fail(ORBX_E_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = orbx_device_count();
+    if (ndev == 0) return fail(ORBX_E_NO_DEVICE, "no HIP device visible: the ORB matcher has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(ORBX_E_INVALID, "device %d out of range", device);
+    orbm_handle* h = new orbm_handle();
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(ORBX_E_HIP, "cannot create stream on device %d", device);
+    }
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" void orbm_destroy(orbm_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (auto p : h->d_buf) if (p) (void)hipFree(p);
+    delete h;
+}
+
+static int orbm_check(orbm_handle* h)
+{
+    if (!h) return fail(ORBX_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_distance_matrix(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* dist)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (nq < 0 || nt < 0 || (nq && !q) || (nt && !t) || !dist) return fail(ORBX_E_INVALID, "bad argument");
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    if ((rc = orbm_reserve(h, 0, (size_t)nq * 32)) || (rc = orbm_reserve(h, 1, (size_t)nt * 32)) ||
+        (rc = orbm_reserve(h, 2, (size_t)nq * nt * 4))) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_buf[0], q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_buf[1], t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(orbm::k_distance_matrix, dim3((nq + 255) / 256, std::min(nt, 64)), dim3(256), 0, s,
+                       (const uint8_t*)h->d_buf[0], nq, (const uint8_t*)h->d_buf[1], nt, (int32_t*)h->d_buf[2]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dist, h->d_buf[2], (size_t)nq * nt * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_match_bruteforce(orbm_t* h, const uint8_t* qdesc, const float* qangle, int nq,
+                                     const uint8_t* tdesc, const float* tangle, int nt,
+                                     float nnratio, int th_low, int check_ori, int32_t* match, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (nq < 0 || nt < 0 || (nq && (!qdesc || !qangle || !match)) || (nt && (!tdesc || !tangle))) return fail(ORBX_E_INVALID, "bad argument");
+    if (nmatches) *nmatches = 0;
+    if (nq == 0) return ORBX_OK;
+    // slots: 0 qdesc, 1 tdesc, 2 qangle, 3 tangle, 4 counts(2), 5 match, 6 binOf, 7 hist(32)+nmatch
+    if ((rc = orbm_reserve(h, 0, (size_t)nq * 32)) || (rc = orbm_reserve(h, 1, (size_t)std::max(nt, 1) * 32)) ||
+        (rc = orbm_reserve(h, 2, (size_t)nq * 4)) || (rc = orbm_reserve(h, 3, (size_t)std::max(nt, 1) * 4)) ||
+        (rc = orbm_reserve(h, 4, 16)) || (rc = orbm_reserve(h, 5, (size_t)nq * 4)) || (rc = orbm_reserve(h, 6, (size_t)nq)) ||
+        (rc = orbm_reserve(h, 7, 34 * 4))) return rc;
+    hipStream_t s = h->stream;
+    const int32_t counts[2] = {nq, nt};
+    HIPCHK(hipMemcpyAsync(h->d_buf[0], qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_buf[2], qangle, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    if (nt) {
+        HIPCHK(hipMemcpyAsync(h->d_buf[1], tdesc, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->d_buf[3], tangle, (size_t)nt * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(h->d_buf[4], counts, sizeof counts, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[7], 0, 34 * 4, s));
+    orbm::MatchIO q{(const uint8_t*)h->d_buf[0], 0, (const float*)h->d_buf[2], 0, 1, (const int32_t*)h->d_buf[4]};
+    orbm::MatchIO t{(const uint8_t*)h->d_buf[1], 0, (const float*)h->d_buf[3], 0, 1, (const int32_t*)h->d_buf[4] + 1};
+    int32_t* d_hist = (int32_t*)h->d_buf[7];
+    hipLaunchKernelGGL(orbm::k_match_best2, dim3((nq + 255) / 256, 1), dim3(256), 0, s, q, t, 0, 0, nnratio, th_low, check_ori,
+                       (int32_t*)h->d_buf[5], (int64_t)nq, (uint8_t*)h->d_buf[6], d_hist);
+    hipLaunchKernelGGL(orbm::k_match_prune, dim3(1), dim3(256), 0, s, q, 0, check_ori, (int32_t*)h->d_buf[5], (int64_t)nq,
+                       (const uint8_t*)h->d_buf[6], d_hist, d_hist + 32);
+    HIPCHK(hipGetLastError());
+    int32_t nm = 0;
+    HIPCHK(hipMemcpyAsync(match, h->d_buf[5], (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nm, d_hist + 32, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------ SearchByBoW
+extern "C" int orbm_search_by_bow(orbm_t* h,
+                                  const uint8_t* qdesc, const float* qangle, const uint8_t* qvalid, int nq,
+                                  const OrbmFeatVec* qfv,
+                                  const uint8_t* tdesc, const float* tangle, const uint8_t* tvalid, int nt,
+                                  const OrbmFeatVec* tfv,
+                                  float nnratio, int check_ori, int out_by_train,
+                                  int32_t* match, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (nq < 0 || nt < 0 || !qfv || !tfv || !match || (nq && (!qdesc || !qangle)) || (nt && (!tdesc || !tangle)))
+        return fail(ORBX_E_INVALID, "bad argument");
+    const int nout = out_by_train ? nt : nq;
+    for (int i = 0; i < nout; i++) match[i] = -1;
+    if (nmatches) *nmatches = 0;
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    // lock-step walk of the two sorted node-id lists (ORBmatcher.cc:180-266): host side,
+    // it only decides WHICH node pairs are searched
+    std::vector<int32_t> pq, pt;
+    {
+        int a = 0, b = 0;
+        while (a < qfv->n_nodes && b < tfv->n_nodes) {
+            if (qfv->node_id[a] == tfv->node_id[b]) { pq.push_back(a); pt.push_back(b); a++; b++; }
+            else if (qfv->node_id[a] < tfv->node_id[b]) a++;
+            else b++;
+        }
+    }
+    const int npairs = (int)pq.size();
+    if (npairs == 0) return ORBX_OK;
+    const int nqi = qfv->start[qfv->n_nodes], nti = tfv->start[tfv->n_nodes];
+    for (int i = 0; i < nqi; i++) if (qfv->idx[i] < 0 || qfv->idx[i] >= nq) return fail(ORBX_E_INVALID, "query feature index out of range");
+    for (int i = 0; i < nti; i++) if (tfv->idx[i] < 0 || tfv->idx[i] >= nt) return fail(ORBX_E_INVALID, "train feature index out of range");
+    enum { S_QD, S_TD, S_QA, S_TA, S_QV, S_TV, S_QS, S_QI, S_TS, S_TI, S_PQ, S_PT, S_MATCHED, S_MATCH, S_BIN, S_HIST };
+    const size_t sizes[] = {(size_t)nq * 32, (size_t)nt * 32, (size_t)nq * 4, (size_t)nt * 4, (size_t)nq, (size_t)nt,
+                            (size_t)(qfv->n_nodes + 1) * 4, (size_t)std::max(nqi, 1) * 4, (size_t)(tfv->n_nodes + 1) * 4,
+                            (size_t)std::max(nti, 1) * 4, (size_t)npairs * 4, (size_t)npairs * 4, (size_t)nt,
+                            (size_t)nout * 4, (size_t)nout, 34 * 4};
+    for (int i = 0; i < 16; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    hipStream_t s = h->stream;
+#define UP(slot, src, bytes) HIPCHK(hipMemcpyAsync(h->d_buf[slot], src, bytes, hipMemcpyHostToDevice, s))
+    UP(S_QD, qdesc, (size_t)nq * 32); UP(S_TD, tdesc, (size_t)nt * 32);
+    UP(S_QA, qangle, (size_t)nq * 4); UP(S_TA, tangle, (size_t)nt * 4);
+    if (qvalid) UP(S_QV, qvalid, (size_t)nq);
+    if (tvalid) UP(S_TV, tvalid, (size_t)nt);
+    UP(S_QS, qfv->start, (size_t)(qfv->n_nodes + 1) * 4);
+    if (nqi) UP(S_QI, qfv->idx, (size_t)nqi * 4);
+    UP(S_TS, tfv->start, (size_t)(tfv->n_nodes + 1) * 4);
+    if (nti) UP(S_TI, tfv->idx, (size_t)nti * 4);
+    UP(S_PQ, pq.data(), (size_t)npairs * 4); UP(S_PT, pt.data(), (size_t)npairs * 4);
+    HIPCHK(hipMemsetAsync(h->d_buf[S_MATCHED], 0, (size_t)nt, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[S_MATCH], 0xFF, (size_t)nout * 4, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[S_HIST], 0, 34 * 4, s));
+    orbm::BowArgs a;
+    a.qdesc = (const uint8_t*)h->d_buf[S_QD]; a.qang = (const float*)h->d_buf[S_QA];
+    a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
+    a.tdesc = (const uint8_t*)h->d_buf[S_TD]; a.tang = (const float*)h->d_buf[S_TA];
+    a.tvalid = tvalid ? (const uint8_t*)h->d_buf[S_TV] : nullptr;
+    a.qstart = (const int32_t*)h->d_buf[S_QS]; a.qidx = (const int32_t*)h->d_buf[S_QI];
+    a.tstart = (const int32_t*)h->d_buf[S_TS]; a.tidx = (const int32_t*)h->d_buf[S_TI];
+    a.pairQ = (const int32_t*)h->d_buf[S_PQ]; a.pairT = (const int32_t*)h->d_buf[S_PT];
+    a.matched = (uint8_t*)h->d_buf[S_MATCHED];
+    a.match = (int32_t*)h->d_buf[S_MATCH]; a.binOf = (uint8_t*)h->d_buf[S_BIN]; a.hist = (int32_t*)h->d_buf[S_HIST];
+    a.nnratio = nnratio; a.thLow = 50; a.checkOri = check_ori; a.outByTrain = out_by_train;
+    hipLaunchKernelGGL(orbm::k_bow_pairs, dim3(npairs), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(orbm::k_prune_flat, dim3(1), dim3(256), 0, s, a.match, nout, check_ori, (const uint8_t*)a.binOf,
+                       a.hist, a.hist + 32);
+    HIPCHK(hipGetLastError());
+    int32_t nm = 0;
+    HIPCHK(hipMemcpyAsync(match, a.match, (size_t)nout * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nm, a.hist + 32, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------ grid + SearchByProjection
+enum { G_KEYS = 16, G_CNT, G_START, G_FILL, G_IDX };
+
+static int orbm_build_grid(orbm_handle* h, const OrbmGrid* grid, const OrbxKeyPoint* keys, int n, orbm::GridDev& gd)
+{
+    if (!grid || grid->cols < 1 || grid->rows < 1 || grid->cols * grid->rows > (1 << 20)) return fail(ORBX_E_INVALID, "bad grid");
+    int rc;
+    const int ncell = grid->cols * grid->rows;
+    if ((rc = orbm_reserve(h, G_KEYS, (size_t)std::max(n, 1) * sizeof(OrbxKeyPoint))) || (rc = orbm_reserve(h, G_CNT, (size_t)ncell * 4)) ||
+        (rc = orbm_reserve(h, G_START, (size_t)(ncell + 1) * 4)) || (rc = orbm_reserve(h, G_FILL, (size_t)ncell * 4)) ||
+        (rc = orbm_reserve(h, G_IDX, (size_t)std::max(n, 1) * 4))) return rc;
+    hipStream_t s = h->stream;
+    gd.minX = grid->minX; gd.minY = grid->minY; gd.invW = grid->invW; gd.invH = grid->invH; gd.cols = grid->cols; gd.rows = grid->rows;
+    if (n) HIPCHK(hipMemcpyAsync(h->d_buf[G_KEYS], keys, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[G_CNT], 0, (size_t)ncell * 4, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[G_FILL], 0, (size_t)ncell * 4, s));
+    const orbm::KeyDev* dk = (const orbm::KeyDev*)h->d_buf[G_KEYS];
+    if (n) hipLaunchKernelGGL(orbm::k_grid_count, dim3((n + 255) / 256), dim3(256), 0, s, gd, dk, n, (int32_t*)h->d_buf[G_CNT]);
+    hipLaunchKernelGGL(orbm::k_scan_small, dim3(1), dim3(1024), 0, s, (const int32_t*)h->d_buf[G_CNT], ncell, (int32_t*)h->d_buf[G_START]);
+    if (n) {
+        hipLaunchKernelGGL(orbm::k_grid_fill, dim3((n + 255) / 256), dim3(256), 0, s, gd, dk, n, (const int32_t*)h->d_buf[G_START],
+                           (int32_t*)h->d_buf[G_FILL], (int32_t*)h->d_buf[G_IDX]);
+        hipLaunchKernelGGL(orbm::k_grid_sort, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, (const int32_t*)h->d_buf[G_START],
+                           (int32_t*)h->d_buf[G_IDX]);
+    }
+    HIPCHK(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const OrbxKeyPoint* keys_un, int n,
+                                     float x, float y, float r, int minLevel, int maxLevel,
+                                     int32_t* out, int cap, int* n_out)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (n < 0 || (n && !keys_un) || cap < 0 || (cap && !out)) return fail(ORBX_E_INVALID, "bad argument");
+    orbm::GridDev gd;
+    if ((rc = orbm_build_grid(h, grid, keys_un, n, gd))) return rc;
+    if ((rc = orbm_reserve(h, 0, (size_t)std::max(cap, 1) * 4)) || (rc = orbm_reserve(h, 1, 16))) return rc;
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL(orbm::k_features_in_area, dim3(1), dim3(1), 0, s, gd, (const orbm::KeyDev*)h->d_buf[G_KEYS],
+                       (const int32_t*)h->d_buf[G_START], (const int32_t*)h->d_buf[G_IDX], x, y, r, minLevel, maxLevel,
+                       (int32_t*)h->d_buf[0], cap, (int32_t*)h->d_buf[1]);
+    HIPCHK(hipGetLastError());
+    int32_t cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, h->d_buf[1], 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (n_out) *n_out = cnt;
+    if (cnt > cap) return fail(ORBX_E_CAPACITY, "%d features in area, capacity %d", cnt, cap);
+    if (cnt) HIPCHK(hipMemcpy(out, h->d_buf[0], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
+                                         const float* q_uvr, const int8_t* q_lvl,
+                                         const uint8_t* qdesc, const float* qangle,
+                                         const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                                         const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un,
+                                         const uint8_t* tdesc, int nt,
+                                         uint8_t* t_occ, int32_t* assign, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (!pp || pp->mode < 3 || pp->mode > 6) return fail(ORBX_E_INVALID, "mode must be 3..6");
+    if (nq < 0 || nt < 0 || (nq && (!q_uvr || !q_lvl || !qdesc)) || (nt && (!t_keys_un || !tdesc || !t_occ || !assign)))
+        return fail(ORBX_E_INVALID, "bad argument");
+    const bool useRot = pp->check_ori && (pp->mode == 4 || pp->mode == 5);
+    if (useRot && nq && !qangle) return fail(ORBX_E_INVALID, "angles required for the rotation check");
+    if (nmatches) *nmatches = 0;
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    orbm::GridDev gd;
+    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, gd))) return rc;
+    enum { S_UVR, S_LVL, S_QD, S_QA, S_QV, S_QO, S_TD, S_CNT, S_OFF, S_KEY, S_CIDX, S_OCC, S_ASSIGN, S_NM, S_PUSHT, S_PUSHB };
+    const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 2, (size_t)nq * 32, (size_t)nq * 4, (size_t)nq, (size_t)nq,
+                            (size_t)nt * 32, (size_t)nq * 4, (size_t)(nq + 1) * 4, 16, 16, (size_t)nt, (size_t)nt * 4, 16,
+                            (size_t)nq * 4, (size_t)nq};
+    for (int i = 0; i < 16; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    hipStream_t s = h->stream;
+    UP(S_UVR, q_uvr, (size_t)nq * 12); UP(S_LVL, q_lvl, (size_t)nq * 2); UP(S_QD, qdesc, (size_t)nq * 32);
+    if (qangle) UP(S_QA, qangle, (size_t)nq * 4);
+    if (qvalid) UP(S_QV, qvalid, (size_t)nq);
+    if (q_obs_pos) UP(S_QO, q_obs_pos, (size_t)nq);
+    UP(S_TD, tdesc, (size_t)nt * 32); UP(S_OCC, t_occ, (size_t)nt); UP(S_ASSIGN, assign, (size_t)nt * 4);
+    orbm::ProjArgs a;
+    a.grid = gd;
+    a.tkeys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
+    a.cellStart = (const int32_t*)h->d_buf[G_START]; a.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    a.quvr = (const float*)h->d_buf[S_UVR]; a.qlvl = (const int8_t*)h->d_buf[S_LVL];
+    a.qdesc = (const uint8_t*)h->d_buf[S_QD]; a.qang = (const float*)h->d_buf[S_QA];
+    a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
+    a.qobs = q_obs_pos ? (const uint8_t*)h->d_buf[S_QO] : nullptr;
+    a.tdesc = (const uint8_t*)h->d_buf[S_TD];
+    a.nq = nq; a.nt = nt;
+    a.candCnt = (int32_t*)h->d_buf[S_CNT]; a.candOff = (int32_t*)h->d_buf[S_OFF];
+    a.candKey = nullptr; a.candIdx = nullptr;
+    a.tocc = (uint8_t*)h->d_buf[S_OCC]; a.assign = (int32_t*)h->d_buf[S_ASSIGN]; a.nmatch = (int32_t*)h->d_buf[S_NM];
+    a.pushT = (int32_t*)h->d_buf[S_PUSHT]; a.pushBin = (uint8_t*)h->d_buf[S_PUSHB];
+    a.mode = pp->mode; a.nnratio = pp->nnratio; a.checkOri = pp->check_ori; a.thDist = pp->th_dist;
+    hipLaunchKernelGGL(orbm::k_proj_candidates, dim3((nq + 63) / 64), dim3(64), 0, s, a, 0);
+    hipLaunchKernelGGL(orbm::k_scan_small, dim3(1), dim3(1024), 0, s, (const int32_t*)a.candCnt, nq, a.candOff);
+    HIPCHK(hipGetLastError());
+    int32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, a.candOff + nq, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = orbm_reserve(h, S_KEY, (size_t)std::max(total, 1) * 4)) || (rc = orbm_reserve(h, S_CIDX, (size_t)std::max(total, 1) * 4))) return rc;
+    a.candKey = (uint32_t*)h->d_buf[S_KEY]; a.candIdx = (int32_t*)h->d_buf[S_CIDX];
+    hipLaunchKernelGGL(orbm::k_proj_candidates, dim3((nq + 63) / 64), dim3(64), 0, s, a, 1);
+    const int words = (nt + 31) / 32;
+    if ((size_t)words * 4 > 150 * 1024) return fail(ORBX_E_UNSUPPORTED, "too many train features for the LDS occupancy bitmap");
+    if ((size_t)words * 4 > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)orbm::k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, words * 4));
+    hipLaunchKernelGGL(orbm::k_proj_resolve, dim3(1), dim3(64), (size_t)words * 4, s, a, words);
+    HIPCHK(hipGetLastError());
+    int32_t nm = 0;
+    HIPCHK(hipMemcpyAsync(t_occ, a.tocc, (size_t)nt, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(assign, a.assign, (size_t)nt * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nm, a.nmatch, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBX_OK;
+}
+#undef UP

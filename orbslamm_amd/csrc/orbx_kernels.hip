@@ -1,0 +1,735 @@
+// orbx_kernels.hip -- gfx950 kernels of the ORB extractor hot path.
+//
+// Stage map (reference: /root/reference/SingleRobotScenario/src/ORBextractor.cc):
+//   k_resize        ComputePyramid :1107-1132 (cv::resize INTER_LINEAR, fixed point)
+//   k_fast          ComputeKeyPointsOctTree cell loop :789-829 (cv::FAST 9/16 + NMS + minTh retry)
+//   k_distribute    DistributeOctTree :539-763 + DivideNode :481-537
+//   k_blur          GaussianBlur 7x7 sigma 2 :1085-1086
+//   k_orient_desc   IC_Angle :77-104, computeOrbDescriptor :108-147, scale/pack :837-847,1095-1101
+//
+// Integer/bitwise path: no MFMA.  64-wide waves, LDS tiles, strict IEEE fp32
+// (no contraction: explicit __fmul_rn/__fadd_rn and -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orbx_common.hpp"
+
+namespace orbx {
+
+struct FrameSrc {
+    const uint8_t* img0;   // level 0 = caller's frames
+    int32_t stride0;
+    int64_t pitch0;        // bytes between frames
+    uint8_t* pyr;          // levels >= 1
+    uint8_t* blur;         // all levels
+};
+
+__device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const FrameSrc& s, int f, int l, int& stride)
+{
+    if (l == 0) { stride = s.stride0; return s.img0 + (int64_t)f * s.pitch0; }
+    stride = g->lv[l].stride;
+    return s.pyr + (int64_t)f * g->pyrFrameBytes + g->lv[l].pyrOff;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt()
+{
+    const uint32_t lane = threadIdx.x & 63;
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// ------------------------------------------------------------------ pyramid
+// xtab[dx] = {sx, a0, a1, interp?}, ytab[dy] = {sy0, sy1, b0, b1}; built on the host
+// (orbx_api.hip: build_resize_tables) exactly as cv::resize builds xofs/ialpha/yofs/ibeta.
+struct ResizeTabs {
+    const short4* xtab[ORBX_MAXL];
+    const short4* ytab[ORBX_MAXL];
+};
+
+__global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, FrameSrc src, ResizeTabs tabs, int level)
+{
+    const LevelGeom& L = g->lv[level];
+    const int f = blockIdx.z;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= L.w || dy >= L.h) return;
+    int sstride;
+    const uint8_t* S = level_ptr(g, src, f, level - 1, sstride);
+    uint8_t* D = src.pyr + (int64_t)f * g->pyrFrameBytes + L.pyrOff + (int64_t)dy * L.stride;
+    const short4 yt = tabs.ytab[level][dy];
+    const uint8_t* S0 = S + (int64_t)yt.x * sstride;
+    const uint8_t* S1 = S + (int64_t)yt.y * sstride;
+    const int b0 = yt.z, b1 = yt.w;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = x4 + i;
+        int v = 0;
+        if (dx < L.w) {
+            const short4 xt = tabs.xtab[level][dx];
+            const int sx = (uint16_t)xt.x;
+            int r0, r1;
+            if (xt.w) {
+                r0 = S0[sx] * xt.y + S0[sx + 1] * xt.z;
+                r1 = S1[sx] * xt.y + S1[sx + 1] * xt.z;
+            } else {
+                r0 = S0[sx] * 2048;
+                r1 = S1[sx] * 2048;
+            }
+            v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        }
+        packed |= (uint32_t)(v & 0xFF) << (8 * i);
+    }
+    *(uint32_t*)(D + x4) = packed;  // rows are 64-byte aligned and padded
+}
+
+// ------------------------------------------------------------------ FAST
+// One wave per reference cell.  S(p) = max over the 16 arcs of 9 contiguous ring
+// pixels of min(v - p_k) resp. min(p_k - v): the pixel is a FAST-9 corner at
+// threshold t iff S > t, and cv::FAST's cornerScore is then S - 1 (threshold
+// independent), so the minThFAST retry re-thresholds the same S map.
+__device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p, const int* off, int tq)
+{
+    const int v = p[0];
+    int d[16];
+    // quick reject (each 9-arc contains one pixel of every opposite pair)
+    d[0] = v - p[off[0]];
+    d[8] = v - p[off[8]];
+    if (abs(d[0]) <= tq && abs(d[8]) <= tq) return 0;
+    d[4] = v - p[off[4]];
+    d[12] = v - p[off[12]];
+    if (abs(d[4]) <= tq && abs(d[12]) <= tq) return 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (k != 0 && k != 8 && k != 4 && k != 12) d[k] = v - p[off[k]];
+    int mn2[16], mx2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+    int mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int A = -256, Bn = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, mn9);
+        Bn = min(Bn, mx9);
+    }
+    const int S = max(A, -Bn);
+    return S < 0 ? 0 : S;
+}
+
+__global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const Cell* __restrict__ cells,
+                                            FrameSrc src, uint64_t* __restrict__ cand,
+                                            int32_t* __restrict__ candCount, int32_t* __restrict__ errFlag,
+                                            int tileStrideDw, int tileRows)
+{
+    extern __shared__ uint32_t lds[];
+    const Cell c = cells[blockIdx.x];
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int level = c.level;
+    const LevelGeom& L = g->lv[level];
+    int stride;
+    const uint8_t* base = level_ptr(g, src, f, level, stride);
+
+    uint32_t* tile = lds;                                   // [tileRows][tileStrideDw] dwords
+    const int tsb = tileStrideDw * 4;                       // tile stride in bytes
+    uint8_t* smap = (uint8_t*)(lds + tileRows * tileStrideDw);  // same geometry, bytes
+    const uint8_t* tb = (const uint8_t*)tile;
+
+    const int cw = c.w, ch = c.h;
+    const int shift = c.x0 & 3;
+    const int ndw = (shift + cw + 3) >> 2;
+    // coalesced aligned dword loads of the ROI rows; zero the S map
+    {
+        const uint8_t* rowbase = base + (int64_t)c.y0 * stride + (c.x0 & ~3);
+        for (int r = lane >> 4; r < ch; r += 4)
+            for (int dd = lane & 15; dd < ndw; dd += 16)
+                tile[r * tileStrideDw + dd] = *(const uint32_t*)(rowbase + (int64_t)r * stride + 4 * dd);
+        uint32_t* sm32 = (uint32_t*)smap;
+        for (int i = lane; i < ch * tileStrideDw; i += 64) sm32[i] = 0;
+    }
+    __syncthreads();
+
+    int off[16];
+    {
+        const int cx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+        const int cy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+#pragma unroll
+        for (int k = 0; k < 16; k++) off[k] = cx[k] + cy[k] * tsb;
+    }
+    const int dw = cw - 6, dh = ch - 6;  // detection area
+    const int tq = min(g->iniTh, g->minTh) < 0 ? 0 : min(g->iniTh, g->minTh);
+
+    for (int xb = 0; xb < dw; xb += 32) {
+        const int x = xb + (lane & 31);
+        for (int y = lane >> 5; y < dh; y += 2) {
+            if (x < dw) {
+                const int pos = (y + 3) * tsb + shift + x + 3;
+                const int S = fast_S(tb + pos, off, tq);
+                smap[pos] = (uint8_t)S;
+            }
+        }
+    }
+    __syncthreads();
+
+    // 3x3 non-max suppression on M_t = (S > t ? S-1 : 0), strict >, zero outside the
+    // detection area; if nothing survives at iniThFAST, retry at minThFAST (:812-816)
+    int th = g->iniTh < 0 ? 0 : (g->iniTh > 255 ? 255 : g->iniTh);
+    const int th2 = g->minTh < 0 ? 0 : (g->minTh > 255 ? 255 : g->minTh);
+    int total = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        total = 0;
+        for (int xb = 0; xb < dw; xb += 32) {
+            const int x = xb + (lane & 31);
+            for (int y0 = 0; y0 < dh; y0 += 2) {
+                const int y = y0 + (lane >> 5);
+                bool keep = false;
+                if (x < dw && y < dh) {
+                    const uint8_t* s = smap + (y + 3) * tsb + shift + x + 3;
+                    const int sc = s[0];
+                    if (sc > th && sc >= 2) {
+                        int m = 0;
+#define NB(o) { const int sn = s[o]; if (sn > th) m = max(m, sn); }
+                        NB(-1) NB(1) NB(-tsb - 1) NB(-tsb) NB(-tsb + 1) NB(tsb - 1) NB(tsb) NB(tsb + 1)
+#undef NB
+                        keep = sc > m;
+                    }
+                }
+                total += __popcll(__ballot(keep));
+            }
+        }
+        if (total > 0 || th == th2) break;
+        th = th2;
+    }
+    if (total == 0) return;
+
+    int basePos = 0;
+    if (lane == 0) basePos = atomicAdd(&candCount[f * g->nlevels + level], total);
+    basePos = __shfl(basePos, 0);
+    uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff;
+    const uint64_t lt = lanemask_lt();
+    int run = 0;
+    for (int xb = 0; xb < dw; xb += 32) {
+        const int x = xb + (lane & 31);
+        for (int y0 = 0; y0 < dh; y0 += 2) {
+            const int y = y0 + (lane >> 5);
+            bool keep = false;
+            int sc = 0;
+            if (x < dw && y < dh) {
+                const uint8_t* s = smap + (y + 3) * tsb + shift + x + 3;
+                sc = s[0];
+                if (sc > th && sc >= 2) {
+                    int m = 0;
+#define NB(o) { const int sn = s[o]; if (sn > th) m = max(m, sn); }
+                    NB(-1) NB(1) NB(-tsb - 1) NB(-tsb) NB(-tsb + 1) NB(tsb - 1) NB(tsb) NB(tsb + 1)
+#undef NB
+                    keep = sc > m;
+                }
+            }
+            const uint64_t bal = __ballot(keep);
+            if (keep) {
+                const int p = basePos + run + __popcll(bal & lt);
+                if (p < L.candCap) {
+                    const uint32_t xr = x + 3, yr = y + 3;  // ROI coordinates
+                    out[p] = pack_cand(c.x0 - kMinBorder + xr, c.y0 - kMinBorder + yr, sc - 1,
+                                       cand_order(c.seq, yr, xr));
+                } else {
+                    atomicOr(errFlag, 1);
+                }
+            }
+            run += __popcll(bal);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ quadtree distribution
+// One 256-thread workgroup per (frame, level) replays DistributeOctTree exactly:
+// the node list lives in LDS in list order; every round is data-parallel
+// (wave-per-node 4-way partition with ballots, block scans for the new list order).
+// Node keys are ranges [start, start+cnt) of a ping-pong record buffer; children
+// partition their parent's range in the other buffer, so ranges never overlap.
+constexpr int kDistThreads = 256;
+
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t* a, int m, uint32_t* wtmp)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (m + kDistThreads - 1) / kDistThreads;
+    const int b = min(tid * per, m), e = min(b + per, m);
+    uint32_t s = 0;
+    for (int i = b; i < e; i++) s += a[i];
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wtmp[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kDistThreads / 64; w++) {
+        const uint32_t t = wtmp[w];
+        if (w < wave) woff += t;
+        total += t;
+    }
+    uint32_t run = woff + incl - s;
+    for (int i = b; i < e; i++) { const uint32_t t = a[i]; a[i] = run; run += t; }
+    __syncthreads();
+    return total;
+}
+
+// 4-way partition of one node's keys by the wave; returns child counts (uniform)
+__device__ __forceinline__ void wave_divide(const uint64_t* __restrict__ srcb, uint64_t* __restrict__ dstb,
+                                            uint32_t start, uint32_t cnt, int xm, int ym, uint32_t c[4])
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lanemask_lt();
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        int q = 4;
+        if (p < cnt) {
+            const uint64_t key = srcb[start + p];
+            q = ((int)cand_x(key) >= xm ? 1 : 0) | ((int)cand_y(key) >= ym ? 2 : 0);
+        }
+        c0 += __popcll(__ballot(q == 0));
+        c1 += __popcll(__ballot(q == 1));
+        c2 += __popcll(__ballot(q == 2));
+        c3 += __popcll(__ballot(q == 3));
+    }
+    uint32_t r0 = start, r1 = start + c0, r2 = start + c0 + c1, r3 = start + c0 + c1 + c2;
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        int q = 4;
+        uint64_t key = 0;
+        if (p < cnt) {
+            key = srcb[start + p];
+            q = ((int)cand_x(key) >= xm ? 1 : 0) | ((int)cand_y(key) >= ym ? 2 : 0);
+        }
+        const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+        if (q == 0) dstb[r0 + __popcll(b0 & lt)] = key;
+        else if (q == 1) dstb[r1 + __popcll(b1 & lt)] = key;
+        else if (q == 2) dstb[r2 + __popcll(b2 & lt)] = key;
+        else if (q == 3) dstb[r3 + __popcll(b3 & lt)] = key;
+        r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+    }
+    c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+}
+
+__global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restrict__ g,
+                                                            const uint64_t* __restrict__ candRaw,
+                                                            uint64_t* __restrict__ candA, uint64_t* __restrict__ candB,
+                                                            const int32_t* __restrict__ candCount,
+                                                            uint64_t* __restrict__ kept, int32_t* __restrict__ keptCount,
+                                                            int32_t* __restrict__ errFlag, int cap)
+{
+    extern __shared__ uint32_t smem[];
+    const int l = blockIdx.x, f = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kDistThreads / 64;
+    const LevelGeom& L = g->lv[l];
+    const int N = L.nFeat;
+    int n = candCount[f * g->nlevels + l];
+    if (n > L.candCap) n = L.candCap;
+    if (n <= 0 || L.nIni < 1) {
+        if (tid == 0) keptCount[f * g->nlevels + l] = 0;
+        return;
+    }
+    uint64_t* bufs[2] = {candA + (int64_t)f * g->candFrameRecs + L.candOff,
+                         candB + (int64_t)f * g->candFrameRecs + L.candOff};
+
+    // LDS carve-up (all u32 arrays of `cap` entries unless noted)
+    short4* nb[2];      // bounds x0,x1,y0,y1
+    uint32_t* ns[2];    // key range start
+    uint32_t* nc[2];    // key count | bufId<<31
+    {
+        uint32_t* p = smem;
+        nb[0] = (short4*)p; p += 2 * cap;
+        nb[1] = (short4*)p; p += 2 * cap;
+        ns[0] = p; p += cap; ns[1] = p; p += cap;
+        nc[0] = p; p += cap; nc[1] = p; p += cap;
+    }
+    uint32_t* cc = smem + 8 * cap;        // [cap*4] child counts per E-entry
+    uint32_t* ord = cc + 4 * cap;         // processing order -> list index
+    uint32_t* ord2 = ord + cap;
+    uint32_t* tA = ord2 + cap;            // scan scratch
+    uint32_t* tB = tA + cap;
+    uint32_t* proc = tB + cap;            // processed flag per list index
+    uint32_t* wtmp = proc + cap;          // [8]
+    __shared__ int sJ;
+
+    // ---- roots (:543-585): nIni nodes, keys routed by (int)(x / hX)
+    const int nIni = L.nIni;
+    const float hX = L.hX;
+    for (int i = tid; i < cap; i += kDistThreads) { tA[i] = 0; tB[i] = 0; }
+    __syncthreads();
+    {
+        // the raw FAST output stays untouched (debug dumps read it); rounds ping-pong A/B
+        const uint64_t* srcb = candRaw + (int64_t)f * g->candFrameRecs + L.candOff;
+        const uint64_t lt = lanemask_lt();
+        for (int pass = 0; pass < 2; pass++) {
+            for (int p0 = wave * 64; p0 < n; p0 += kDistThreads) {
+                const int p = p0 + lane;
+                int r = -1;
+                uint64_t key = 0;
+                if (p < n) {
+                    key = srcb[p];
+                    r = (int)__fdiv_rn((float)cand_x(key), hX);
+                    if (r >= nIni) r = nIni - 1;
+                }
+                uint64_t todo = __ballot(r >= 0);
+                while (todo) {
+                    const int leader = __ffsll((unsigned long long)todo) - 1;
+                    const int rr = __shfl(r, leader);
+                    const uint64_t mask = __ballot(r == rr);
+                    if (pass == 0) {
+                        if (lane == leader) atomicAdd(&tA[rr], (uint32_t)__popcll(mask));
+                    } else {
+                        uint32_t bpos = 0;
+                        if (lane == leader) bpos = atomicAdd(&tB[rr], (uint32_t)__popcll(mask));
+                        bpos = __shfl(bpos, leader);
+                        if (r == rr) bufs[1][tA[rr] + bpos + __popcll(mask & lt)] = key;
+                    }
+                    todo &= ~mask;
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                for (int i = tid; i < nIni; i += kDistThreads) ord[i] = tA[i];  // counts
+                __syncthreads();
+                block_excl_scan(tA, nIni, wtmp);  // tA = starts
+            }
+        }
+    }
+    // non-empty roots in order 0..nIni-1 (:572-585)
+    for (int i = tid; i < nIni; i += kDistThreads) tB[i] = ord[i] > 0 ? 1u : 0u;
+    __syncthreads();
+    // tB flags -> positions (keep counts in ord, starts in tA)
+    for (int i = tid; i < nIni; i += kDistThreads) ord2[i] = tB[i];
+    __syncthreads();
+    int m = (int)block_excl_scan(ord2, nIni, wtmp);
+    int cur = 0;
+    for (int i = tid; i < nIni; i += kDistThreads) {
+        if (tB[i]) {
+            const int pos = ord2[i];
+            nb[cur][pos] = make_short4((short)(int)__fmul_rn(hX, (float)i), (short)(int)__fmul_rn(hX, (float)(i + 1)), 0, (short)L.winH);
+            ns[cur][pos] = tA[i];
+            nc[cur][pos] = ord[i] | (1u << 31);  // keys are in buffer 1
+        }
+    }
+    __syncthreads();
+
+    // ---- rounds
+    bool careful = false;
+    for (int iter = 0; iter < 64; iter++) {
+        const int prevSize = m;
+        // E = nodes with more than one key, in list order
+        for (int i = tid; i < m; i += kDistThreads) tA[i] = (nc[cur][i] & 0x7FFFFFFFu) > 1 ? 1u : 0u;
+        __syncthreads();
+        for (int i = tid; i < m; i += kDistThreads) tB[i] = tA[i];
+        __syncthreads();
+        const int E = (int)block_excl_scan(tB, m, wtmp);
+        if (E == 0) break;  // size unchanged -> finish (:669 / :733)
+        for (int i = tid; i < m; i += kDistThreads) if (tA[i]) ord[tB[i]] = i;
+        __syncthreads();
+        if (careful) {
+            // sort by (count desc, list position asc) == reference's (size, creation) ascending
+            // sort walked from the back (:684-685, tie-break see DESIGN.md)
+            for (int e = tid; e < E; e += kDistThreads) {
+                const uint32_t i = ord[e];
+                const uint32_t ci = nc[cur][i] & 0x7FFFFFFFu;
+                int rank = 0;
+                for (int e2 = 0; e2 < E; e2++) {
+                    const uint32_t i2 = ord[e2];
+                    const uint32_t c2 = nc[cur][i2] & 0x7FFFFFFFu;
+                    rank += (c2 > ci || (c2 == ci && i2 < i)) ? 1 : 0;
+                }
+                ord2[rank] = i;
+            }
+            __syncthreads();
+            for (int e = tid; e < E; e += kDistThreads) ord[e] = ord2[e];
+            __syncthreads();
+        }
+        // divide every E node (tentatively in careful mode) into the other buffer
+        for (int t = wave; t < E; t += NW) {
+            const uint32_t i = ord[t];
+            const short4 b = nb[cur][i];
+            const uint32_t cb = nc[cur][i];
+            const uint32_t cnt = cb & 0x7FFFFFFFu, bid = cb >> 31;
+            const int xm = b.x + ((b.y - b.x + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  :483
+            const int ym = b.z + ((b.w - b.z + 1) >> 1);  // UL.y + ceil((BR.y-UL.y)/2)  :484
+            uint32_t c[4];
+            wave_divide(bufs[bid], bufs[bid ^ 1], ns[cur][i], cnt, xm, ym, c);
+            if (lane == 0) { cc[4 * t] = c[0]; cc[4 * t + 1] = c[1]; cc[4 * t + 2] = c[2]; cc[4 * t + 3] = c[3]; }
+        }
+        __syncthreads();
+        // k_t = non-empty children; prefix over processing order
+        for (int t = tid; t < E; t += kDistThreads) {
+            const uint32_t k = (cc[4 * t] ? 1 : 0) + (cc[4 * t + 1] ? 1 : 0) + (cc[4 * t + 2] ? 1 : 0) + (cc[4 * t + 3] ? 1 : 0);
+            tA[t] = k;
+            tB[t] = k;
+        }
+        if (tid == 0) sJ = E - 1;
+        __syncthreads();
+        block_excl_scan(tB, E, wtmp);  // tB[t] = sum_{u<t} k_u
+        if (careful) {
+            // stop as soon as the list holds N nodes (:727-728)
+            for (int t = tid; t < E; t += kDistThreads) {
+                const int sizeAfter = m + (int)(tB[t] + tA[t]) - (t + 1);
+                if (sizeAfter >= N) atomicMin(&sJ, t);
+            }
+            __syncthreads();
+        }
+        const int J = sJ;
+        const uint32_t K = tB[J] + tA[J];  // children of processed nodes
+        // survivors: old nodes not processed keep their relative order behind the new ones
+        for (int i = tid; i < m; i += kDistThreads) proc[i] = 0;
+        __syncthreads();
+        for (int t = tid; t <= J; t += kDistThreads) proc[ord[t]] = 1;
+        __syncthreads();
+        for (int i = tid; i < m; i += kDistThreads) ord2[i] = proc[i] ? 0u : 1u;
+        __syncthreads();
+        const int nSurv = (int)block_excl_scan(ord2, m, wtmp);
+        const int nxt = cur ^ 1;
+        const int newSize = (int)K + nSurv;
+        if (newSize > cap) {  // cannot happen (size <= max(N+2, 4*nIni)); guard anyway
+            if (tid == 0) atomicOr(errFlag, 2);
+            break;
+        }
+        for (int i = tid; i < m; i += kDistThreads) {
+            if (!proc[i]) {
+                const int pos = (int)K + (int)ord2[i];
+                nb[nxt][pos] = nb[cur][i];
+                ns[nxt][pos] = ns[cur][i];
+                nc[nxt][pos] = nc[cur][i];
+            }
+        }
+        // children: groups in reverse processing order, inside a group n4,n3,n2,n1 (push_front, :621-660)
+        int nToExpandLocal = 0;
+        for (int t = tid; t <= J; t += kDistThreads) {
+            const uint32_t i = ord[t];
+            const short4 b = nb[cur][i];
+            const uint32_t cb = nc[cur][i];
+            const uint32_t bid = (cb >> 31) ^ 1u;
+            const int xm = b.x + ((b.y - b.x + 1) >> 1);
+            const int ym = b.z + ((b.w - b.z + 1) >> 1);
+            const uint32_t c0 = cc[4 * t], c1 = cc[4 * t + 1], c2 = cc[4 * t + 2], c3 = cc[4 * t + 3];
+            const uint32_t st = ns[cur][i];
+            int pos = (int)(K - (tB[t] + tA[t]));  // sum of k_u for u in (t, J]
+            if (c3) { nb[nxt][pos] = make_short4((short)xm, b.y, (short)ym, b.w); ns[nxt][pos] = st + c0 + c1 + c2; nc[nxt][pos] = c3 | (bid << 31); pos++; nToExpandLocal += c3 > 1; }
+            if (c2) { nb[nxt][pos] = make_short4(b.x, (short)xm, (short)ym, b.w); ns[nxt][pos] = st + c0 + c1; nc[nxt][pos] = c2 | (bid << 31); pos++; nToExpandLocal += c2 > 1; }
+            if (c1) { nb[nxt][pos] = make_short4((short)xm, b.y, b.z, (short)ym); ns[nxt][pos] = st + c0; nc[nxt][pos] = c1 | (bid << 31); pos++; nToExpandLocal += c1 > 1; }
+            if (c0) { nb[nxt][pos] = make_short4(b.x, (short)xm, b.z, (short)ym); ns[nxt][pos] = st; nc[nxt][pos] = c0 | (bid << 31); pos++; nToExpandLocal += c0 > 1; }
+        }
+        // block-wide sum of nToExpand (main mode only needs it)
+        {
+            int v = nToExpandLocal;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+            __syncthreads();
+            if (lane == 0) wtmp[wave] = (uint32_t)v;
+            __syncthreads();
+        }
+        int nToExpand = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) nToExpand += (int)wtmp[w];
+        __syncthreads();
+        cur = nxt;
+        m = newSize;
+        if (m >= N || m == prevSize) break;             // :669 / :733
+        if (!careful && m + nToExpand * 3 > N) careful = true;  // :673
+    }
+
+    // ---- best response per node, first pushed wins ties (:742-760) == max record
+    uint64_t* outk = kept + (int64_t)f * g->keptFrameRecs + L.keptOff;
+    if (m > L.keptCap) { if (tid == 0) atomicOr(errFlag, 4); m = L.keptCap; }
+    for (int i = wave; i < m; i += NW) {
+        const uint32_t cb = nc[cur][i];
+        const uint32_t cnt = cb & 0x7FFFFFFFu;
+        const uint64_t* srcb = bufs[cb >> 31] + ns[cur][i];
+        uint64_t best = 0;
+        for (uint32_t p = lane; p < cnt; p += 64) { const uint64_t k = srcb[p]; best = k > best ? k : best; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint64_t o = __shfl_xor((unsigned long long)best, d);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) outk[i] = best;
+    }
+    if (tid == 0) keptCount[f * g->nlevels + l] = m;
+}
+
+// ------------------------------------------------------------------ Gaussian 7x7 sigma 2
+// cv::GaussianBlur on 8U: kernel x256 -> [18,34,49,55,49,34,18], separable integer
+// filter, (sum + 2^15) >> 16, saturate, BORDER_REFLECT_101.
+struct BlurTiles { int32_t base[ORBX_MAXL + 1]; int32_t tilesX[ORBX_MAXL]; };
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt)
+{
+    constexpr int TW = 64, TH = 16;
+    __shared__ uint8_t in[TH + 6][TW + 8];
+    __shared__ uint16_t rp[TH + 6][TW];
+    const int f = blockIdx.y;
+    int l = 0;
+    while (l + 1 < g->nlevels && (int)blockIdx.x >= bt.base[l + 1]) l++;
+    const int tIdx = blockIdx.x - bt.base[l];
+    const int tx0 = (tIdx % bt.tilesX[l]) * TW, ty0 = (tIdx / bt.tilesX[l]) * TH;
+    const LevelGeom& L = g->lv[l];
+    int stride;
+    const uint8_t* S = level_ptr(g, src, f, l, stride);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (TH + 6) * (TW + 6); i += 256) {
+        const int r = i / (TW + 6), c = i % (TW + 6);
+        const int sy = reflect101(ty0 + r - 3, L.h), sx = reflect101(tx0 + c - 3, L.w);
+        in[r][c] = S[(int64_t)sy * stride + sx];
+    }
+    __syncthreads();
+    const int kx = tid & 63, ky = tid >> 6;
+    for (int r = ky; r < TH + 6; r += 4) {
+        const uint8_t* p = &in[r][kx];
+        const int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+        rp[r][kx] = (uint16_t)s;  // <= 257*255 = 65535
+    }
+    __syncthreads();
+    uint8_t* D = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff;
+    for (int r = ky; r < TH; r += 4) {
+        const int x = tx0 + kx, y = ty0 + r;
+        if (x < L.w && y < L.h) {
+            int s = 18 * (rp[r][kx] + rp[r + 6][kx]) + 34 * (rp[r + 1][kx] + rp[r + 5][kx]) +
+                    49 * (rp[r + 2][kx] + rp[r + 4][kx]) + 55 * rp[r + 3][kx];
+            s = (s + (1 << 15)) >> 16;
+            D[(int64_t)y * L.blurStride + x] = (uint8_t)(s > 255 ? 255 : s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ orientation + rBRIEF + pack
+__device__ const int8_t d_pattern[1024] __attribute__((aligned(16))) = {
+#include "brief_pattern.inc"
+};
+
+// cv::fastAtan2 (degrees), every operation a separate binary32 rounding
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    constexpr float k180pi = (float)(180.0 / 3.1415926535897932384626433832795);
+    constexpr float p1 = 0.9997878412794807f * k180pi;
+    constexpr float p3 = -0.3258083974640975f * k180pi;
+    constexpr float p5 = 0.1555786518463281f * k180pi;
+    constexpr float p7 = -0.04432655554792128f * k180pi;
+    constexpr float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+struct KpBlocks { int32_t base[ORBX_MAXL + 1]; };  // block index -> level (4 keypoints per block)
+
+__global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g, FrameSrc src, KpBlocks kb,
+                                                    const uint64_t* __restrict__ kept,
+                                                    const int32_t* __restrict__ keptCount,
+                                                    OrbxKeyPointDev* __restrict__ outKps,
+                                                    uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount)
+{
+    __shared__ int32_t spat[256];  // 256 tests x (x0,y0,x1,y1) int8
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.y;
+    spat[tid] = ((const int32_t*)d_pattern)[tid];
+    __syncthreads();
+    int l = 0;
+    while (l + 1 < g->nlevels && (int)blockIdx.x >= kb.base[l + 1]) l++;
+    const int idx = ((int)blockIdx.x - kb.base[l]) * 4 + wave;
+    const int nl = g->nlevels;
+    int before = 0, totalAll = 0;
+    for (int i = 0; i < nl; i++) {
+        const int c = keptCount[f * nl + i];
+        if (i < l) before += c;
+        totalAll += c;
+    }
+    if (blockIdx.x == 0 && tid == 0) outCount[f] = totalAll < g->maxKp ? totalAll : g->maxKp;
+    if (idx >= keptCount[f * nl + l]) return;
+    const int o = before + idx;
+    if (o >= g->maxKp) return;
+    const LevelGeom& L = g->lv[l];
+    const uint64_t rec = kept[(int64_t)f * g->keptFrameRecs + L.keptOff + idx];
+    const int cx = (int)cand_x(rec) + kMinBorder, cy = (int)cand_y(rec) + kMinBorder;  // :843-844
+    int stride;
+    const uint8_t* img = level_ptr(g, src, f, l, stride);
+    const uint8_t* center = img + (int64_t)cy * stride + cx;
+
+    // IC_Angle: integer moments over the radius-15 disc of the raw level
+    int m10 = 0, m01 = 0;
+    {
+        const int half = lane >> 5, u = (lane & 31) - kHalfPatch;
+        for (int it = 0; it < 16; it++) {
+            const int v = -kHalfPatch + 2 * it + half;
+            if (v <= kHalfPatch && (lane & 31) <= 30) {
+                const int av = v < 0 ? -v : v;
+                const int d = g->umax[av];
+                if (u >= -d && u <= d) {
+                    const int val = center[v * stride + u];
+                    m10 += u * val;
+                    m01 += v * val;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // steered BRIEF on the blurred level: lane j owns tests j, j+64, j+128, j+192
+    constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float ang = __fmul_rn(angle, factorPI);
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    const uint8_t* bc = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)cy * L.blurStride + cx;
+    const int bs = L.blurStride;
+    uint64_t bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int32_t pk = spat[lane + 64 * r];
+        const float x0 = (float)(int8_t)(pk & 0xFF), y0 = (float)(int8_t)((pk >> 8) & 0xFF);
+        const float x1 = (float)(int8_t)((pk >> 16) & 0xFF), y1 = (float)(int8_t)((pk >> 24) & 0xFF);
+        const int ry0 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int rx0 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int ry1 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int rx1 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = bc[ry0 * bs + rx0], t1 = bc[ry1 * bs + rx1];
+        bits[r] = __ballot(t0 < t1);
+    }
+    if (lane < 4) ((uint64_t*)(outDesc + ((int64_t)f * g->maxKp + o) * 32))[lane] =
+        lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
+    if (lane == 0) {
+        OrbxKeyPointDev kp;
+        kp.x = __fmul_rn((float)cx, L.scale);  // level 0: scale == 1.0f, identity (:1095-1101)
+        kp.y = __fmul_rn((float)cy, L.scale);
+        kp.size = L.kpSize;
+        kp.angle = angle;
+        kp.response = (float)cand_resp(rec);
+        kp.octave = l;
+        kp.class_id = -1;
+        outKps[(int64_t)f * g->maxKp + o] = kp;
+    }
+}
+
+}  // namespace orbx

@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's ORBextractor (include/ORBextractor.h:45-111)
+over the C ABI.  Same constructor arguments, same getters, `__call__` = operator().
+All compute happens in HIP kernels; nothing here touches pixels."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, OrbxParams, check, lib, ptr
+
+
+class ORBextractor:
+    HARRIS_SCORE, FAST_SCORE = 0, 1  # ORBextractor.h:49 (unused enum in the reference too)
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
+                 max_width=1280, max_height=720, max_batch=1, device=0):
+        """ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+        -- src/ORBextractor.cc:410.  device=-1 gives a host-only handle (tables only)."""
+        self._L = lib()
+        self._h = C.c_void_p()
+        prm = OrbxParams(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST))
+        check(self._L.orbx_create(C.byref(prm), int(max_width), int(max_height), int(max_batch), int(device),
+                                  C.byref(self._h)))
+        self.nfeatures, self.nlevels, self.max_batch, self.device = nfeatures, nlevels, max_batch, device
+        self._cap = self._L.orbx_max_keypoints(self._h)
+        self._last_shape = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- getters (ORBextractor.h:60-83)
+    def GetLevels(self):
+        return self._L.orbx_levels(self._h)
+
+    def GetScaleFactor(self):
+        return self._L.orbx_scale_factor(self._h)
+
+    def _tables(self):
+        n = self.GetLevels()
+        a = [np.zeros(n, dtype=np.float32) for _ in range(4)]
+        check(self._L.orbx_scale_tables(self._h, *[ptr(x) for x in a]))
+        return a
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        out = np.zeros(self.GetLevels(), dtype=np.int32)
+        check(self._L.orbx_features_per_level(self._h, ptr(out)))
+        return out
+
+    def umax(self):
+        out = np.zeros(16, dtype=np.int32)
+        check(self._L.orbx_umax(self._h, ptr(out)))
+        return out
+
+    @property
+    def max_keypoints(self):
+        return self._cap
+
+    # ---- operator() (src/ORBextractor.cc:1043-1105); mask is ignored like in the reference
+    def __call__(self, image, mask=None):
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, dtype=KP_DTYPE), np.zeros((0, 32), dtype=np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "image.type() == CV_8UC1"
+        kps, desc = self.extract_batch(image[None])
+        return kps[0], desc[0]
+
+    def extract_batch(self, images):
+        """images: [B,H,W] uint8 host array (or list of [H,W]); returns lists of (kps, desc)."""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        B = len(imgs)
+        h, w = imgs[0].shape
+        cap = self._cap
+        kps = np.zeros((B, cap), dtype=KP_DTYPE)
+        desc = np.zeros((B, cap, 32), dtype=np.uint8)
+        n = np.zeros(B, dtype=np.int32)
+        arr = (C.c_void_p * B)(*[im.ctypes.data for im in imgs])
+        check(self._L.orbx_extract_batch(self._h, arr, B, w, h, w, ptr(kps), ptr(desc), cap, ptr(n)))
+        self._last_shape = (w, h)
+        return [kps[f, :n[f]].copy() for f in range(B)], [desc[f, :n[f]].copy() for f in range(B)]
+
+    # ---- device-resident path (frames already in HBM)
+    def extract_batch_device(self, d_ptr, B, w, h, stride, frame_pitch):
+        check(self._L.orbx_extract_batch_device(self._h, C.c_void_p(int(d_ptr)), int(B), int(w), int(h), int(stride),
+                                                C.c_size_t(int(frame_pitch))))
+        self._last_shape = (w, h)
+
+    def match_prev_batch_device(self, nnratio=0.7, th_low=50, check_ori=True):
+        check(self._L.orbx_match_prev_batch_device(self._h, C.c_float(nnratio), int(th_low), int(bool(check_ori))))
+
+    def reset_stream(self):
+        check(self._L.orbx_reset_stream(self._h))
+
+    def sync(self):
+        check(self._L.orbx_sync(self._h))
+
+    def download(self, frame):
+        cap = self._cap
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        check(self._L.orbx_download(self._h, int(frame), ptr(kps), ptr(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def download_matches(self, frame):
+        cap = self._cap
+        m = np.full(cap, -1, dtype=np.int32)
+        nm = C.c_int(0)
+        check(self._L.orbx_download_matches(self._h, int(frame), ptr(m), cap, C.byref(nm)))
+        return m, nm.value
+
+    def device_results(self):
+        k, d, c, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        check(self._L.orbx_device_results(self._h, C.byref(k), C.byref(d), C.byref(c), C.byref(cap)))
+        return k.value, d.value, c.value, cap.value
+
+    def device_matches(self):
+        m, n = C.c_void_p(), C.c_void_p()
+        check(self._L.orbx_device_matches(self._h, C.byref(m), C.byref(n)))
+        return m.value, n.value
+
+    # ---- mvImagePyramid (ORBextractor.h:85), lazy download
+    def pyramid_level(self, frame, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        check(self._L.orbx_pyramid_level(self._h, int(frame), int(level), int(blurred), None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), dtype=np.uint8)
+        check(self._L.orbx_pyramid_level(self._h, int(frame), int(level), int(blurred), ptr(out), C.byref(w), C.byref(h)))
+        return out
+
+    def level_candidates(self, frame, level):
+        n = C.c_int()
+        check(self._L.orbx_level_candidates(self._h, int(frame), int(level), None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.uint64)
+        check(self._L.orbx_level_candidates(self._h, int(frame), int(level), ptr(out), out.shape[0], C.byref(n)))
+        return out[:n.value]
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        check(self._L.orbx_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        p = _lib.OrbxProfile()
+        check(self._L.orbx_profile_read(self._h, C.byref(p), int(bool(reset))))
+        return {p.name[i].decode(): (p.ms[i], p.launches[i]) for i in range(p.n)}
+
+
+def unpack_candidates(rec):
+    """u64 candidate records -> (x, y, response, order) arrays (orbx_common.hpp: pack_cand)"""
+    rec = np.asarray(rec, dtype=np.uint64)
+    x = (rec & np.uint64(0x1FFF)).astype(np.int32)
+    y = ((rec >> np.uint64(13)) & np.uint64(0x1FFF)).astype(np.int32)
+    resp = (rec >> np.uint64(56)).astype(np.int32)
+    order = ((~(rec >> np.uint64(26))) & np.uint64(0x3FFFFFFF)).astype(np.int64)
+    return x, y, resp, order

@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference's ORBmatcher (include/ORBmatcher.h:37-102) over
+the C ABI, on flattened arrays (the MapPoint/KeyFrame object graph stays with the
+caller).  All Hamming work runs in HIP kernels."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import KP_DTYPE, OrbmFeatVec, OrbmGrid, OrbmProjParams, check, lib, ptr
+
+
+def make_grid(minX, minY, maxX, maxY, cols=64, rows=48):
+    """Frame.cc:212-213: mfGridElementWidthInv = FRAME_GRID_COLS / (mnMaxX - mnMinX) in float"""
+    g = OrbmGrid()
+    g.minX, g.minY = minX, minY
+    g.invW = np.float32(cols) / np.float32(np.float32(maxX) - np.float32(minX))
+    g.invH = np.float32(rows) / np.float32(np.float32(maxY) - np.float32(minY))
+    g.cols, g.rows = cols, rows
+    return g
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # ORBmatcher.cc:37-39
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        """ORBmatcher(float nnratio=0.6, bool checkOri=true) -- ORBmatcher.h:41"""
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+        self._L = lib()
+        self._h = C.c_void_p()
+        check(self._L.orbm_create(int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # static int DescriptorDistance(const cv::Mat&, const cv::Mat&) -- ORBmatcher.cc:1649
+    def DescriptorDistance(self, a, b):
+        return int(self.distance_matrix(np.asarray(a).reshape(1, 32), np.asarray(b).reshape(1, 32))[0, 0])
+
+    def distance_matrix(self, q, t):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        out = np.zeros((q.shape[0], t.shape[0]), dtype=np.int32)
+        check(self._L.orbm_distance_matrix(self._h, ptr(q), q.shape[0], ptr(t), t.shape[0], ptr(out)))
+        return out
+
+    def match_bruteforce(self, qdesc, qangle, tdesc, tangle, th_low=50):
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+        tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+        qangle = np.ascontiguousarray(qangle, dtype=np.float32)
+        tangle = np.ascontiguousarray(tangle, dtype=np.float32)
+        nq, nt = qdesc.shape[0], tdesc.shape[0]
+        match = np.full(max(nq, 1), -1, dtype=np.int32)
+        n = C.c_int(0)
+        check(self._L.orbm_match_bruteforce(self._h, ptr(qdesc), ptr(qangle), nq, ptr(tdesc), ptr(tangle), nt,
+                                            C.c_float(self.mfNNratio), int(th_low), int(self.mbCheckOrientation),
+                                            ptr(match), C.byref(n)))
+        return match[:nq], n.value
+
+    @staticmethod
+    def _fv(node_id, start, idx):
+        fv = OrbmFeatVec()
+        keep = (np.ascontiguousarray(node_id, dtype=np.uint32), np.ascontiguousarray(start, dtype=np.int32),
+                np.ascontiguousarray(idx, dtype=np.int32))
+        fv.n_nodes = keep[0].shape[0]
+        fv.node_id, fv.start, fv.idx = (k.ctypes.data for k in keep)
+        return fv, keep
+
+    def SearchByBoW(self, qdesc, qangle, qvalid, qfv, tdesc, tangle, tvalid, tfv, out_by_train=True):
+        """SearchByBoW(KeyFrame*, Frame&, ...) (out_by_train=True, ORBmatcher.cc:159) or
+        SearchByBoW(KeyFrame*, KeyFrame*, ...) (out_by_train=False, :524).  qfv/tfv = (node_id, start, idx)."""
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+        tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+        qangle = np.ascontiguousarray(qangle, dtype=np.float32)
+        tangle = np.ascontiguousarray(tangle, dtype=np.float32)
+        qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+        tv = None if tvalid is None else np.ascontiguousarray(tvalid, dtype=np.uint8)
+        nq, nt = qdesc.shape[0], tdesc.shape[0]
+        fq, kq = self._fv(*qfv)
+        ft, kt = self._fv(*tfv)
+        nout = nt if out_by_train else nq
+        match = np.full(max(nout, 1), -1, dtype=np.int32)
+        n = C.c_int(0)
+        check(self._L.orbm_search_by_bow(self._h, ptr(qdesc), ptr(qangle), ptr(qv), nq, C.byref(fq),
+                                         ptr(tdesc), ptr(tangle), ptr(tv), nt, C.byref(ft),
+                                         C.c_float(self.mfNNratio), int(self.mbCheckOrientation), int(bool(out_by_train)),
+                                         ptr(match), C.byref(n)))
+        return match[:nout], n.value
+
+    def SearchByProjection(self, mode, th_dist, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos,
+                           grid, t_keys_un, tdesc, t_occ, assign):
+        """The four SearchByProjection overloads, flattened (mode 3/4/5/6, see orbslamm_hip.h)."""
+        pp = OrbmProjParams(int(mode), self.mfNNratio, int(self.mbCheckOrientation), int(th_dist))
+        q_uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
+        q_lvl = np.ascontiguousarray(q_lvl, dtype=np.int8)
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+        qangle = np.ascontiguousarray(qangle, dtype=np.float32)
+        qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+        qo = None if q_obs_pos is None else np.ascontiguousarray(q_obs_pos, dtype=np.uint8)
+        t_keys_un = np.ascontiguousarray(t_keys_un, dtype=KP_DTYPE)
+        tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+        t_occ = np.ascontiguousarray(t_occ, dtype=np.uint8).copy()
+        assign = np.ascontiguousarray(assign, dtype=np.int32).copy()
+        n = C.c_int(0)
+        check(self._L.orbm_search_by_projection(self._h, C.byref(pp), ptr(q_uvr), ptr(q_lvl), ptr(qdesc), ptr(qangle),
+                                                ptr(qv), ptr(qo), q_uvr.shape[0], C.byref(grid), ptr(t_keys_un),
+                                                ptr(tdesc), t_keys_un.shape[0], ptr(t_occ), ptr(assign), C.byref(n)))
+        return assign, t_occ, n.value
+
+    def GetFeaturesInArea(self, grid, keys_un, x, y, r, minLevel=-1, maxLevel=-1):
+        """Frame::GetFeaturesInArea (Frame.cc:327-380) evaluated on the device grid"""
+        keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)
+        out = np.zeros(max(keys_un.shape[0], 1), dtype=np.int32)
+        n = C.c_int(0)
+        check(self._L.orbm_features_in_area(self._h, C.byref(grid), ptr(keys_un), keys_un.shape[0], C.c_float(x),
+                                            C.c_float(y), C.c_float(r), int(minLevel), int(maxLevel), ptr(out),
+                                            out.shape[0], C.byref(n)))
+        return out[:n.value].copy()
