@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of ORB extract + match-vs-previous-frame on MI355X.
+
+Workload (BASELINE.json configs[2]/[3]): KITTI-shape 1241x376 uint8 mono frames,
+2000 features, 8 levels, scale 1.2, FAST 20/7; every frame is extracted and
+brute-force Hamming matched against the previous frame of its stream.  A "step" is
+one pass of the hot path over one batch of `--batch` (default 64) frames that are
+already resident in HBM.  One process per GPU; each rank owns an independent camera
+stream (MultipleRobotsScenario: one tracking thread per robot) -- no data-path
+collective; RCCL only gathers the match statistics after the timed region.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _ROOT)
+
+W, H, NFEAT = 1241, 376, 2000
+STRIDE = 1280  # device rows are 64-byte aligned
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_bytes(ex, w, h, nfeat):
+    """staged dataflow, each stage reads its input once and writes
+    its output once.  Returns per-frame bytes per kernel and the total."""
+    from oracle import binding as ob  # only for level sizes of the documented figure
+    o = ob.Extractor(nfeat, 1.2, 8, 20, 7)
+    px = [a * b for a, b in (o.level_size(w, h, l) for l in range(8))]
+    S = sum(px)
+    per = {
+        "k_resize": (S - px[7]) + (S - px[0]),
+        "k_fast": S,
+        "k_blur": 2 * S,
+        "k_orient_desc": 749 * nfeat + 512 * nfeat + (32 + 28) * nfeat,
+        "k_distribute": 0,  # works on candidate records, not counted in the SURVEY figure
+        "k_match_best2": 2 * 32 * nfeat + 8 * nfeat,
+        "k_match_prune": 0,
+    }
+    return per, sum(per.values())
+
+
+def cpu_baseline(frames, seconds_budget=20.0):
+    """The oracle (a port: kind="port") timed single-threaded on this host."""
+    from oracle import binding as ob
+    try:
+        so = ob.build(march_native=True, out_dir="/tmp")
+        L = ob.lib(path=so)
+    except Exception:
+        L = ob.lib()
+    ex = ob.Extractor(NFEAT, 1.2, 8, 20, 7, L=L)
+    prev = None
+    t0 = time.perf_counter()
+    n = 0
+    for f in range(len(frames)):
+        r = ex(frames[f])
+        if prev is not None:
+            ob.match_bruteforce(r["desc"], r["kps"]["angle"], prev["desc"], prev["kps"]["angle"], 0.7, 50, True, L=L)
+        prev = r
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic %dx%d frames, extract + brute-force match, 1 thread, gcc -O3 -march=native -ffp-contract=off" % (n, W, H)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from orbslamm_amd import ORBextractor, synth
+
+    B = args.batch
+    frames = synth.make_frames(W, H, B, stream=rank)  # this rank's camera stream
+    padded = np.zeros((B, H, STRIDE), dtype=np.uint8)
+    padded[:, :, :W] = frames
+    d_frames = torch.from_numpy(padded).to("cuda:%d" % local_rank)
+    torch.cuda.synchronize()
+
+    ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
+
+    def step():
+        ex.extract_batch_device(d_frames.data_ptr(), B, W, H, STRIDE, STRIDE * H)
+        ex.match_prev_batch_device(0.7, 50, True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ex.sync()
+    if not args.no_profile:
+        ex.profile_enable(True)
+        ex.profile_read(reset=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ex.sync()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ex.profile_read(reset=True) if not args.no_profile else {}
+    ex.profile_enable(False)
+
+    # match statistics of the last batch; RCCL gather over xGMI (not on the data path)
+    m_ptr, n_ptr = ex.device_matches()
+    _, _, c_ptr, cap = ex.device_results()
+    nm = np.zeros(B, dtype=np.int32)
+    _, nmatch0 = ex.download_matches(B - 1)
+    kps_last, _ = ex.download(B - 1)
+    stats = torch.tensor([float(B * args.steps), float(len(kps_last)), float(nmatch0), dt], device="cuda:%d" % local_rank)
+    if world > 1:
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        tmax = torch.tensor([dt], device="cuda:%d" % local_rank)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_max = float(tmax.item())
+        gathered = [g.cpu().tolist() for g in gathered]
+    else:
+        dt_max = dt
+        gathered = [stats.cpu().tolist()]
+
+    if rank == 0:
+        total_frames = sum(g[0] for g in gathered)
+        fps = total_frames / dt_max
+        per, bytes_frame = algorithmic_bytes(ex, W, H, NFEAT)
+        out = {
+            "metric": "frames/s ORB extract+match, 1241x376 @2000 kp; bit-exact kp/desc vs CPU",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "KITTI-shape 1241x376 mono, 2000 features, 8 levels x1.2, FAST 20/7, extract + brute-force Hamming match vs previous frame (BASELINE.json configs[2]/[3])",
+                       "frames_per_step_per_gpu": B, "streams": world, "parallelism": "1 independent stream per GPU"},
+            "keypoints_last_frame": [int(g[1]) for g in gathered],
+            "matches_last_frame": [int(g[2]) for g in gathered],
+        }
+        if prof:
+            kern = {k: v for k, v in prof.items() if v[1] > 0 and k.startswith("k_")}
+            dom = max(kern, key=lambda k: kern[k][0])
+            avg_ms = kern[dom][0] / kern[dom][1]
+            launches_per_step = kern[dom][1] / args.steps
+            # k_resize is launched once per level (7 launches per step); its bytes are per step
+            alg_launch = per[dom] * B / launches_per_step
+            achieved = alg_launch / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_launch,
+                               "pipeline_bytes_per_frame": bytes_frame,
+                               "pipeline_achieved_GBs": fps / world * bytes_frame / 1e9,
+                               "pipeline_frac": fps / world * bytes_frame / 1e9 / HBM_PEAK_GBS,
+                               "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,12 +73,37 @@ def build(force=False):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so.7; if
+    this library pulled in /opt/rocm's copy first, a later `import torch` in the same
+    process would find the GPU already owned by the other runtime ("No HIP GPUs are
+    available").  So when torch is installed, its runtime is loaded (not torch itself)
+    before liborbslamm_hip.so, whose NEEDED libamdhip64.so.7 then resolves to it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(SO_PATH):
             raise RuntimeError("liborbslamm_hip.so is missing (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                "there is no CPU fallback for the ORB front-end")
+        _preload_hip_runtime()
         L = C.CDLL(SO_PATH)
         L.orbx_last_error.restype = C.c_char_p
         L.orbx_scale_factor.restype = C.c_float

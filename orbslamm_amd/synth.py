@@ -1,6 +1,6 @@
 """Deterministic synthetic camera streams: a static scene of random
 rectangles and discs on a canvas, a slowly panning viewport, additive noise.
-Pure numpy so that the CPU oracle and the GPU harness see identical bytes."""
+Pure numpy so that every harness (CPU checker, GPU bench) sees identical bytes."""
 import numpy as np
 
 

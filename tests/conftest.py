@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_count():
+    try:
+        from orbslamm_amd import _lib
+        return _lib.lib().orbx_device_count()
+    except Exception:
+        return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must FAIL loudly (no silent skip, no CPU fallback);
+    # without -m gpu, gpu tests are deselected by the marker expression the driver passes.
+    pass
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding as ob
+    ob.build()
+    return ob
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    n = _gpu_count()
+    assert n > 0, "no HIP device visible: gpu tests must run on the GPU box (there is no CPU fallback)"
+    return n
+
+
+def frames_for(w, h, n, stream=0):
+    from orbslamm_amd import synth
+    return synth.make_frames(w, h, n, stream=stream)
+
+
+def random_descriptors(rng, n):
+    return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)

@@ -1,0 +1,71 @@
+"""The C-ABI library loads, exports every symbol include/orbslamm_hip.h declares,
+its host-side tables agree with the oracle, and compute entries refuse to run
+without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "orbslamm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(orb[xm]_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from orbslamm_amd import _lib
+    L = _lib.lib()
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "missing export " + n
+    assert sorted(names) == sorted(_lib.EXPORTS)
+
+
+@pytest.mark.parametrize("nf,sf,nl", [(1000, 1.2, 8), (2000, 1.2, 8), (4000, 1.2, 8), (500, 1.5, 5), (1500, 1.1, 12)])
+def test_host_tables_match_oracle(oracle, nf, sf, nl):
+    from orbslamm_amd import ORBextractor
+    ex = ORBextractor(nf, sf, nl, 20, 7, max_width=752, max_height=480, device=-1)
+    oe = oracle.Extractor(nf, sf, nl, 20, 7)
+    assert ex.GetLevels() == nl
+    assert ex.GetScaleFactor() == np.float32(sf)
+    assert np.array_equal(ex.GetScaleFactors(), oe.scale_factors())
+    assert np.array_equal(ex.GetInverseScaleFactors(), np.array(oe.ex.mvInvScaleFactor[:nl], dtype=np.float32))
+    assert np.array_equal(ex.GetScaleSigmaSquares(), np.array(oe.ex.mvLevelSigma2[:nl], dtype=np.float32))
+    assert np.array_equal(ex.GetInverseScaleSigmaSquares(), np.array(oe.ex.mvInvLevelSigma2[:nl], dtype=np.float32))
+    assert ex.features_per_level().tolist() == oe.features_per_level()
+    assert ex.umax().tolist() == oe.umax()
+    assert ex.max_keypoints >= nf
+
+
+def test_bad_parameters_are_rejected():
+    from orbslamm_amd import ORBextractor, OrbError
+    for args in [(0, 1.2, 8, 20, 7), (1000, 1.0, 8, 20, 7), (1000, 1.2, 0, 20, 7), (1000, 1.2, 17, 20, 7)]:
+        with pytest.raises(OrbError) as e:
+            ORBextractor(*args, device=-1)
+        assert e.value.code == -1
+
+
+def test_no_cpu_fallback():
+    """Without a device the product refuses to compute.  (On the GPU box this test is
+    still valid: the host-only handle must refuse regardless.)"""
+    from orbslamm_amd import ORBextractor, OrbError
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, device=-1)
+    with pytest.raises(OrbError) as e:
+        ex(np.zeros((480, 640), np.uint8))
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    """grep-level guard: nothing under orbslamm_amd/ or include/ references oracle/"""
+    for base in ("orbslamm_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h")):
+                    txt = open(os.path.join(dp, f), errors="replace").read()
+                    assert "oracle" not in txt.lower().replace("no cpu fallback", ""), os.path.join(dp, f)

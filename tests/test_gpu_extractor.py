@@ -1,0 +1,223 @@
+"""GPU parity tests proper: the HIP extractor (through the C ABI) against the CPU
+oracle on the same seeded frames -- bit-exact keypoint records (28 B) and
+descriptor bytes -- plus stage-level parity (pyramid, blur, FAST candidates),
+edge cases and size-independent properties."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import frames_for
+from test_golden_cpu import check_against_golden
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def gpu_extractor(nf, w, h, B=1, sf=1.2, nl=8, ini=20, mn=7):
+    from orbslamm_amd import ORBextractor
+    return ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B, device=0)
+
+
+def assert_same(ref, kps, desc):
+    assert len(ref["kps"]) == len(kps)
+    for name in ref["kps"].dtype.names:
+        assert np.array_equal(ref["kps"][name], kps[name]), "field " + name
+    assert ref["kps"].tobytes() == kps.tobytes()
+    assert np.array_equal(ref["desc"], desc)
+
+
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (1241, 376, 2000), (320, 240, 500), (401, 263, 700),
+                                    (752, 480, 1200), (1241, 376, 4000), (480, 640, 800)])
+def test_extract_bit_exact(gpu, oracle, w, h, nf):
+    fr = frames_for(w, h, 2, stream=w % 7)
+    gex = gpu_extractor(nf, w, h, B=2)
+    kps, desc = gex.extract_batch(fr)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    for f in range(2):
+        assert_same(oex(fr[f]), kps[f], desc[f])
+
+
+@pytest.mark.parametrize("sf,nl,ini,mn,nf", [(1.5, 5, 20, 7, 600), (1.1, 12, 30, 10, 1500), (1.2, 8, 12, 12, 900),
+                                             (1.2, 1, 20, 7, 300), (1.3, 6, 40, 5, 50)])
+def test_extract_other_parameters(gpu, oracle, sf, nl, ini, mn, nf):
+    w, h = 640, 480
+    fr = frames_for(w, h, 1, stream=9)
+    gex = gpu_extractor(nf, w, h, 1, sf, nl, ini, mn)
+    kps, desc = gex.extract_batch(fr)
+    assert_same(oracle.Extractor(nf, sf, nl, ini, mn)(fr[0]), kps[0], desc[0])
+
+
+def test_tall_frame_is_refused_like_the_reference_would_crash(gpu, oracle):
+    # width/height of the FAST window < 0.5 -> nIni = round(..) = 0 -> hX = width/0 in the
+    # reference (ORBextractor.cc:543-545, UB).  Both oracle and product refuse the shape.
+    from orbslamm_amd import OrbError
+    with pytest.raises(OrbError) as e:
+        gpu_extractor(800, 300, 700)
+    assert e.value.code == -5
+    with pytest.raises(RuntimeError):
+        oracle.Extractor(800, 1.2, 8, 20, 7)(frames_for(300, 700, 1)[0])
+
+
+def test_stage_parity(gpu, oracle):
+    from orbslamm_amd import unpack_candidates
+    w, h, nf = 640, 480, 1000
+    fr = frames_for(w, h, 1)
+    gex = gpu_extractor(nf, w, h)
+    gex.extract_batch(fr)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    ref = oex(fr[0], want_pyramid=True)
+    off = 0
+    for l in range(8):
+        lw, lh = oex.level_size(w, h, l)
+        rl = ref["pyramid"][off:off + lw * lh].reshape(lh, lw)
+        off += lw * lh
+        assert np.array_equal(gex.pyramid_level(0, l), rl), "pyramid level %d" % l
+        assert np.array_equal(gex.pyramid_level(0, l, blurred=True), oracle.gaussian7(rl)), "blur level %d" % l
+        rc = oex.level_candidates(rl)
+        gx, gy, gr, go = unpack_candidates(gex.level_candidates(0, l))
+        o = np.argsort(go, kind="stable")  # reference push order is encoded in the record
+        assert len(rc) == len(gx) == ref["cand_counts"][l]
+        assert np.array_equal(rc["x"], gx[o]) and np.array_equal(rc["y"], gy[o]) and np.array_equal(rc["score"], gr[o])
+
+
+def test_golden_fixtures(gpu):
+    for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))):
+        g = np.load(path)
+        w, h, nf, nl, ini, mn, stream = [int(v) for v in g["params"]]
+        fr = frames_for(w, h, 2, stream=stream)
+        gex = gpu_extractor(nf, w, h, B=2, sf=float(g["scale"]), nl=nl, ini=ini, mn=mn)
+        kps, desc = gex.extract_batch(fr)
+        from orbslamm_amd import ORBmatcher
+        m, n = ORBmatcher(0.7, True).match_bruteforce(desc[1], kps[1]["angle"], desc[0], kps[0]["angle"])
+        check_against_golden(g, kps, desc, m, n)
+
+
+def test_edge_cases(gpu, oracle):
+    w, h = 320, 240
+    gex = gpu_extractor(500, w, h, B=3)
+    # empty image: silent return, outputs untouched (ORBextractor.cc:1046-1047)
+    k, d = gex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    # constant image: no corners at either threshold
+    k, d = gex(np.full((h, w), 128, np.uint8))
+    assert len(k) == 0
+    # all-white / all-black, a vertical step edge (no FAST-9 corners on a straight edge)
+    step = np.zeros((h, w), np.uint8)
+    step[:, w // 2:] = 255
+    for img in (np.full((h, w), 255, np.uint8), np.zeros((h, w), np.uint8), step):
+        k, d = gex(img)
+        assert len(k) == len(oracle.Extractor(500, 1.2, 8, 20, 7)(img)["kps"])
+    # low-contrast noise: only the minThFAST retry finds anything -> still bit-exact
+    rng = np.random.default_rng(4)
+    lo = (120 + rng.integers(-9, 10, size=(h, w))).astype(np.uint8)
+    ref = oracle.Extractor(500, 1.2, 8, 20, 7)(lo)
+    k, d = gex(lo)
+    assert len(ref["kps"]) > 0
+    assert_same(ref, k, d)
+    # pure white noise: far more candidates than nfeatures at every level
+    noise = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    assert_same(oracle.Extractor(500, 1.2, 8, 20, 7)(noise), *gex(noise))
+    # ragged batch content: frames of one batch are independent
+    frs = np.stack([noise, lo, step])
+    kk, dd = gex.extract_batch(frs)
+    for f in range(3):
+        assert_same(oracle.Extractor(500, 1.2, 8, 20, 7)(frs[f]), kk[f], dd[f])
+
+
+def test_strided_and_smaller_shape_on_same_handle(gpu, oracle):
+    gex = gpu_extractor(800, 800, 600)
+    big = frames_for(800, 600, 1, stream=2)[0]
+    view = big[40:40 + 360, 100:100 + 500]  # non-contiguous rows, stride 800
+    assert not view.flags["C_CONTIGUOUS"]
+    L = gex._L
+    cap = gex.max_keypoints
+    from orbslamm_amd import KP_DTYPE
+    kps = np.zeros(cap, dtype=KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int()
+    rc = L.orbx_extract(gex._h, C.c_void_p(view.ctypes.data), 500, 360, 800, kps.ctypes.data_as(C.c_void_p),
+                        desc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    assert rc == 0
+    ref = oracle.Extractor(800, 1.2, 8, 20, 7)(np.ascontiguousarray(view))
+    assert_same(ref, kps[:n.value], desc[:n.value])
+    # capacity overflow is reported, nothing written past cap
+    small = np.zeros(10, dtype=KP_DTYPE)
+    sd = np.full((11, 32), 0xEE, np.uint8)
+    rc = L.orbx_extract(gex._h, C.c_void_p(view.ctypes.data), 500, 360, 800, small.ctypes.data_as(C.c_void_p),
+                        sd.ctypes.data_as(C.c_void_p), 10, C.byref(n))
+    assert rc == -4 and n.value == len(ref["kps"]) and (sd[10] == 0xEE).all()
+
+
+def test_batch_and_device_path_agree_with_single(gpu, oracle):
+    import torch
+    w, h, nf, B = 1241, 376, 2000, 8
+    fr = frames_for(w, h, B, stream=1)
+    gex = gpu_extractor(nf, w, h, B=B)
+    kb, db = gex.extract_batch(fr)
+    # device-resident frames with padded stride
+    stride = 1280
+    pad = np.zeros((B, h, stride), np.uint8)
+    pad[:, :, :w] = fr
+    dt = torch.from_numpy(pad).cuda()
+    gex.reset_stream()
+    gex.extract_batch_device(dt.data_ptr(), B, w, h, stride, stride * h)
+    gex.match_prev_batch_device(0.7, 50, True)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    prev = None
+    for f in range(B):
+        k, d = gex.download(f)
+        assert k.tobytes() == kb[f].tobytes() and np.array_equal(d, db[f])
+        m, nm = gex.download_matches(f)
+        if f in (0, 1, B - 1):
+            ref = oex(fr[f])
+            assert_same(ref, k, d)
+        if prev is None:
+            assert nm == 0 and (m[:len(k)] == -1).all()  # no previous frame in a fresh stream
+        else:
+            mr, nr = oracle.match_bruteforce(d, k["angle"], prev[1], prev[0]["angle"], 0.7, 50, True)
+            assert nm == nr and np.array_equal(m[:len(k)], mr)
+        prev = (k, d)
+    # next batch: frame 0 is matched against the last frame of the previous batch
+    gex.extract_batch_device(dt.data_ptr(), B, w, h, stride, stride * h)
+    gex.match_prev_batch_device(0.7, 50, True)
+    k0, d0 = gex.download(0)
+    m, nm = gex.download_matches(0)
+    mr, nr = oracle.match_bruteforce(d0, k0["angle"], prev[1], prev[0]["angle"], 0.7, 50, True)
+    assert nm == nr and np.array_equal(m[:len(k0)], mr)
+
+
+def test_properties_full_size(gpu):
+    """size-independent properties at BASELINE's full size with 64 frames in flight"""
+    import torch
+    w, h, nf, B = 1241, 376, 2000, 64
+    fr = frames_for(w, h, 4, stream=5)
+    pad = np.zeros((B, h, 1280), np.uint8)
+    for f in range(B):
+        pad[f, :, :w] = fr[f % 4]
+    dt = torch.from_numpy(pad).cuda()
+    gex = gpu_extractor(nf, w, h, B=B)
+    gex.extract_batch_device(dt.data_ptr(), B, w, h, 1280, 1280 * h)
+    gex.match_prev_batch_device(0.7, 50, True)
+    res = [gex.download(f) for f in range(B)]
+    for f in range(4, B):  # determinism: identical frames give identical bytes wherever they sit in the batch
+        assert res[f][0].tobytes() == res[f % 4][0].tobytes() and np.array_equal(res[f][1], res[f % 4][1])
+    fpl = gex.features_per_level()
+    for k, d in res[:4]:
+        assert len(k) >= nf - 50 and (np.diff(k["octave"]) >= 0).all()
+        cnt = np.bincount(k["octave"], minlength=8)
+        assert (cnt >= fpl).all() and (cnt <= fpl + 2).all()
+        assert len(np.unique(np.stack([k["x"], k["y"], k["octave"].astype(np.float32)], 1), axis=0)) == len(k)
+    # a frame matched against an identical previous frame maps every keypoint to itself
+    gex2 = gpu_extractor(nf, w, h, B=2)
+    same = np.stack([pad[0], pad[0]])
+    d2 = torch.from_numpy(same).cuda()
+    gex2.extract_batch_device(d2.data_ptr(), 2, w, h, 1280, 1280 * h)
+    gex2.match_prev_batch_device(0.7, 50, True)
+    m, nm = gex2.download_matches(1)
+    k, _ = gex2.download(1)
+    kept = m[:len(k)]
+    assert nm == (kept >= 0).sum() and nm > 0.8 * len(k)
+    assert (kept[kept >= 0] == np.nonzero(kept >= 0)[0]).all()

@@ -1,0 +1,189 @@
+"""CPU tests of the oracle against everything the reference pins for this path.
+
+The reference has no tests/golden vectors and OpenCV is absent, so
+parity at the OpenCV boundary is UNPINNED; what can be pinned is checked here:
+the BRIEF pattern hash, the umax table, the per-level feature split and level
+sizes derived from the reference formulas, and the
+self-derivable invariants listed in SURVEY.md 8(c)."""
+import hashlib
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATTERN_SHA = "7e645581387b82784797e8adddb9b6f0c12611859fda09ca8a9bec96d767a05f"
+
+
+def _read_pattern(path):
+    txt = open(path).read()
+    txt = txt[txt.index("*/") + 2:]
+    return [int(t) for t in txt.replace("\n", "").split(",") if t.strip()]
+
+
+@pytest.mark.parametrize("rel", ["oracle/brief_pattern.inc", "orbslamm_amd/csrc/brief_pattern.inc"])
+def test_brief_pattern_hash(rel):
+    vals = _read_pattern(os.path.join(ROOT, rel))
+    assert len(vals) == 1024
+    assert hashlib.sha256(struct.pack("<1024i", *vals)).hexdigest() == PATTERN_SHA
+
+
+def test_umax_and_feature_split(oracle):
+    ex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    assert ex.umax() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert ex.features_per_level() == [217, 181, 151, 126, 105, 87, 73, 60]
+    ex2 = oracle.Extractor(2000, 1.2, 8, 20, 7)
+    assert ex2.features_per_level() == [434, 362, 302, 251, 209, 175, 145, 122]
+    sf = ex.scale_factors()
+    assert sf[0] == 1.0 and sf[1] == np.float32(1.2) and sf[7] == np.float32(3.5831816)
+
+
+def test_level_sizes_appendix_b(oracle):
+    ex = oracle.Extractor(2000, 1.2, 8, 20, 7)
+    assert [ex.level_size(1241, 376, l) for l in range(8)] == [
+        (1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]
+    assert [ex.level_size(640, 480, l) for l in range(8)] == [
+        (640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+
+
+def test_hamming_properties(oracle):
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, 32, dtype=np.uint8)
+    b = rng.integers(0, 256, 32, dtype=np.uint8)
+    assert oracle.descriptor_distance(a, a) == 0
+    assert oracle.descriptor_distance(a, ~a) == 256
+    d = oracle.descriptor_distance(a, b)
+    assert d == oracle.descriptor_distance(b, a)
+    assert d == int(np.unpackbits(a ^ b).sum())
+
+
+def test_fast_nothing_on_flat_and_ramp(oracle):
+    assert len(oracle.fast(np.full((60, 60), 77, np.uint8), 20)) == 0
+    ramp = np.tile(np.arange(60, dtype=np.uint8) * 4, (60, 1))
+    assert len(oracle.fast(ramp, 20)) == 0
+
+
+def test_fast_single_bright_dot(oracle):
+    img = np.full((40, 40), 50, np.uint8)
+    img[20, 20] = 200  # isolated dot: all 16 ring pixels darker by 150
+    c = oracle.fast(img, 20)
+    assert [(int(k["x"]), int(k["y"]), int(k["score"])) for k in c] == [(20, 20, 149)]
+
+
+def test_fast_equal_neighbours_suppress_each_other(oracle):
+    # two adjacent identical maxima: strict > kills both (this is what triggers the minTh retry)
+    img = np.full((40, 40), 50, np.uint8)
+    img[20, 20] = 200
+    img[20, 21] = 200
+    c = oracle.fast(img, 20)
+    assert len(c) == 0
+
+
+def test_gaussian_kernel_and_constant(oracle):
+    img = np.full((50, 70), 255, np.uint8)
+    assert np.array_equal(oracle.gaussian7(img), img)  # sum 257 -> saturates to 255
+    img2 = np.full((50, 70), 100, np.uint8)
+    # (100*257*257 + 32768) >> 16 = 101  (kernel sums to 257, not renormalised)
+    assert int(oracle.gaussian7(img2)[25, 35]) == (100 * 257 * 257 + 32768) >> 16
+    imp = np.zeros((21, 21), np.uint8)
+    imp[10, 10] = 255
+    k = np.array([18, 34, 49, 55, 49, 34, 18])
+    want = (255 * np.outer(k, k) + 32768) >> 16
+    assert np.array_equal(oracle.gaussian7(imp)[7:14, 7:14], want)
+
+
+def test_fast_atan2_close_to_libm(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    for _ in range(500):
+        y, x = rng.integers(-400000, 400000, 2)
+        a = L.orc_fast_atan2(float(y), float(x))
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        d = abs(a - ref)
+        assert min(d, 360 - d) < 0.3
+    assert L.orc_fast_atan2(0.0, 0.0) == 0.0
+
+
+def test_resize_constant_and_shape(oracle):
+    img = np.full((100, 120), 131, np.uint8)
+    out = oracle.resize(img, 100, 83)
+    assert out.shape == (83, 100) and (out == 131).all()
+
+
+def test_descriptor_constant_image_is_zero(oracle):
+    # strict "<" on equal samples -> every bit 0
+    ex = oracle.Extractor(500, 1.2, 8, 20, 7)
+    L = oracle.lib()
+    img = np.full((64, 64), 9, np.uint8)
+    desc = np.full(32, 0xAA, np.uint8)
+    import ctypes as C
+    L.orc_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.orc_brief(img.ctypes.data, 64, 32, 32, 33.0, desc.ctypes.data)
+    assert (desc == 0).all()
+
+
+def test_distribute_keeps_everything_when_few(oracle):
+    rng = np.random.default_rng(5)
+    n = 40
+    pts = set()
+    while len(pts) < n:
+        pts.add((int(rng.integers(3, 597)), int(rng.integers(3, 400))))
+    c = np.zeros(n, dtype=oracle.CORNER_DTYPE)
+    for i, (x, y) in enumerate(sorted(pts)):
+        c[i] = (x, y, int(rng.integers(10, 200)))
+    out = oracle.distribute(c, 16, 616, 16, 419, 500)
+    assert len(out) == n
+    assert sorted(map(tuple, out.tolist())) == sorted(map(tuple, c.tolist()))
+
+
+def test_distribute_size_bounds(oracle):
+    # careful phase stops at >= N having added <= 3 per split: N..N+2; the first pass from the
+    # 4 roots (1209/344 -> nIni = 4) may already hold 16 nodes
+    rng = np.random.default_rng(6)
+    for N in (10, 50, 217, 434):
+        n = 3000
+        xs = rng.integers(3, 1206, n)
+        ys = rng.integers(3, 341, n)
+        seen = {}
+        for x, y in zip(xs, ys):
+            seen[(int(x), int(y))] = int(rng.integers(7, 250))
+        c = np.zeros(len(seen), dtype=oracle.CORNER_DTYPE)
+        for i, ((x, y), s) in enumerate(seen.items()):
+            c[i] = (x, y, s)
+        out = oracle.distribute(c, 16, 1225, 16, 360, N)
+        assert N <= len(out) <= max(N + 2, 16)
+        assert len(set(map(tuple, out.tolist()))) == len(out)
+
+
+def test_three_maxima_rule(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    h = np.zeros(30, np.int32)
+    h[3], h[7], h[20] = 100, 9, 50
+    i1, i2, i3 = C.c_int(), C.c_int(), C.c_int()
+    L.orc_three_maxima(h.ctypes.data_as(C.c_void_p), 30, C.byref(i1), C.byref(i2), C.byref(i3))
+    assert (i1.value, i2.value, i3.value) == (3, 20, -1)  # 9 < 0.1*100 drops the third
+    assert L.orc_rot_bin(10.0, 350.0) == 1   # rot=20 -> round(20/30)=1 (sic, factor 1/30)
+    assert L.orc_rot_bin(350.0, 10.0) == 11  # rot=340 -> round(11.33)=11
+    assert L.orc_rot_bin(0.0, 0.0) == 0
+
+
+def test_extract_counts_and_ranges(oracle):
+    from conftest import frames_for
+    fr = frames_for(640, 480, 1)[0]
+    ex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    r = ex(fr)
+    kps = r["kps"]
+    assert 900 <= len(kps) <= 1000 + 16
+    assert (kps["class_id"] == -1).all()
+    assert set(np.unique(kps["octave"])) <= set(range(8))
+    assert ((kps["angle"] >= 0) & (kps["angle"] < 360)).all()
+    assert (np.diff(kps["octave"]) >= 0).all()  # concatenated level by level
+    sizes = {0: 31, 1: 37, 2: 44, 3: 53, 4: 64, 5: 77, 6: 92, 7: 111}
+    for o, s in sizes.items():
+        assert (kps["size"][kps["octave"] == o] == s).all()
+    # level-0 keypoints stay >= 19 px inside (EDGE_THRESHOLD)
+    k0 = kps[kps["octave"] == 0]
+    assert k0["x"].min() >= 19 and k0["x"].max() <= 640 - 20 and k0["y"].min() >= 19 and k0["y"].max() <= 480 - 20
