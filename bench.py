@@ -12,7 +12,6 @@ collective; RCCL only gathers the match statistics after the timed region.
 Prints ONE JSON line on rank 0 (see the contract in the task statement).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -83,25 +82,19 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
+    from orbslamm_amd import streams
+
+    rank, world, local_rank = streams.env_rank()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    streams.init("nccl", device)  # "nccl" is RCCL on ROCm; no-op when WORLD_SIZE == 1
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from orbslamm_amd import ORBextractor, synth
 
     B = args.batch
-    frames = synth.make_frames(W, H, B, stream=rank)  # this rank's camera stream
+    frames = synth.make_frames(W, H, B, stream=streams.stream_of_rank(rank)[0])  # this rank's camera stream
     padded = np.zeros((B, H, STRIDE), dtype=np.uint8)
     padded[:, :, :W] = frames
     d_frames = torch.from_numpy(padded).to("cuda:%d" % local_rank)
@@ -113,49 +106,27 @@ def main():
         ex.extract_batch_device(d_frames.data_ptr(), B, W, H, STRIDE, STRIDE * H)
         ex.match_prev_batch_device(0.7, 50, True)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    def sync():
+        ex.sync()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    ex.sync()
+    sync()
     if not args.no_profile:
         ex.profile_enable(True)
         ex.profile_read(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ex.sync()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = streams.timed_region(step, args.steps, sync, world)
     prof = ex.profile_read(reset=True) if not args.no_profile else {}
     ex.profile_enable(False)
 
-    # match statistics of the last batch; RCCL gather over xGMI (not on the data path)
-    m_ptr, n_ptr = ex.device_matches()
-    _, _, c_ptr, cap = ex.device_results()
-    nm = np.zeros(B, dtype=np.int32)
-    _, nmatch0 = ex.download_matches(B - 1)
+    # match statistics of the last frame; RCCL all_gather over xGMI (not on the data path)
+    _, nmatch_last = ex.download_matches(B - 1)
     kps_last, _ = ex.download(B - 1)
-    stats = torch.tensor([float(B * args.steps), float(len(kps_last)), float(nmatch0), dt], device="cuda:%d" % local_rank)
-    if world > 1:
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        tmax = torch.tensor([dt], device="cuda:%d" % local_rank)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_max = float(tmax.item())
-        gathered = [g.cpu().tolist() for g in gathered]
-    else:
-        dt_max = dt
-        gathered = [stats.cpu().tolist()]
+    gathered, dt_max = streams.gather_stats((B * args.steps, len(kps_last), nmatch_last, dt), world, device)
 
     if rank == 0:
-        total_frames = sum(g[0] for g in gathered)
-        fps = total_frames / dt_max
+        fps, total_frames = streams.aggregate(gathered, dt_max)
         per, bytes_frame = algorithmic_bytes(ex, W, H, NFEAT)
         out = {
             "metric": "frames/s ORB extract+match, 1241x376 @2000 kp; bit-exact kp/desc vs CPU",
@@ -185,8 +156,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    streams.finalize(world)
 
 
 if __name__ == "__main__":
