@@ -81,34 +81,33 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
     args = ap.parse_args()
 
-    import torch
-
-    from orbslamm_amd import streams
+    from orbslamm_amd import ORBextractor, streams, synth
 
     rank, world, local_rank = streams.env_rank()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    streams.init("nccl", device)  # "nccl" is RCCL on ROCm; no-op when WORLD_SIZE == 1
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-
-    from orbslamm_amd import ORBextractor, synth
+    torch = None
+    device = "cpu"
+    if world > 1:
+        # torch only for torch.distributed (backend "nccl" = RCCL over xGMI); a 1-GPU run
+        # needs no torch at all (its first import on a cold box can take minutes)
+        import torch
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        streams.init("nccl", device)
 
     B = args.batch
     frames = synth.make_frames(W, H, B, stream=streams.stream_of_rank(rank)[0])  # this rank's camera stream
-    padded = np.zeros((B, H, STRIDE), dtype=np.uint8)
-    padded[:, :, :W] = frames
-    d_frames = torch.from_numpy(padded).to("cuda:%d" % local_rank)
-    torch.cuda.synchronize()
-
     ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
+    dargs = ex.upload_frames(frames, stride=STRIDE)  # frames resident in HBM before the timed region
 
     def step():
-        ex.extract_batch_device(d_frames.data_ptr(), B, W, H, STRIDE, STRIDE * H)
+        ex.extract_batch_device(*dargs)
         ex.match_prev_batch_device(0.7, 50, True)
 
     def sync():
-        ex.sync()
-        torch.cuda.synchronize()
+        ex.sync()  # hipStreamSynchronize of the handle's stream (all work of this process is on it)
+        if torch is not None:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()

@@ -115,6 +115,13 @@ int orbx_level_candidates(orbx_t* h, int frame, int level, uint64_t* dst, int ca
 
 int orbx_sync(orbx_t* h);
 
+/* Convenience for hosts that do not link HIP themselves (the reference does not):
+ * device buffers for the device-resident entry points, on the handle's GPU.
+ * orbx_upload is a blocking host->device copy. */
+int orbx_device_alloc(orbx_t* h, size_t bytes, void** d_ptr);
+int orbx_device_free(orbx_t* h, void* d_ptr);
+int orbx_upload(orbx_t* h, void* d_dst, const void* h_src, size_t bytes);
+
 /* "match vs previous frame" for the stream held by this handle:
  * frame f of the last extracted batch is matched against frame f-1 (frame 0 against
  * the last frame of the previous batch; no previous frame -> no matches).

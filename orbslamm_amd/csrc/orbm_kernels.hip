@@ -41,19 +41,28 @@ __device__ __forceinline__ int rot_bin(float aq, float at)
     return bin;
 }
 
-// query slot = qslot0 + blockIdx.y, train slot = tslot0 + blockIdx.y
-__global__ __launch_bounds__(256) void k_match_best2(MatchIO q, MatchIO t, int qslot0, int tslot0,
-                                                    float nnratio, int thLow, int checkOri,
-                                                    int32_t* __restrict__ match, int64_t matchPitch,
-                                                    uint8_t* __restrict__ binOf,
-                                                    int32_t* __restrict__ hist /* [frames][32] */)
+// Brute-force best/second over a CHUNK of the train descriptors.
+// grid (queryBlocks, frames, chunks): chunking multiplies the wave count (2000 queries are
+// only 32 waves per frame) and the scalar loads of U train descriptors are issued one
+// iteration ahead of their use (software pipeline), so the loop is VALU-bound.
+// partial[(f*nchunks + chunk)*pitch + q] = {k1, k2}: k1 = best<<20 | trainIdx, k2 = second<<20 | 0xFFFFF.
+constexpr int kMatchUnroll = 4;
+
+__device__ __forceinline__ void best2_update(int d, int j, int& best1, int& best2, int& bestIdx)
 {
-    const int f = blockIdx.y;
+    if (d < best1) { best2 = best1; best1 = d; bestIdx = j; }
+    else if (d < best2) best2 = d;
+}
+
+__global__ __launch_bounds__(256) void k_match_best2(MatchIO q, MatchIO t, int qslot0, int tslot0, int nchunks,
+                                                    uint2* __restrict__ partial, int64_t pitch)
+{
+    const int f = blockIdx.y, chunk = blockIdx.z;
     const int qi = blockIdx.x * 256 + threadIdx.x;
     const int nq = q.count[qslot0 + f], nt = t.count[tslot0 + f];
     if (blockIdx.x * 256 >= nq) return;
     const uint8_t* qd = q.desc + (int64_t)(qslot0 + f) * q.descPitch;
-    const uint32_t* td = (const uint32_t*)(t.desc + (int64_t)(tslot0 + f) * t.descPitch);
+    const uint32_t* __restrict__ td = (const uint32_t*)(t.desc + (int64_t)(tslot0 + f) * t.descPitch);
     uint32_t qw[8];
     {
         const int qq = qi < nq ? qi : nq - 1;
@@ -62,22 +71,75 @@ __global__ __launch_bounds__(256) void k_match_best2(MatchIO q, MatchIO t, int q
         qw[0] = a.x; qw[1] = a.y; qw[2] = a.z; qw[3] = a.w;
         qw[4] = b.x; qw[5] = b.y; qw[6] = b.z; qw[7] = b.w;
     }
+    constexpr int U = kMatchUnroll;
+    int chunkLen = (nt + nchunks - 1) / nchunks;
+    chunkLen = (chunkLen + U - 1) / U * U;
+    const int j0 = chunk * chunkLen;
+    const int j1 = min(nt, j0 + chunkLen);
     int best1 = 256, best2 = 256, bestIdx = -1;
-    for (int j = 0; j < nt; j++) {
-        const int d = hamming256(qw, td + 8 * j);
-        if (d < best1) { best2 = best1; best1 = d; bestIdx = j; }
-        else if (d < best2) best2 = d;
+    int j = j0;
+    if (j + U <= j1) {
+        uint32_t cur[U][8], nxt[U][8];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) cur[u][i] = td[8 * (j + u) + i];
+        for (; j + 2 * U <= j1; j += U) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) nxt[u][i] = td[8 * (j + U + u) + i];
+#pragma unroll
+            for (int u = 0; u < U; u++) best2_update(hamming256(qw, cur[u]), j + u, best1, best2, bestIdx);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) cur[u][i] = nxt[u][i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) best2_update(hamming256(qw, cur[u]), j + u, best1, best2, bestIdx);
+        j += U;
     }
+    for (; j < j1; j++) best2_update(hamming256(qw, td + 8 * j), j, best1, best2, bestIdx);
     if (qi >= nq) return;
+    uint2 r;
+    r.x = bestIdx < 0 ? 0xFFFFFFFFu : (((uint32_t)best1 << 20) | (uint32_t)bestIdx);
+    r.y = ((uint32_t)best2 << 20) | 0xFFFFFu;
+    partial[((int64_t)f * nchunks + chunk) * pitch + qi] = r;
+}
+
+// merge the chunk partials in index order, apply the acceptance rule (ORBmatcher.cc:230-232)
+// and histogram the rotation bin (:238-248)
+__global__ __launch_bounds__(256) void k_match_accept(MatchIO q, MatchIO t, int qslot0, int tslot0, int nchunks,
+                                                     const uint2* __restrict__ partial, int64_t pitch,
+                                                     float nnratio, int thLow, int checkOri,
+                                                     int32_t* __restrict__ match, int64_t matchPitch,
+                                                     uint8_t* __restrict__ binOf, int32_t* __restrict__ hist)
+{
+    const int f = blockIdx.y;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int nq = q.count[qslot0 + f];
+    if (qi >= nq) return;
+    uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    for (int c = 0; c < nchunks; c++) {
+        const uint2 p = partial[((int64_t)f * nchunks + c) * pitch + qi];
+        const uint32_t lo = min(k1, p.x), hi = max(k1, p.x);
+        k2 = min(hi, min(k2, p.y));
+        k1 = lo;
+    }
     int m = -1;
-    if (best1 <= thLow && (float)best1 < __fmul_rn(nnratio, (float)best2)) {  // :230-232
-        m = bestIdx;
-        if (checkOri) {
-            const float aq = q.ang[(int64_t)(qslot0 + f) * q.angPitch + (int64_t)qi * q.angStride];
-            const float at = t.ang[(int64_t)(tslot0 + f) * t.angPitch + (int64_t)bestIdx * t.angStride];
-            const int bin = rot_bin(aq, at);
-            binOf[(int64_t)f * matchPitch + qi] = (uint8_t)bin;
-            atomicAdd(&hist[f * 32 + bin], 1);
+    if (k1 != 0xFFFFFFFFu) {
+        const int best1 = (int)(k1 >> 20), bestIdx = (int)(k1 & 0xFFFFFu);
+        const int best2 = k2 == 0xFFFFFFFFu ? 256 : min(256, (int)(k2 >> 20));
+        if (best1 <= thLow && (float)best1 < __fmul_rn(nnratio, (float)best2)) {
+            m = bestIdx;
+            if (checkOri) {
+                const float aq = q.ang[(int64_t)(qslot0 + f) * q.angPitch + (int64_t)qi * q.angStride];
+                const float at = t.ang[(int64_t)(tslot0 + f) * t.angPitch + (int64_t)bestIdx * t.angStride];
+                const int bin = rot_bin(aq, at);
+                binOf[(int64_t)f * matchPitch + qi] = (uint8_t)bin;
+                atomicAdd(&hist[f * 32 + bin], 1);
+            }
         }
     }
     match[(int64_t)f * matchPitch + qi] = m;

@@ -57,9 +57,9 @@ static inline int cv_round(double v) { return (int)lrint(v); }  // cvRound: half
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------ profiling
-enum ProfId { P_H2D = 0, P_RESIZE, P_FAST, P_DISTRIBUTE, P_BLUR, P_ORIENT_DESC, P_MATCH_BEST2, P_MATCH_PRUNE, P_D2H, P_COUNT };
+enum ProfId { P_H2D = 0, P_RESIZE, P_FAST, P_DISTRIBUTE, P_BLUR, P_ORIENT_DESC, P_MATCH_BEST2, P_MATCH_ACCEPT, P_MATCH_PRUNE, P_D2H, P_COUNT };
 static const char* kProfNames[P_COUNT] = {"h2d", "k_resize", "k_fast", "k_distribute", "k_blur",
-                                          "k_orient_desc", "k_match_best2", "k_match_prune", "d2h"};
+                                          "k_orient_desc", "k_match_best2", "k_match_accept", "k_match_prune", "d2h"};
 struct ProfSpan { int id; hipEvent_t a, b; };
 
 struct Profiler {
@@ -129,6 +129,8 @@ struct orbx_handle {
     int kpBlocksTotal = 0;
 
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // blur runs beside FAST + quadtree
+    hipEvent_t evPyr = nullptr, evBlur = nullptr;
     // device buffers (sized for maxW x maxH x maxB at create)
     Geom* d_geom = nullptr;
     Cell* d_cells = nullptr; size_t cellsCap = 0;
@@ -150,6 +152,7 @@ struct orbx_handle {
     uint8_t* d_binOf = nullptr;          // [maxB][maxKp]
     int32_t* d_hist = nullptr;           // [maxB][32]
     int32_t* d_nmatch = nullptr;         // [maxB]
+    uint2* d_partial = nullptr;          // [maxB][kMatchChunks][maxKp] chunk partials of the brute-force scan
     uint8_t* h_pinned = nullptr; size_t pinnedBytes = 0;
     int lastB = 0;
     FrameSrc lastSrc{};
@@ -344,12 +347,12 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
             out.tabs.push_back(make_short4((short)clip(sy), (short)clip(sy + 1), sat((1.f - fy) * 2048), sat(fy * 2048)));
         }
     }
-    // blur tiles (64x16) and orient/desc blocks (4 keypoints) per level
+    // blur tiles (kBlurTW x kBlurTH) and orient/desc blocks (4 keypoints) per level
     int tb = 0, kb = 0;
     for (int l = 0; l < g.nlevels; l++) {
         out.bt.base[l] = tb;
-        out.bt.tilesX[l] = (g.lv[l].w + 63) / 64;
-        tb += out.bt.tilesX[l] * ((g.lv[l].h + 15) / 16);
+        out.bt.tilesX[l] = (g.lv[l].w + kBlurTW - 1) / kBlurTW;
+        tb += out.bt.tilesX[l] * ((g.lv[l].h + kBlurTH - 1) / kBlurTH);
         out.kb.base[l] = kb;
         kb += (g.lv[l].keptCap + 3) / 4;
     }
@@ -359,6 +362,8 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     return ORBX_OK;
 }
 
+static constexpr int kMatchChunks = 4;  // train chunks per query block (wave count x4)
+
 static size_t dist_lds_bytes(int cap) { return (size_t)(17 * cap + 8) * 4; }
 
 // ------------------------------------------------------------------ create / destroy
@@ -367,12 +372,16 @@ static void free_device(orbx_handle* h)
     if (h->device < 0) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     h->prof.destroy();
     void* ptrs[] = {h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
                     h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
-                    h->d_match, h->d_binOf, h->d_hist, h->d_nmatch};
+                    h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    if (h->evPyr) (void)hipEventDestroy(h->evPyr);
+    if (h->evBlur) (void)hipEventDestroy(h->evBlur);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -398,6 +407,9 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
 #define CRT(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int r_ = fail(ORBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); free_device(h); delete h; return r_; } } while (0)
     CRT(hipSetDevice(device));
     CRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CRT(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    CRT(hipEventCreateWithFlags(&h->evPyr, hipEventDisableTiming));
+    CRT(hipEventCreateWithFlags(&h->evBlur, hipEventDisableTiming));
     const size_t B = (size_t)max_batch;
     // capacities with head-room so that smaller shapes (different cell layouts) also fit
     h->cellsCap = hg.cells.size() * 2 + 64;
@@ -429,6 +441,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_binOf, B * (size_t)h->maxKp));
     CRT(hipMalloc(&h->d_hist, B * 32 * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_nmatch, B * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_partial, B * kMatchChunks * h->maxKp * sizeof(uint2)));
     CRT(hipMemset(h->d_err, 0, sizeof(int32_t)));
     CRT(hipMemset(h->d_count, 0, (B + 1) * sizeof(int32_t)));
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
@@ -548,6 +561,14 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         hipLaunchKernelGGL(k_resize, grid, block, 0, s, h->d_geom, src, h->tabs, l);
         h->prof.end(s);
     }
+    // blur only needs the pyramid: run it on the second stream beside FAST + quadtree
+    hipStream_t s2 = h->stream2;
+    HIPCHK(hipEventRecord(h->evPyr, s));
+    HIPCHK(hipStreamWaitEvent(s2, h->evPyr, 0));
+    h->prof.begin(P_BLUR, s2);
+    hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], B), dim3(256), 0, s2, h->d_geom, src, h->blurTiles);
+    h->prof.end(s2);
+    HIPCHK(hipEventRecord(h->evBlur, s2));
     if (g.totalCells > 0) {
         const size_t lds = (size_t)2 * h->tileRows * h->tileStrideDw * 4;
         h->prof.begin(P_FAST, s);
@@ -559,9 +580,7 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     hipLaunchKernelGGL(k_distribute, dim3(g.nlevels, B), dim3(kDistThreads), dist_lds_bytes(h->nodeCap), s, h->d_geom,
                        h->d_candRaw, h->d_candA, h->d_candB, h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->nodeCap);
     h->prof.end(s);
-    h->prof.begin(P_BLUR, s);
-    hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], B), dim3(256), 0, s, h->d_geom, src, h->blurTiles);
-    h->prof.end(s);
+    HIPCHK(hipStreamWaitEvent(s, h->evBlur, 0));
     h->prof.begin(P_ORIENT_DESC, s);
     hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, B), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
                        h->d_keptCount, h->d_kps + h->maxKp, h->d_desc + (size_t)h->maxKp * 32, h->d_count + 1);
@@ -602,6 +621,33 @@ extern "C" int orbx_sync(orbx_t* h)
         (void)hipMemset(h->d_err, 0, sizeof err);
         return fail(ORBX_E_CAPACITY, "device scratch overflow (flags 0x%x)", err);
     }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_device_alloc(orbx_t* h, size_t bytes, void** d_ptr)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!d_ptr || bytes == 0) return fail(ORBX_E_INVALID, "bad argument");
+    HIPCHK(hipMalloc(d_ptr, bytes));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_device_free(orbx_t* h, void* d_ptr)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (d_ptr) HIPCHK(hipFree(d_ptr));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_upload(orbx_t* h, void* d_dst, const void* h_src, size_t bytes)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!d_dst || !h_src) return fail(ORBX_E_INVALID, "null argument");
+    HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
     return ORBX_OK;
 }
 
@@ -726,8 +772,13 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     hipStream_t s = h->stream;
     orbm::MatchIO io = slots_io(h);
     h->prof.begin(P_MATCH_BEST2, s);
-    hipLaunchKernelGGL(orbm::k_match_best2, dim3((h->maxKp + 255) / 256, B), dim3(256), 0, s, io, io, 1, 0, nnratio, th_low,
-                       check_ori, h->d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist);
+    hipLaunchKernelGGL(orbm::k_match_best2, dim3((h->maxKp + 255) / 256, B, kMatchChunks), dim3(256), 0, s, io, io, 1, 0,
+                       kMatchChunks, h->d_partial, (int64_t)h->maxKp);
+    h->prof.end(s);
+    h->prof.begin(P_MATCH_ACCEPT, s);
+    hipLaunchKernelGGL(orbm::k_match_accept, dim3((h->maxKp + 255) / 256, B), dim3(256), 0, s, io, io, 1, 0, kMatchChunks,
+                       (const uint2*)h->d_partial, (int64_t)h->maxKp, nnratio, th_low, check_ori, h->d_match,
+                       (int64_t)h->maxKp, h->d_binOf, h->d_hist);
     h->prof.end(s);
     h->prof.begin(P_MATCH_PRUNE, s);
     hipLaunchKernelGGL(orbm::k_match_prune, dim3(B), dim3(256), 0, s, io, 1, check_ori, h->d_match, (int64_t)h->maxKp,
@@ -898,8 +949,12 @@ extern "C" int orbm_match_bruteforce(orbm_t* h, const uint8_t* qdesc, const floa
     orbm::MatchIO q{(const uint8_t*)h->d_buf[0], 0, (const float*)h->d_buf[2], 0, 1, (const int32_t*)h->d_buf[4]};
     orbm::MatchIO t{(const uint8_t*)h->d_buf[1], 0, (const float*)h->d_buf[3], 0, 1, (const int32_t*)h->d_buf[4] + 1};
     int32_t* d_hist = (int32_t*)h->d_buf[7];
-    hipLaunchKernelGGL(orbm::k_match_best2, dim3((nq + 255) / 256, 1), dim3(256), 0, s, q, t, 0, 0, nnratio, th_low, check_ori,
-                       (int32_t*)h->d_buf[5], (int64_t)nq, (uint8_t*)h->d_buf[6], d_hist);
+    if ((rc = orbm_reserve(h, 8, (size_t)nq * kMatchChunks * sizeof(uint2)))) return rc;
+    hipLaunchKernelGGL(orbm::k_match_best2, dim3((nq + 255) / 256, 1, kMatchChunks), dim3(256), 0, s, q, t, 0, 0, kMatchChunks,
+                       (uint2*)h->d_buf[8], (int64_t)nq);
+    hipLaunchKernelGGL(orbm::k_match_accept, dim3((nq + 255) / 256, 1), dim3(256), 0, s, q, t, 0, 0, kMatchChunks,
+                       (const uint2*)h->d_buf[8], (int64_t)nq, nnratio, th_low, check_ori, (int32_t*)h->d_buf[5],
+                       (int64_t)nq, (uint8_t*)h->d_buf[6], d_hist);
     hipLaunchKernelGGL(orbm::k_match_prune, dim3(1), dim3(256), 0, s, q, 0, check_ori, (int32_t*)h->d_buf[5], (int64_t)nq,
                        (const uint8_t*)h->d_buf[6], d_hist, d_hist + 32);
     HIPCHK(hipGetLastError());

@@ -574,41 +574,100 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
+// 128x32 output tile per 256-thread block.  Global traffic is aligned dwords (byte
+// path only where a dword straddles the image border); every thread owns 4 adjacent
+// pixels in both passes, so LDS is read as b32/b64 and the result leaves as one dword.
+constexpr int kBlurTW = 128, kBlurTH = 32;
+
 __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt)
 {
-    constexpr int TW = 64, TH = 16;
-    __shared__ uint8_t in[TH + 6][TW + 8];
-    __shared__ uint16_t rp[TH + 6][TW];
+    constexpr int TW = kBlurTW, TH = kBlurTH;
+    constexpr int IN_DW = (TW + 8) / 4;       // 34 dwords per input row (4 px margin each side)
+    constexpr int IN_STRIDE = IN_DW + 1;      // 35
+    constexpr int RP_STRIDE = TW / 2 + 2;     // 66 dwords (u16 pairs), even for b64 reads
+    __shared__ uint32_t in[(TH + 6) * IN_STRIDE];
+    __shared__ uint32_t rp[(TH + 6) * RP_STRIDE];
     const int f = blockIdx.y;
     int l = 0;
     while (l + 1 < g->nlevels && (int)blockIdx.x >= bt.base[l + 1]) l++;
     const int tIdx = blockIdx.x - bt.base[l];
     const int tx0 = (tIdx % bt.tilesX[l]) * TW, ty0 = (tIdx / bt.tilesX[l]) * TH;
     const LevelGeom& L = g->lv[l];
+    const int w = L.w, h = L.h;
     int stride;
     const uint8_t* S = level_ptr(g, src, f, l, stride);
     const int tid = threadIdx.x;
-    for (int i = tid; i < (TH + 6) * (TW + 6); i += 256) {
-        const int r = i / (TW + 6), c = i % (TW + 6);
-        const int sy = reflect101(ty0 + r - 3, L.h), sx = reflect101(tx0 + c - 3, L.w);
-        in[r][c] = S[(int64_t)sy * stride + sx];
+
+    for (int i = tid; i < (TH + 6) * IN_DW; i += 256) {
+        const int r = i / IN_DW, c = i - r * IN_DW;
+        const int sy = reflect101(ty0 + r - 3, h);
+        const int x0 = tx0 - 4 + 4 * c;
+        const uint8_t* row = S + (int64_t)sy * stride;
+        uint32_t v;
+        if (x0 >= 0 && x0 + 3 < w) {
+            v = *(const uint32_t*)(row + x0);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect101(x0 + k, w)] << (8 * k);
+        }
+        in[r * IN_STRIDE + c] = v;
     }
     __syncthreads();
-    const int kx = tid & 63, ky = tid >> 6;
-    for (int r = ky; r < TH + 6; r += 4) {
-        const uint8_t* p = &in[r][kx];
-        const int s = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        rp[r][kx] = (uint16_t)s;  // <= 257*255 = 65535
+
+    const int xq = tid & 31, yr = tid >> 5;
+    for (int r = yr; r < TH + 6; r += 8) {
+        const uint32_t d0 = in[r * IN_STRIDE + xq], d1 = in[r * IN_STRIDE + xq + 1], d2 = in[r * IN_STRIDE + xq + 2];
+        uint32_t b[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            b[k] = (d0 >> (8 * k)) & 0xFF;
+            b[4 + k] = (d1 >> (8 * k)) & 0xFF;
+            b[8 + k] = (d2 >> (8 * k)) & 0xFF;
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)  // <= 257*255 = 65535
+            o[i] = 18 * (b[1 + i] + b[7 + i]) + 34 * (b[2 + i] + b[6 + i]) + 49 * (b[3 + i] + b[5 + i]) + 55 * b[4 + i];
+        uint2 st;
+        st.x = o[0] | (o[1] << 16);
+        st.y = o[2] | (o[3] << 16);
+        *(uint2*)&rp[r * RP_STRIDE + 2 * xq] = st;
     }
     __syncthreads();
+
+    uint32_t acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[j][i] = 1u << 15;
+    constexpr uint32_t K[7] = {18, 34, 49, 55, 49, 34, 18};
+#pragma unroll
+    for (int rr = 0; rr < 10; rr++) {
+        const uint2 v = *(const uint2*)&rp[(yr * 4 + rr) * RP_STRIDE + 2 * xq];
+        const uint32_t e[4] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int tap = rr - j;
+            if (tap >= 0 && tap < 7) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[j][i] += K[tap] * e[i];
+            }
+        }
+    }
     uint8_t* D = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff;
-    for (int r = ky; r < TH; r += 4) {
-        const int x = tx0 + kx, y = ty0 + r;
-        if (x < L.w && y < L.h) {
-            int s = 18 * (rp[r][kx] + rp[r + 6][kx]) + 34 * (rp[r + 1][kx] + rp[r + 5][kx]) +
-                    49 * (rp[r + 2][kx] + rp[r + 4][kx]) + 55 * rp[r + 3][kx];
-            s = (s + (1 << 15)) >> 16;
-            D[(int64_t)y * L.blurStride + x] = (uint8_t)(s > 255 ? 255 : s);
+    const int x = tx0 + 4 * xq;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int y = ty0 + yr * 4 + j;
+        if (x < w && y < h) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t sv = acc[j][i] >> 16;
+                pk |= (sv > 255u ? 255u : sv) << (8 * i);
+            }
+            *(uint32_t*)(D + (int64_t)y * L.blurStride + x) = pk;
         }
     }
 }

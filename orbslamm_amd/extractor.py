@@ -24,9 +24,13 @@ class ORBextractor:
         self.nfeatures, self.nlevels, self.max_batch, self.device = nfeatures, nlevels, max_batch, device
         self._cap = self._L.orbx_max_keypoints(self._h)
         self._last_shape = None
+        self._dev_bufs = []
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
+            for d in getattr(self, "_dev_bufs", []):
+                self._L.orbx_device_free(self._h, d)
+            self._dev_bufs = []
             self._L.orbx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -99,6 +103,20 @@ class ORBextractor:
         return [kps[f, :n[f]].copy() for f in range(B)], [desc[f, :n[f]].copy() for f in range(B)]
 
     # ---- device-resident path (frames already in HBM)
+    def upload_frames(self, frames, stride=None):
+        """copy [B,H,W] uint8 host frames into a device buffer with 64-byte aligned rows;
+        returns (device_ptr, B, w, h, stride, frame_pitch).  The buffer lives until close()."""
+        frames = np.asarray(frames, dtype=np.uint8)
+        B, h, w = frames.shape
+        stride = stride or (w + 63) // 64 * 64
+        pad = np.zeros((B, h, stride), dtype=np.uint8)
+        pad[:, :, :w] = frames
+        d = C.c_void_p()
+        check(self._L.orbx_device_alloc(self._h, C.c_size_t(pad.nbytes), C.byref(d)))
+        self._dev_bufs.append(d)
+        check(self._L.orbx_upload(self._h, d, ptr(pad), C.c_size_t(pad.nbytes)))
+        return d.value, B, w, h, stride, stride * h
+
     def extract_batch_device(self, d_ptr, B, w, h, stride, frame_pitch):
         check(self._L.orbx_extract_batch_device(self._h, C.c_void_p(int(d_ptr)), int(B), int(w), int(h), int(stride),
                                                 C.c_size_t(int(frame_pitch))))

@@ -152,18 +152,14 @@ def test_strided_and_smaller_shape_on_same_handle(gpu, oracle):
 
 
 def test_batch_and_device_path_agree_with_single(gpu, oracle):
-    import torch
     w, h, nf, B = 1241, 376, 2000, 8
     fr = frames_for(w, h, B, stream=1)
     gex = gpu_extractor(nf, w, h, B=B)
     kb, db = gex.extract_batch(fr)
     # device-resident frames with padded stride
-    stride = 1280
-    pad = np.zeros((B, h, stride), np.uint8)
-    pad[:, :, :w] = fr
-    dt = torch.from_numpy(pad).cuda()
+    dargs = gex.upload_frames(fr, stride=1280)
     gex.reset_stream()
-    gex.extract_batch_device(dt.data_ptr(), B, w, h, stride, stride * h)
+    gex.extract_batch_device(*dargs)
     gex.match_prev_batch_device(0.7, 50, True)
     oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
     prev = None
@@ -181,7 +177,7 @@ def test_batch_and_device_path_agree_with_single(gpu, oracle):
             assert nm == nr and np.array_equal(m[:len(k)], mr)
         prev = (k, d)
     # next batch: frame 0 is matched against the last frame of the previous batch
-    gex.extract_batch_device(dt.data_ptr(), B, w, h, stride, stride * h)
+    gex.extract_batch_device(*dargs)
     gex.match_prev_batch_device(0.7, 50, True)
     k0, d0 = gex.download(0)
     m, nm = gex.download_matches(0)
@@ -191,15 +187,11 @@ def test_batch_and_device_path_agree_with_single(gpu, oracle):
 
 def test_properties_full_size(gpu):
     """size-independent properties at BASELINE's full size with 64 frames in flight"""
-    import torch
     w, h, nf, B = 1241, 376, 2000, 64
     fr = frames_for(w, h, 4, stream=5)
-    pad = np.zeros((B, h, 1280), np.uint8)
-    for f in range(B):
-        pad[f, :, :w] = fr[f % 4]
-    dt = torch.from_numpy(pad).cuda()
+    rep = np.stack([fr[f % 4] for f in range(B)])
     gex = gpu_extractor(nf, w, h, B=B)
-    gex.extract_batch_device(dt.data_ptr(), B, w, h, 1280, 1280 * h)
+    gex.extract_batch_device(*gex.upload_frames(rep, stride=1280))
     gex.match_prev_batch_device(0.7, 50, True)
     res = [gex.download(f) for f in range(B)]
     for f in range(4, B):  # determinism: identical frames give identical bytes wherever they sit in the batch
@@ -212,9 +204,7 @@ def test_properties_full_size(gpu):
         assert len(np.unique(np.stack([k["x"], k["y"], k["octave"].astype(np.float32)], 1), axis=0)) == len(k)
     # a frame matched against an identical previous frame maps every keypoint to itself
     gex2 = gpu_extractor(nf, w, h, B=2)
-    same = np.stack([pad[0], pad[0]])
-    d2 = torch.from_numpy(same).cuda()
-    gex2.extract_batch_device(d2.data_ptr(), 2, w, h, 1280, 1280 * h)
+    gex2.extract_batch_device(*gex2.upload_frames(np.stack([fr[0], fr[0]]), stride=1280))
     gex2.match_prev_batch_device(0.7, 50, True)
     m, nm = gex2.download_matches(1)
     k, _ = gex2.download(1)
