@@ -122,7 +122,7 @@ struct orbx_handle {
     Geom geom;
     int curW = 0, curH = 0;
     std::vector<Cell> cells;
-    int tileStrideDw = 0, tileRows = 0;
+    int tileStrideDw = 0, tileRows = 0, fastListCap = 0;
     int nodeCap = 0;
     BlurTiles blurTiles;
     KpBlocks kpBlocks;
@@ -130,7 +130,9 @@ struct orbx_handle {
 
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // blur runs beside FAST + quadtree
-    hipEvent_t evPyr = nullptr, evBlur = nullptr;
+    hipStream_t stream3 = nullptr;            // matching runs beside the next batch's pyramid/FAST
+    hipEvent_t evPyr = nullptr, evBlur = nullptr, evDesc = nullptr, evMatch = nullptr;
+    bool matchPending = false;
     // device buffers (sized for maxW x maxH x maxB at create)
     Geom* d_geom = nullptr;
     Cell* d_cells = nullptr; size_t cellsCap = 0;
@@ -209,7 +211,7 @@ struct HostGeom {
     std::vector<Cell> cells;
     std::vector<short4> tabs;          // all x/y tables back to back
     int xoff[ORBX_MAXL], yoff[ORBX_MAXL];
-    int tileStrideDw, tileRows, nodeCap;
+    int tileStrideDw, tileRows, fastListCap, nodeCap;
     BlurTiles bt;
     int blurTilesTotal;
     KpBlocks kb;
@@ -310,6 +312,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     g.maxKp = keptOff;
     out.tileStrideDw = ((3 + maxRoiW + 3) / 4 + 1) | 1;  // odd dword stride
     out.tileRows = maxRoiH;
+    out.fastListCap = ((maxRoiW - 6) * (maxRoiH - 6) + 63) / 64 * 64;  // compacted detection pixels
     out.nodeCap = align_up(nodeCap, 2);
 
     // cv::resize INTER_LINEAR coefficient tables, levels >= 1
@@ -373,6 +376,7 @@ static void free_device(orbx_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     h->prof.destroy();
     void* ptrs[] = {h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
                     h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
@@ -381,6 +385,9 @@ static void free_device(orbx_handle* h)
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->evPyr) (void)hipEventDestroy(h->evPyr);
     if (h->evBlur) (void)hipEventDestroy(h->evBlur);
+    if (h->evDesc) (void)hipEventDestroy(h->evDesc);
+    if (h->evMatch) (void)hipEventDestroy(h->evMatch);
+    if (h->stream3) (void)hipStreamDestroy(h->stream3);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
 }
@@ -410,6 +417,9 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CRT(hipEventCreateWithFlags(&h->evPyr, hipEventDisableTiming));
     CRT(hipEventCreateWithFlags(&h->evBlur, hipEventDisableTiming));
+    CRT(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    CRT(hipEventCreateWithFlags(&h->evDesc, hipEventDisableTiming));
+    CRT(hipEventCreateWithFlags(&h->evMatch, hipEventDisableTiming));
     const size_t B = (size_t)max_batch;
     // capacities with head-room so that smaller shapes (different cell layouts) also fit
     h->cellsCap = hg.cells.size() * 2 + 64;
@@ -495,6 +505,15 @@ extern "C" int orbx_max_keypoints(const orbx_t* h)
 }
 
 // ------------------------------------------------------------------ shape configuration
+static int sync_all(orbx_handle* h)
+{
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    HIPCHK(hipStreamSynchronize(h->stream3));
+    h->matchPending = false;
+    return ORBX_OK;
+}
+
 static int configure_shape(orbx_handle* h, int w, int hh)
 {
     if (h->curW == w && h->curH == hh) return ORBX_OK;
@@ -511,7 +530,7 @@ static int configure_shape(orbx_handle* h, int w, int hh)
     if (dist_lds_bytes(hg.nodeCap) > 48 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)k_distribute, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dist_lds_bytes(hg.nodeCap)));
     hg.g.maxKp = h->maxKp;  // output slots keep their create-time pitch
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
     HIPCHK(hipMemcpy(h->d_geom, &hg.g, sizeof(Geom), hipMemcpyHostToDevice));
     if (!hg.cells.empty()) HIPCHK(hipMemcpy(h->d_cells, hg.cells.data(), hg.cells.size() * sizeof(Cell), hipMemcpyHostToDevice));
     if (!hg.tabs.empty()) HIPCHK(hipMemcpy(h->d_tabs, hg.tabs.data(), hg.tabs.size() * sizeof(short4), hipMemcpyHostToDevice));
@@ -521,7 +540,7 @@ static int configure_shape(orbx_handle* h, int w, int hh)
     }
     h->geom = hg.g;
     h->cells = hg.cells;
-    h->tileStrideDw = hg.tileStrideDw; h->tileRows = hg.tileRows; h->nodeCap = hg.nodeCap;
+    h->tileStrideDw = hg.tileStrideDw; h->tileRows = hg.tileRows; h->fastListCap = hg.fastListCap; h->nodeCap = hg.nodeCap;
     h->blurTiles = hg.bt; h->kpBlocks = hg.kb; h->kpBlocksTotal = hg.kbTotal;
     h->geom.totalCells = hg.g.totalCells;
     h->curW = w; h->curH = hh;
@@ -570,10 +589,10 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     h->prof.end(s2);
     HIPCHK(hipEventRecord(h->evBlur, s2));
     if (g.totalCells > 0) {
-        const size_t lds = (size_t)2 * h->tileRows * h->tileStrideDw * 4;
+        const size_t lds = (size_t)2 * h->tileRows * h->tileStrideDw * 4 + (size_t)h->fastListCap * 2;
         h->prof.begin(P_FAST, s);
         hipLaunchKernelGGL(k_fast, dim3(g.totalCells, B), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
-                           h->d_candCount, h->d_err, h->tileStrideDw, h->tileRows);
+                           h->d_candCount, h->d_err, h->tileStrideDw, h->tileRows, h->fastListCap);
         h->prof.end(s);
     }
     h->prof.begin(P_DISTRIBUTE, s);
@@ -581,6 +600,8 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
                        h->d_candRaw, h->d_candA, h->d_candB, h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->nodeCap);
     h->prof.end(s);
     HIPCHK(hipStreamWaitEvent(s, h->evBlur, 0));
+    // the output slots are still being read by the previous batch's matching on stream3
+    if (h->matchPending) HIPCHK(hipStreamWaitEvent(s, h->evMatch, 0));
     h->prof.begin(P_ORIENT_DESC, s);
     hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, B), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
                        h->d_keptCount, h->d_kps + h->maxKp, h->d_desc + (size_t)h->maxKp * 32, h->d_count + 1);
@@ -614,7 +635,7 @@ extern "C" int orbx_sync(orbx_t* h)
 {
     int rc = check_device(h);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
     int32_t err = 0;
     HIPCHK(hipMemcpy(&err, h->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (err) {
@@ -637,7 +658,7 @@ extern "C" int orbx_device_free(orbx_t* h, void* d_ptr)
 {
     int rc = check_device(h);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
     if (d_ptr) HIPCHK(hipFree(d_ptr));
     return ORBX_OK;
 }
@@ -680,7 +701,7 @@ extern "C" int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, 
     // stage through pinned memory into the aligned device frames
     const int dstride = align_up(w, 64);
     const size_t dpitch = (size_t)dstride * hh;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;  // the staging frames may still be read by the previous call
     for (int f = 0; f < B; f++) {
         if (!imgs[f]) return fail(ORBX_E_INVALID, "null frame %d", f);
         for (int y = 0; y < hh; y++) memcpy(h->h_pinned + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
@@ -769,7 +790,10 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     if (rc) return rc;
     const int B = h->lastB;
     if (B < 1) return fail(ORBX_E_INVALID, "no extracted batch to match");
-    hipStream_t s = h->stream;
+    // matching runs on its own stream so that the next batch's pyramid/FAST can start beside it
+    hipStream_t s = h->stream3;
+    HIPCHK(hipEventRecord(h->evDesc, h->stream));
+    HIPCHK(hipStreamWaitEvent(s, h->evDesc, 0));
     orbm::MatchIO io = slots_io(h);
     h->prof.begin(P_MATCH_BEST2, s);
     hipLaunchKernelGGL(orbm::k_match_best2, dim3((h->maxKp + 255) / 256, B, kMatchChunks), dim3(256), 0, s, io, io, 1, 0,
@@ -788,7 +812,9 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     HIPCHK(hipMemcpyAsync(h->d_kps, h->d_kps + (size_t)B * h->maxKp, (size_t)h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(h->d_desc, h->d_desc + (size_t)B * h->maxKp * 32, (size_t)h->maxKp * 32, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(h->d_count, h->d_count + B, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipEventRecord(h->evMatch, s));
     HIPCHK(hipGetLastError());
+    h->matchPending = true;
     h->havePrev = true;
     return ORBX_OK;
 }
@@ -820,7 +846,9 @@ extern "C" int orbx_reset_stream(orbx_t* h)
 {
     int rc = check_device(h);
     if (rc) return rc;
+    if ((rc = sync_all(h))) return rc;
     HIPCHK(hipMemsetAsync(h->d_count, 0, sizeof(int32_t), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->havePrev = false;
     return ORBX_OK;
 }
@@ -838,7 +866,7 @@ extern "C" int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset)
     int rc = check_device(h);
     if (rc) return rc;
     if (!out) return fail(ORBX_E_INVALID, "null argument");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
     h->prof.collect();
     out->n = P_COUNT;
     for (int i = 0; i < P_COUNT; i++) {

@@ -87,20 +87,17 @@ __global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, Fram
 // pixels of min(v - p_k) resp. min(p_k - v): the pixel is a FAST-9 corner at
 // threshold t iff S > t, and cv::FAST's cornerScore is then S - 1 (threshold
 // independent), so the minThFAST retry re-thresholds the same S map.
-__device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p, const int* off, int tq)
+//
+// Two-stage: a cheap compass test (every 9-arc holds one pixel of each opposite pair)
+// runs on all pixels and COMPACTS the survivors (about a quarter of a busy image) into
+// an LDS list; the exact 16-arc score, the 3x3 non-max suppression and the emission
+// then run on the dense list, so no lane idles through the heavy part.
+__device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p, const int* off)
 {
     const int v = p[0];
     int d[16];
-    // quick reject (each 9-arc contains one pixel of every opposite pair)
-    d[0] = v - p[off[0]];
-    d[8] = v - p[off[8]];
-    if (abs(d[0]) <= tq && abs(d[8]) <= tq) return 0;
-    d[4] = v - p[off[4]];
-    d[12] = v - p[off[12]];
-    if (abs(d[4]) <= tq && abs(d[12]) <= tq) return 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (k != 0 && k != 8 && k != 4 && k != 12) d[k] = v - p[off[k]];
+    for (int k = 0; k < 16; k++) d[k] = v - p[off[k]];
     int mn2[16], mx2[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
@@ -122,7 +119,7 @@ __device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p, const int* 
 __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const Cell* __restrict__ cells,
                                             FrameSrc src, uint64_t* __restrict__ cand,
                                             int32_t* __restrict__ candCount, int32_t* __restrict__ errFlag,
-                                            int tileStrideDw, int tileRows)
+                                            int tileStrideDw, int tileRows, int listCap)
 {
     extern __shared__ uint32_t lds[];
     const Cell c = cells[blockIdx.x];
@@ -136,6 +133,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     uint32_t* tile = lds;                                   // [tileRows][tileStrideDw] dwords
     const int tsb = tileStrideDw * 4;                       // tile stride in bytes
     uint8_t* smap = (uint8_t*)(lds + tileRows * tileStrideDw);  // same geometry, bytes
+    uint16_t* list = (uint16_t*)(lds + 2 * tileRows * tileStrideDw);  // compacted (y<<8 | x)
     const uint8_t* tb = (const uint8_t*)tile;
 
     const int cw = c.w, ch = c.h;
@@ -160,45 +158,66 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
         for (int k = 0; k < 16; k++) off[k] = cx[k] + cy[k] * tsb;
     }
     const int dw = cw - 6, dh = ch - 6;  // detection area
-    const int tq = min(g->iniTh, g->minTh) < 0 ? 0 : min(g->iniTh, g->minTh);
+    int th = g->iniTh < 0 ? 0 : (g->iniTh > 255 ? 255 : g->iniTh);
+    const int th2 = g->minTh < 0 ? 0 : (g->minTh > 255 ? 255 : g->minTh);
+    const int tq = min(th, th2);
+    const uint64_t lt = lanemask_lt();
+    const int pos0 = 3 * tsb + shift + 3;  // tile byte offset of detection pixel (0,0)
 
+    // stage 1: compass test on every pixel, survivors compacted (S <= tq otherwise: never a
+    // corner at either threshold and never a suppressing neighbour)
+    int cnt = 0;
     for (int xb = 0; xb < dw; xb += 32) {
         const int x = xb + (lane & 31);
-        for (int y = lane >> 5; y < dh; y += 2) {
-            if (x < dw) {
-                const int pos = (y + 3) * tsb + shift + x + 3;
-                const int S = fast_S(tb + pos, off, tq);
-                smap[pos] = (uint8_t)S;
+        for (int y0 = 0; y0 < dh; y0 += 2) {
+            const int y = y0 + (lane >> 5);
+            bool pass = false;
+            if (x < dw && y < dh) {
+                const uint8_t* p = tb + pos0 + y * tsb + x;
+                const int v = p[0];
+                const int d0 = v - p[off[0]], d8 = v - p[off[8]], d4 = v - p[off[4]], d12 = v - p[off[12]];
+                pass = !(abs(d0) <= tq && abs(d8) <= tq) && !(abs(d4) <= tq && abs(d12) <= tq);
             }
+            const uint64_t bal = __ballot(pass);
+            if (pass) {
+                const int slot = cnt + __popcll(bal & lt);
+                if (slot < listCap) list[slot] = (uint16_t)((y << 8) | x);
+            }
+            cnt += __popcll(bal);
         }
+    }
+    if (cnt > listCap) { if (lane == 0) atomicOr(errFlag, 8); cnt = listCap; }
+    __syncthreads();
+    if (cnt == 0) return;
+
+    // stage 2: exact score on the dense list
+    for (int i = lane; i < cnt; i += 64) {
+        const int e = list[i];
+        const int pos = pos0 + (e >> 8) * tsb + (e & 0xFF);
+        smap[pos] = (uint8_t)fast_S(tb + pos, off);
     }
     __syncthreads();
 
     // 3x3 non-max suppression on M_t = (S > t ? S-1 : 0), strict >, zero outside the
     // detection area; if nothing survives at iniThFAST, retry at minThFAST (:812-816)
-    int th = g->iniTh < 0 ? 0 : (g->iniTh > 255 ? 255 : g->iniTh);
-    const int th2 = g->minTh < 0 ? 0 : (g->minTh > 255 ? 255 : g->minTh);
+    auto nms_keep = [&](int e, int& sc) {
+        const uint8_t* sp = smap + pos0 + (e >> 8) * tsb + (e & 0xFF);
+        sc = sp[0];
+        if (!(sc > th && sc >= 2)) return false;
+        int m = 0;
+#define NB(o) { const int sn = sp[o]; if (sn > th) m = max(m, sn); }
+        NB(-1) NB(1) NB(-tsb - 1) NB(-tsb) NB(-tsb + 1) NB(tsb - 1) NB(tsb) NB(tsb + 1)
+#undef NB
+        return sc > m;
+    };
+    const int cntUp = (cnt + 63) & ~63;
     int total = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         total = 0;
-        for (int xb = 0; xb < dw; xb += 32) {
-            const int x = xb + (lane & 31);
-            for (int y0 = 0; y0 < dh; y0 += 2) {
-                const int y = y0 + (lane >> 5);
-                bool keep = false;
-                if (x < dw && y < dh) {
-                    const uint8_t* s = smap + (y + 3) * tsb + shift + x + 3;
-                    const int sc = s[0];
-                    if (sc > th && sc >= 2) {
-                        int m = 0;
-#define NB(o) { const int sn = s[o]; if (sn > th) m = max(m, sn); }
-                        NB(-1) NB(1) NB(-tsb - 1) NB(-tsb) NB(-tsb + 1) NB(tsb - 1) NB(tsb) NB(tsb + 1)
-#undef NB
-                        keep = sc > m;
-                    }
-                }
-                total += __popcll(__ballot(keep));
-            }
+        for (int i = lane; i < cntUp; i += 64) {
+            int sc;
+            const bool keep = i < cnt && nms_keep(list[i], sc);
+            total += __popcll(__ballot(keep));
         }
         if (total > 0 || th == th2) break;
         th = th2;
@@ -209,38 +228,22 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     if (lane == 0) basePos = atomicAdd(&candCount[f * g->nlevels + level], total);
     basePos = __shfl(basePos, 0);
     uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff;
-    const uint64_t lt = lanemask_lt();
     int run = 0;
-    for (int xb = 0; xb < dw; xb += 32) {
-        const int x = xb + (lane & 31);
-        for (int y0 = 0; y0 < dh; y0 += 2) {
-            const int y = y0 + (lane >> 5);
-            bool keep = false;
-            int sc = 0;
-            if (x < dw && y < dh) {
-                const uint8_t* s = smap + (y + 3) * tsb + shift + x + 3;
-                sc = s[0];
-                if (sc > th && sc >= 2) {
-                    int m = 0;
-#define NB(o) { const int sn = s[o]; if (sn > th) m = max(m, sn); }
-                    NB(-1) NB(1) NB(-tsb - 1) NB(-tsb) NB(-tsb + 1) NB(tsb - 1) NB(tsb) NB(tsb + 1)
-#undef NB
-                    keep = sc > m;
-                }
+    for (int i = lane; i < cntUp; i += 64) {
+        int sc = 0, e = 0;
+        bool keep = false;
+        if (i < cnt) { e = list[i]; keep = nms_keep(e, sc); }
+        const uint64_t bal = __ballot(keep);
+        if (keep) {
+            const int p = basePos + run + __popcll(bal & lt);
+            if (p < L.candCap) {
+                const uint32_t xr = (e & 0xFF) + 3, yr = (e >> 8) + 3;  // ROI coordinates
+                out[p] = pack_cand(c.x0 - kMinBorder + xr, c.y0 - kMinBorder + yr, sc - 1, cand_order(c.seq, yr, xr));
+            } else {
+                atomicOr(errFlag, 1);
             }
-            const uint64_t bal = __ballot(keep);
-            if (keep) {
-                const int p = basePos + run + __popcll(bal & lt);
-                if (p < L.candCap) {
-                    const uint32_t xr = x + 3, yr = y + 3;  // ROI coordinates
-                    out[p] = pack_cand(c.x0 - kMinBorder + xr, c.y0 - kMinBorder + yr, sc - 1,
-                                       cand_order(c.seq, yr, xr));
-                } else {
-                    atomicOr(errFlag, 1);
-                }
-            }
-            run += __popcll(bal);
         }
+        run += __popcll(bal);
     }
 }
 
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
 // (wave-per-node 4-way partition with ballots, block scans for the new list order).
 // Node keys are ranges [start, start+cnt) of a ping-pong record buffer; children
 // partition their parent's range in the other buffer, so ranges never overlap.
-constexpr int kDistThreads = 256;
+constexpr int kDistThreads = 512;
 
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t* a, int m, uint32_t* wtmp)
 {
@@ -282,39 +285,51 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t* a, int m, uint32_t
 }
 
 // 4-way partition of one node's keys by the wave; returns child counts (uniform)
+// 4 keys per lane per iteration so that four global loads are in flight per lane
+// (the partition is latency-bound: few waves, dependent round trips)
 __device__ __forceinline__ void wave_divide(const uint64_t* __restrict__ srcb, uint64_t* __restrict__ dstb,
                                             uint32_t start, uint32_t cnt, int xm, int ym, uint32_t c[4])
 {
+    constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     const uint64_t lt = lanemask_lt();
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
-        const uint32_t p = p0 + lane;
-        int q = 4;
-        if (p < cnt) {
-            const uint64_t key = srcb[start + p];
-            q = ((int)cand_x(key) >= xm ? 1 : 0) | ((int)cand_y(key) >= ym ? 2 : 0);
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 64 * U) {
+        uint64_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            key[u] = p < cnt ? srcb[start + p] : ~0ull;
         }
-        c0 += __popcll(__ballot(q == 0));
-        c1 += __popcll(__ballot(q == 1));
-        c2 += __popcll(__ballot(q == 2));
-        c3 += __popcll(__ballot(q == 3));
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            const int q = p < cnt ? (((int)cand_x(key[u]) >= xm ? 1 : 0) | ((int)cand_y(key[u]) >= ym ? 2 : 0)) : 4;
+            c0 += __popcll(__ballot(q == 0));
+            c1 += __popcll(__ballot(q == 1));
+            c2 += __popcll(__ballot(q == 2));
+            c3 += __popcll(__ballot(q == 3));
+        }
     }
     uint32_t r0 = start, r1 = start + c0, r2 = start + c0 + c1, r3 = start + c0 + c1 + c2;
-    for (uint32_t p0 = 0; p0 < cnt; p0 += 64) {
-        const uint32_t p = p0 + lane;
-        int q = 4;
-        uint64_t key = 0;
-        if (p < cnt) {
-            key = srcb[start + p];
-            q = ((int)cand_x(key) >= xm ? 1 : 0) | ((int)cand_y(key) >= ym ? 2 : 0);
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 64 * U) {
+        uint64_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            key[u] = p < cnt ? srcb[start + p] : ~0ull;
         }
-        const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
-        if (q == 0) dstb[r0 + __popcll(b0 & lt)] = key;
-        else if (q == 1) dstb[r1 + __popcll(b1 & lt)] = key;
-        else if (q == 2) dstb[r2 + __popcll(b2 & lt)] = key;
-        else if (q == 3) dstb[r3 + __popcll(b3 & lt)] = key;
-        r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            const int q = p < cnt ? (((int)cand_x(key[u]) >= xm ? 1 : 0) | ((int)cand_y(key[u]) >= ym ? 2 : 0)) : 4;
+            const uint64_t b0 = __ballot(q == 0), b1 = __ballot(q == 1), b2 = __ballot(q == 2), b3 = __ballot(q == 3);
+            if (q == 0) dstb[r0 + __popcll(b0 & lt)] = key[u];
+            else if (q == 1) dstb[r1 + __popcll(b1 & lt)] = key[u];
+            else if (q == 2) dstb[r2 + __popcll(b2 & lt)] = key[u];
+            else if (q == 3) dstb[r3 + __popcll(b3 & lt)] = key[u];
+            r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+        }
     }
     c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
 }
