@@ -35,7 +35,7 @@ def algorithmic_bytes(ex, w, h, nfeat):
     px = [a * b for a, b in (o.level_size(w, h, l) for l in range(8))]
     S = sum(px)
     per = {
-        "k_resize": (S - px[7]) + (S - px[0]),
+        "k_pyramid": (S - px[7]) + (S - px[0]),
         "k_fast": S,
         "k_blur": 2 * S,
         "k_orient_desc": 749 * nfeat + 512 * nfeat + (32 + 28) * nfeat,
@@ -142,7 +142,6 @@ def main():
             dom = max(kern, key=lambda k: kern[k][0])
             avg_ms = kern[dom][0] / kern[dom][1]
             launches_per_step = kern[dom][1] / args.steps
-            # k_resize is launched once per level (7 launches per step); its bytes are per step
             alg_launch = per[dom] * B / launches_per_step
             achieved = alg_launch / (avg_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

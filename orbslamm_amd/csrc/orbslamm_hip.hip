@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -58,7 +59,7 @@ static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------ profiling
 enum ProfId { P_H2D = 0, P_RESIZE, P_FAST, P_DISTRIBUTE, P_BLUR, P_ORIENT_DESC, P_MATCH_BEST2, P_MATCH_ACCEPT, P_MATCH_PRUNE, P_D2H, P_COUNT };
-static const char* kProfNames[P_COUNT] = {"h2d", "k_resize", "k_fast", "k_distribute", "k_blur",
+static const char* kProfNames[P_COUNT] = {"h2d", "k_pyramid", "k_fast", "k_distribute", "k_blur",
                                           "k_orient_desc", "k_match_best2", "k_match_accept", "k_match_prune", "d2h"};
 struct ProfSpan { int id; hipEvent_t a, b; };
 
@@ -127,12 +128,15 @@ struct orbx_handle {
     BlurTiles blurTiles;
     KpBlocks kpBlocks;
     int kpBlocksTotal = 0;
+    int pyrBlocks = 0, pyrBufA = 0, pyrBufB = 0, pyrTabCap = 0;
+    PyrRange* d_pyrRanges = nullptr; size_t pyrRangesCap = 0;
 
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // blur runs beside FAST + quadtree
     hipStream_t stream3 = nullptr;            // matching runs beside the next batch's pyramid/FAST
     hipEvent_t evPyr = nullptr, evBlur = nullptr, evDesc = nullptr, evMatch = nullptr;
     bool matchPending = false;
+    bool serial = false;                      // ORBX_SERIAL=1: everything on one stream (profiling aid)
     // device buffers (sized for maxW x maxH x maxB at create)
     Geom* d_geom = nullptr;
     Cell* d_cells = nullptr; size_t cellsCap = 0;
@@ -216,6 +220,8 @@ struct HostGeom {
     int blurTilesTotal;
     KpBlocks kb;
     int kbTotal;
+    std::vector<PyrRange> pyrRanges;   // [block][level]
+    int pyrBlocks, pyrBufA, pyrBufB, pyrTabCap;
 };
 
 static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
@@ -362,6 +368,62 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     for (int l = g.nlevels; l <= ORBX_MAXL; l++) { out.bt.base[l] = tb; out.kb.base[l] = kb; }
     out.blurTilesTotal = tb;
     out.kbTotal = kb;
+
+    // fused pyramid: every block owns the same fractional rectangle of each level;
+    // the computed range of level l = owned range + what level l+1's computed range reads
+    {
+        const int nl = g.nlevels;
+        const int top = nl - 1;
+        int BX = 8, BY = 4;
+        while (BX > 1 && g.lv[top].w / BX < 8) BX >>= 1;
+        while (BY > 1 && g.lv[top].h / BY < 8) BY >>= 1;
+        out.pyrBlocks = BX * BY;
+        out.pyrRanges.assign((size_t)out.pyrBlocks * nl, PyrRange{0, 0, 0, 0, 0, 0, 0, 0});
+        int maxA = 4, maxB = 4, tabCap = 4;
+        for (int bj = 0; bj < BY; bj++)
+            for (int bi = 0; bi < BX; bi++) {
+                PyrRange* R = &out.pyrRanges[(size_t)(bj * BX + bi) * nl];
+                int nx0 = 0, nx1 = 0, ny0 = 0, ny1 = 0;  // computed range of the level above (empty)
+                for (int l = top; l >= 0; l--) {
+                    const int w = g.lv[l].w, hh = g.lv[l].h;
+                    // x boundaries are multiples of 4 so that every output dword has one owner
+                    int ox0 = (int)((int64_t)bi * w / BX) & ~3, ox1 = bi + 1 == BX ? w : ((int)((int64_t)(bi + 1) * w / BX) & ~3);
+                    int oy0 = (int)((int64_t)bj * hh / BY), oy1 = (int)((int64_t)(bj + 1) * hh / BY);
+                    if (l == 0) ox0 = ox1 = oy0 = oy1 = 0;  // level 0 is the caller's frame: nothing to write
+                    int cx0 = ox0, cx1 = ox1, cy0 = oy0, cy1 = oy1;
+                    if (l < top && nx1 > nx0 && ny1 > ny0) {
+                        const short4* xt = &out.tabs[out.xoff[l + 1]];
+                        const short4* yt = &out.tabs[out.yoff[l + 1]];
+                        int sx0 = 1 << 30, sx1 = -1, sy0 = 1 << 30, sy1 = -1;
+                        // the kernel computes whole dword groups: cover the rounded-up range
+                        const int nx1g = std::min<int>(g.lv[l + 1].w, nx0 + ((nx1 - nx0 + 3) & ~3));
+                        for (int dx = nx0; dx < nx1g; dx++) {
+                            const int a = (uint16_t)xt[dx].x, b = a + (xt[dx].w ? 2 : 1);
+                            sx0 = std::min(sx0, a); sx1 = std::max(sx1, b);
+                        }
+                        for (int dy = ny0; dy < ny1; dy++) {
+                            sy0 = std::min<int>(sy0, yt[dy].x); sy1 = std::max<int>(sy1, yt[dy].y + 1);
+                        }
+                        sx1 = std::min(sx1, w); sy1 = std::min(sy1, hh);
+                        if (cx1 > cx0 && cy1 > cy0) {
+                            cx0 = std::min(cx0, sx0); cx1 = std::max(cx1, sx1);
+                            cy0 = std::min(cy0, sy0); cy1 = std::max(cy1, sy1);
+                        } else { cx0 = sx0; cx1 = sx1; cy0 = sy0; cy1 = sy1; }
+                    }
+                    cx0 &= ~3;  // dword-aligned tile origin
+                    R[l] = PyrRange{(int16_t)ox0, (int16_t)ox1, (int16_t)oy0, (int16_t)oy1,
+                                    (int16_t)cx0, (int16_t)cx1, (int16_t)cy0, (int16_t)cy1};
+                    nx0 = cx0; nx1 = cx1; ny0 = cy0; ny1 = cy1;
+                    if (cx1 > cx0 && cy1 > cy0) {
+                        const int rowBytes = (cx1 - cx0 + 3) & ~3;
+                        const int words = rowBytes / 4 * (cy1 - cy0) + 4;
+                        if (l & 1) maxB = std::max(maxB, words); else maxA = std::max(maxA, words);
+                        if (l > 0) tabCap = std::max(tabCap, std::max(rowBytes, cy1 - cy0));
+                    }
+                }
+            }
+        out.pyrBufA = maxA; out.pyrBufB = maxB; out.pyrTabCap = (tabCap + 3) & ~3;
+    }
     return ORBX_OK;
 }
 
@@ -378,7 +440,7 @@ static void free_device(orbx_handle* h)
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     h->prof.destroy();
-    void* ptrs[] = {h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
+    void* ptrs[] = {h->d_pyrRanges, h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
                     h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
                     h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -401,6 +463,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     int rc = init_tables(h);
     if (rc) { delete h; return rc; }
     h->device = device;
+    { const char* e = getenv("ORBX_SERIAL"); h->serial = e && e[0] == '1'; }
     h->maxW = max_w; h->maxH = max_h; h->maxB = max_batch;
     if (device < 0) { *out = h; return ORBX_OK; }  // host-only handle: tables and geometry queries
     if (max_w < 1 || max_h < 1 || max_batch < 1) { delete h; return fail(ORBX_E_INVALID, "bad maximum shape"); }
@@ -434,6 +497,8 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_geom, sizeof(Geom)));
     CRT(hipMalloc(&h->d_cells, h->cellsCap * sizeof(Cell)));
     CRT(hipMalloc(&h->d_tabs, h->tabsCap * sizeof(short4)));
+    h->pyrRangesCap = 64 * ORBX_MAXL;
+    CRT(hipMalloc(&h->d_pyrRanges, h->pyrRangesCap * sizeof(PyrRange)));
     CRT(hipMalloc(&h->d_img, h->imgFrameBytes * B));
     CRT(hipMalloc(&h->d_pyr, h->pyrCapFrame * B));
     CRT(hipMalloc(&h->d_blur, h->blurCapFrame * B));
@@ -534,6 +599,14 @@ static int configure_shape(orbx_handle* h, int w, int hh)
     HIPCHK(hipMemcpy(h->d_geom, &hg.g, sizeof(Geom), hipMemcpyHostToDevice));
     if (!hg.cells.empty()) HIPCHK(hipMemcpy(h->d_cells, hg.cells.data(), hg.cells.size() * sizeof(Cell), hipMemcpyHostToDevice));
     if (!hg.tabs.empty()) HIPCHK(hipMemcpy(h->d_tabs, hg.tabs.data(), hg.tabs.size() * sizeof(short4), hipMemcpyHostToDevice));
+    if (hg.pyrRanges.size() > h->pyrRangesCap) return fail(ORBX_E_INVALID, "pyramid range table overflow");
+    HIPCHK(hipMemcpy(h->d_pyrRanges, hg.pyrRanges.data(), hg.pyrRanges.size() * sizeof(PyrRange), hipMemcpyHostToDevice));
+    h->pyrBlocks = hg.pyrBlocks; h->pyrBufA = hg.pyrBufA; h->pyrBufB = hg.pyrBufB; h->pyrTabCap = hg.pyrTabCap;
+    {
+        const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
+        if (pl > 156 * 1024) return fail(ORBX_E_UNSUPPORTED, "frame too large for the LDS-tiled pyramid");
+        if (pl > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl));
+    }
     for (int l = 0; l < ORBX_MAXL; l++) {
         h->tabs.xtab[l] = h->d_tabs + (l < hg.g.nlevels ? hg.xoff[l] : 0);
         h->tabs.ytab[l] = h->d_tabs + (l < hg.g.nlevels ? hg.yoff[l] : 0);
@@ -574,14 +647,15 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     // the pyramid/blur buffers use the geometry's per-frame sizes as pitch
     HIPCHK(hipMemsetAsync(h->d_candCount, 0, (size_t)B * g.nlevels * sizeof(int32_t), s));
 
-    for (int l = 1; l < g.nlevels; l++) {
-        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, B), block(64, 4, 1);
+    if (g.nlevels > 1) {
+        const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
         h->prof.begin(P_RESIZE, s);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, s, h->d_geom, src, h->tabs, l);
+        hipLaunchKernelGGL(k_pyramid, dim3(h->pyrBlocks, B), dim3(256), pl, s, h->d_geom, src, h->tabs,
+                           (const PyrRange*)h->d_pyrRanges, h->pyrBufA, h->pyrBufB, h->pyrTabCap);
         h->prof.end(s);
     }
     // blur only needs the pyramid: run it on the second stream beside FAST + quadtree
-    hipStream_t s2 = h->stream2;
+    hipStream_t s2 = h->serial ? h->stream : h->stream2;
     HIPCHK(hipEventRecord(h->evPyr, s));
     HIPCHK(hipStreamWaitEvent(s2, h->evPyr, 0));
     h->prof.begin(P_BLUR, s2);
@@ -791,7 +865,7 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     const int B = h->lastB;
     if (B < 1) return fail(ORBX_E_INVALID, "no extracted batch to match");
     // matching runs on its own stream so that the next batch's pyramid/FAST can start beside it
-    hipStream_t s = h->stream3;
+    hipStream_t s = h->serial ? h->stream : h->stream3;
     HIPCHK(hipEventRecord(h->evDesc, h->stream));
     HIPCHK(hipStreamWaitEvent(s, h->evDesc, 0));
     orbm::MatchIO io = slots_io(h);

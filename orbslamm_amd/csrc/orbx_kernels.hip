@@ -82,6 +82,105 @@ __global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, Fram
     *(uint32_t*)(D + x4) = packed;  // rows are 64-byte aligned and padded
 }
 
+// ------------------------------------------------------------------ fused pyramid
+// All 7 resizes in ONE launch.  A block owns the same fractional rectangle of every
+// level; per level it computes the pixels it owns plus the small halo the next level
+// will read (ranges are chained top-down on the host, PyrRange), keeps the tile in LDS
+// (ping-pong) and writes only the owned pixels to HBM.  The level-0 source tile is
+// staged with aligned dword loads.  Same fixed-point arithmetic as k_resize.
+struct PyrRange {
+    int16_t ox0, ox1, oy0, oy1;   // owned output range at this level (exclusive ends)
+    int16_t nx0, nx1, ny0, ny1;   // computed range (owned + halo needed by the next level)
+};
+
+__global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, FrameSrc src, ResizeTabs tabs,
+                                                const PyrRange* __restrict__ ranges, int bufAWords, int bufBWords,
+                                                int tabCap)
+{
+    // one LDS array addressed with integer offsets (keeps every access in the LDS address space)
+    extern __shared__ uint32_t plds[];
+    uint8_t* const ldsb = (uint8_t*)plds;
+    const int offBuf[2] = {0, bufAWords * 4};            // even / odd levels (bytes)
+    uint2* const sxt = (uint2*)(plds + bufAWords + bufBWords);  // staged {sx,a0 | a1,interp}
+    uint2* const syt = sxt + tabCap;                              // staged {sy0,sy1 | b0,b1}
+    const int f = blockIdx.y;
+    const int nl = g->nlevels;
+    const PyrRange* R = ranges + (int64_t)blockIdx.x * nl;
+    const int tid = threadIdx.x;
+
+    // level-0 tile: aligned dword loads (ranges have 4-aligned x origins)
+    PyrRange p = R[0];
+    int pstride = 0;
+    if (p.nx1 > p.nx0 && p.ny1 > p.ny0) {
+        int stride0;
+        const uint8_t* S = level_ptr(g, src, f, 0, stride0);
+        const int ndw = (p.nx1 - p.nx0 + 3) >> 2, rows = p.ny1 - p.ny0;
+        pstride = ndw * 4;
+        const uint8_t* S0 = S + (int64_t)p.ny0 * stride0 + p.nx0;
+        int r = tid / ndw, c = tid - r * ndw;
+        const int dr = 256 / ndw, dc = 256 - dr * ndw;
+        while (r < rows) {
+            plds[r * ndw + c] = *(const uint32_t*)(S0 + (int64_t)r * stride0 + 4 * c);
+            r += dr; c += dc;
+            if (c >= ndw) { c -= ndw; r++; }
+        }
+    }
+    for (int l = 1; l < nl; l++) {
+        const PyrRange c = R[l];
+        const int cw = c.nx1 - c.nx0, chh = c.ny1 - c.ny0;
+        const int gpr = (cw + 3) >> 2;           // dword groups per row
+        const int cstride = gpr * 4;
+        const int lw = g->lv[l].w, dstStride = g->lv[l].stride;
+        uint8_t* const D = src.pyr + (int64_t)f * g->pyrFrameBytes + g->lv[l].pyrOff;
+        const int pnx0 = p.nx0, pny0 = p.ny0;
+        const uint2* __restrict__ gx_tab = (const uint2*)tabs.xtab[l];
+        const uint2* __restrict__ gy_tab = (const uint2*)tabs.ytab[l];
+        // stage this level's coefficient rows (entries past the level width are never used)
+        for (int i = tid; i < cstride; i += 256) sxt[i] = gx_tab[min(c.nx0 + i, lw - 1)];
+        for (int i = tid; i < chh; i += 256) syt[i] = gy_tab[c.ny0 + i];
+        __syncthreads();  // also orders the previous level's tile writes before the reads below
+        const int offP = offBuf[(l - 1) & 1], offC = offBuf[l & 1];
+        if (gpr > 0) {
+            int yy = tid / gpr, gx = tid - yy * gpr;
+            const int dr = 256 / gpr, dc = 256 - dr * gpr;
+            while (yy < chh) {
+                const uint2 yt = syt[yy];
+                const int sy0 = (int16_t)(yt.x & 0xFFFF), sy1 = (int16_t)(yt.x >> 16);
+                const int b0 = (int16_t)(yt.y & 0xFFFF), b1 = (int16_t)(yt.y >> 16);
+                const int o0 = offP + (sy0 - pny0) * pstride - pnx0;
+                const int o1 = offP + (sy1 - pny0) * pstride - pnx0;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint2 xt = sxt[4 * gx + i];
+                    const int sx = (int)(xt.x & 0xFFFF);
+                    const int a0 = (int16_t)(xt.x >> 16), a1 = (int16_t)(xt.y & 0xFFFF);
+                    const int s00 = ldsb[o0 + sx], s10 = ldsb[o1 + sx];
+                    int r0, r1;
+                    if (xt.y >> 16) {
+                        r0 = s00 * a0 + ldsb[o0 + sx + 1] * a1;
+                        r1 = s10 * a0 + ldsb[o1 + sx + 1] * a1;
+                    } else {
+                        r0 = s00 * 2048;
+                        r1 = s10 * 2048;
+                    }
+                    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                    packed |= (uint32_t)(v & 0xFF) << (8 * i);
+                }
+                plds[(offC >> 2) + yy * gpr + gx] = packed;
+                const int dx = c.nx0 + 4 * gx, dy = c.ny0 + yy;
+                if (dy >= c.oy0 && dy < c.oy1 && dx >= c.ox0 && dx < c.ox1)
+                    *(uint32_t*)(D + (int64_t)dy * dstStride + dx) = packed;  // own ranges are 4-aligned in x
+                yy += dr; gx += dc;
+                if (gx >= gpr) { gx -= gpr; yy++; }
+            }
+        }
+        p = c;
+        pstride = cstride;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ FAST
 // One wave per reference cell.  S(p) = max over the 16 arcs of 9 contiguous ring
 // pixels of min(v - p_k) resp. min(p_k - v): the pixel is a FAST-9 corner at
