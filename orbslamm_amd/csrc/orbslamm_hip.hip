@@ -132,9 +132,13 @@ struct orbx_handle {
     PyrRange* d_pyrRanges = nullptr; size_t pyrRangesCap = 0;
 
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // blur runs beside FAST + quadtree
+    static constexpr int kMaxSplit = 4;
+    int nsplit = 2;                           // sub-batches per call (ORBX_SPLIT)
+    hipStream_t streamP[kMaxSplit] = {nullptr};  // pipeline stream of sub-batch p (p = 0 uses `stream`)
+    hipStream_t streamB[kMaxSplit] = {nullptr};  // blur runs beside FAST + quadtree
+    hipEvent_t evStart = nullptr, evPart[kMaxSplit] = {nullptr};
     hipStream_t stream3 = nullptr;            // matching runs beside the next batch's pyramid/FAST
-    hipEvent_t evPyr = nullptr, evBlur = nullptr, evDesc = nullptr, evMatch = nullptr;
+    hipEvent_t evPyr[kMaxSplit] = {nullptr}, evBlur[kMaxSplit] = {nullptr}, evDesc = nullptr, evMatch = nullptr;
     bool matchPending = false;
     bool serial = false;                      // ORBX_SERIAL=1: everything on one stream (profiling aid)
     // device buffers (sized for maxW x maxH x maxB at create)
@@ -437,7 +441,10 @@ static void free_device(orbx_handle* h)
     if (h->device < 0) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
+        if (h->streamP[i]) (void)hipStreamSynchronize(h->streamP[i]);
+        if (h->streamB[i]) (void)hipStreamSynchronize(h->streamB[i]);
+    }
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     h->prof.destroy();
     void* ptrs[] = {h->d_pyrRanges, h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
@@ -445,12 +452,17 @@ static void free_device(orbx_handle* h)
                     h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-    if (h->evPyr) (void)hipEventDestroy(h->evPyr);
-    if (h->evBlur) (void)hipEventDestroy(h->evBlur);
+    for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
+        if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]);
+        if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]);
+        if (h->evPart[i]) (void)hipEventDestroy(h->evPart[i]);
+        if (h->streamP[i]) (void)hipStreamDestroy(h->streamP[i]);
+        if (h->streamB[i]) (void)hipStreamDestroy(h->streamB[i]);
+    }
+    if (h->evStart) (void)hipEventDestroy(h->evStart);
     if (h->evDesc) (void)hipEventDestroy(h->evDesc);
     if (h->evMatch) (void)hipEventDestroy(h->evMatch);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -464,6 +476,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     if (rc) { delete h; return rc; }
     h->device = device;
     { const char* e = getenv("ORBX_SERIAL"); h->serial = e && e[0] == '1'; }
+    { const char* e = getenv("ORBX_SPLIT"); if (e && e[0] >= '1' && e[0] <= '4') h->nsplit = e[0] - '0'; }
     h->maxW = max_w; h->maxH = max_h; h->maxB = max_batch;
     if (device < 0) { *out = h; return ORBX_OK; }  // host-only handle: tables and geometry queries
     if (max_w < 1 || max_h < 1 || max_batch < 1) { delete h; return fail(ORBX_E_INVALID, "bad maximum shape"); }
@@ -477,9 +490,14 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
 #define CRT(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int r_ = fail(ORBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); free_device(h); delete h; return r_; } } while (0)
     CRT(hipSetDevice(device));
     CRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    CRT(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    CRT(hipEventCreateWithFlags(&h->evPyr, hipEventDisableTiming));
-    CRT(hipEventCreateWithFlags(&h->evBlur, hipEventDisableTiming));
+    for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
+        if (i > 0) CRT(hipStreamCreateWithFlags(&h->streamP[i], hipStreamNonBlocking));
+        CRT(hipStreamCreateWithFlags(&h->streamB[i], hipStreamNonBlocking));
+        CRT(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
+        CRT(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming));
+        CRT(hipEventCreateWithFlags(&h->evPart[i], hipEventDisableTiming));
+    }
+    CRT(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
     CRT(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
     CRT(hipEventCreateWithFlags(&h->evDesc, hipEventDisableTiming));
     CRT(hipEventCreateWithFlags(&h->evMatch, hipEventDisableTiming));
@@ -573,7 +591,10 @@ extern "C" int orbx_max_keypoints(const orbx_t* h)
 static int sync_all(orbx_handle* h)
 {
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream2));
+    for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
+        if (h->streamP[i]) HIPCHK(hipStreamSynchronize(h->streamP[i]));
+        if (h->streamB[i]) HIPCHK(hipStreamSynchronize(h->streamB[i]));
+    }
     HIPCHK(hipStreamSynchronize(h->stream3));
     h->matchPending = false;
     return ORBX_OK;
@@ -632,6 +653,9 @@ static int check_device(orbx_handle* h)
 }
 
 // ------------------------------------------------------------------ the pipeline
+// The batch is cut into kSplit sub-batches that run on separate stream groups: the
+// latency-bound kernels of one sub-batch (quadtree, descriptors) overlap the
+// throughput-bound ones (FAST, matching) of the other.
 static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int hh, int stride, size_t pitch)
 {
     int rc = configure_shape(h, w, hh);
@@ -640,48 +664,63 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     if (((uintptr_t)d_imgs & 3) || (stride & 3) || (pitch & 3) || stride < w)
         return fail(ORBX_E_INVALID, "device frames need 4-byte aligned base/stride/pitch and stride >= width");
     const Geom& g = h->geom;
-    hipStream_t s = h->stream;
     FrameSrc src;
     src.img0 = d_imgs; src.stride0 = stride; src.pitch0 = (int64_t)pitch;
-    src.pyr = h->d_pyr; src.blur = h->d_blur;
+    src.pyr = h->d_pyr; src.blur = h->d_blur; src.f0 = 0;
     // the pyramid/blur buffers use the geometry's per-frame sizes as pitch
-    HIPCHK(hipMemsetAsync(h->d_candCount, 0, (size_t)B * g.nlevels * sizeof(int32_t), s));
-
-    if (g.nlevels > 1) {
-        const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
-        h->prof.begin(P_RESIZE, s);
-        hipLaunchKernelGGL(k_pyramid, dim3(h->pyrBlocks, B), dim3(256), pl, s, h->d_geom, src, h->tabs,
-                           (const PyrRange*)h->d_pyrRanges, h->pyrBufA, h->pyrBufB, h->pyrTabCap);
+    hipStream_t s0 = h->stream;
+    HIPCHK(hipMemsetAsync(h->d_candCount, 0, (size_t)B * g.nlevels * sizeof(int32_t), s0));
+    const int nsplit = h->serial ? 1 : std::min(h->nsplit, B);
+    if (nsplit > 1) HIPCHK(hipEventRecord(h->evStart, s0));
+    for (int part = 0; part < nsplit; part++) {
+        const int f0 = (int)((int64_t)B * part / nsplit), f1 = (int)((int64_t)B * (part + 1) / nsplit);
+        const int nb = f1 - f0;
+        if (nb <= 0) continue;
+        hipStream_t s = part == 0 ? s0 : h->streamP[part];
+        hipStream_t s2 = h->serial ? s : h->streamB[part];
+        if (part > 0) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
+        src.f0 = f0;
+        if (g.nlevels > 1) {
+            const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
+            h->prof.begin(P_RESIZE, s);
+            hipLaunchKernelGGL(k_pyramid, dim3(h->pyrBlocks, nb), dim3(256), pl, s, h->d_geom, src, h->tabs,
+                               (const PyrRange*)h->d_pyrRanges, h->pyrBufA, h->pyrBufB, h->pyrTabCap);
+            h->prof.end(s);
+        }
+        // blur only needs the pyramid: run it on a second stream beside FAST + quadtree
+        HIPCHK(hipEventRecord(h->evPyr[part], s));
+        HIPCHK(hipStreamWaitEvent(s2, h->evPyr[part], 0));
+        h->prof.begin(P_BLUR, s2);
+        hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], nb), dim3(256), 0, s2, h->d_geom, src, h->blurTiles);
+        h->prof.end(s2);
+        HIPCHK(hipEventRecord(h->evBlur[part], s2));
+        if (g.totalCells > 0) {
+            const size_t lds = (size_t)2 * h->tileRows * h->tileStrideDw * 4 + (size_t)h->fastListCap * 2;
+            h->prof.begin(P_FAST, s);
+            hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nb), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
+                               h->d_candCount, h->d_err, h->tileStrideDw, h->tileRows, h->fastListCap);
+            h->prof.end(s);
+        }
+        h->prof.begin(P_DISTRIBUTE, s);
+        hipLaunchKernelGGL(k_distribute, dim3(g.nlevels, nb), dim3(kDistThreads), dist_lds_bytes(h->nodeCap), s, h->d_geom,
+                           h->d_candRaw, h->d_candA, h->d_candB, h->d_candCount, h->d_kept, h->d_keptCount, h->d_err,
+                           h->nodeCap, f0);
         h->prof.end(s);
-    }
-    // blur only needs the pyramid: run it on the second stream beside FAST + quadtree
-    hipStream_t s2 = h->serial ? h->stream : h->stream2;
-    HIPCHK(hipEventRecord(h->evPyr, s));
-    HIPCHK(hipStreamWaitEvent(s2, h->evPyr, 0));
-    h->prof.begin(P_BLUR, s2);
-    hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], B), dim3(256), 0, s2, h->d_geom, src, h->blurTiles);
-    h->prof.end(s2);
-    HIPCHK(hipEventRecord(h->evBlur, s2));
-    if (g.totalCells > 0) {
-        const size_t lds = (size_t)2 * h->tileRows * h->tileStrideDw * 4 + (size_t)h->fastListCap * 2;
-        h->prof.begin(P_FAST, s);
-        hipLaunchKernelGGL(k_fast, dim3(g.totalCells, B), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
-                           h->d_candCount, h->d_err, h->tileStrideDw, h->tileRows, h->fastListCap);
+        HIPCHK(hipStreamWaitEvent(s, h->evBlur[part], 0));
+        // the output slots are still being read by the previous batch's matching on stream3
+        if (h->matchPending) HIPCHK(hipStreamWaitEvent(s, h->evMatch, 0));
+        h->prof.begin(P_ORIENT_DESC, s);
+        hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, nb), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
+                           h->d_keptCount, h->d_kps + h->maxKp, h->d_desc + (size_t)h->maxKp * 32, h->d_count + 1);
         h->prof.end(s);
+        if (part > 0) {  // join back into the main stream
+            HIPCHK(hipEventRecord(h->evPart[part], s));
+            HIPCHK(hipStreamWaitEvent(s0, h->evPart[part], 0));
+        }
     }
-    h->prof.begin(P_DISTRIBUTE, s);
-    hipLaunchKernelGGL(k_distribute, dim3(g.nlevels, B), dim3(kDistThreads), dist_lds_bytes(h->nodeCap), s, h->d_geom,
-                       h->d_candRaw, h->d_candA, h->d_candB, h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->nodeCap);
-    h->prof.end(s);
-    HIPCHK(hipStreamWaitEvent(s, h->evBlur, 0));
-    // the output slots are still being read by the previous batch's matching on stream3
-    if (h->matchPending) HIPCHK(hipStreamWaitEvent(s, h->evMatch, 0));
-    h->prof.begin(P_ORIENT_DESC, s);
-    hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, B), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
-                       h->d_keptCount, h->d_kps + h->maxKp, h->d_desc + (size_t)h->maxKp * 32, h->d_count + 1);
-    h->prof.end(s);
     HIPCHK(hipGetLastError());
     h->lastB = B;
+    src.f0 = 0;
     h->lastSrc = src;
     return ORBX_OK;
 }

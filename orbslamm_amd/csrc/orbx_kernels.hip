@@ -22,6 +22,7 @@ struct FrameSrc {
     int64_t pitch0;        // bytes between frames
     uint8_t* pyr;          // levels >= 1
     uint8_t* blur;         // all levels
+    int32_t f0;            // first frame of this launch (sub-batches run on separate streams)
 };
 
 __device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const FrameSrc& s, int f, int l, int& stride)
@@ -45,43 +46,6 @@ struct ResizeTabs {
     const short4* ytab[ORBX_MAXL];
 };
 
-__global__ __launch_bounds__(256) void k_resize(const Geom* __restrict__ g, FrameSrc src, ResizeTabs tabs, int level)
-{
-    const LevelGeom& L = g->lv[level];
-    const int f = blockIdx.z;
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    if (x4 >= L.w || dy >= L.h) return;
-    int sstride;
-    const uint8_t* S = level_ptr(g, src, f, level - 1, sstride);
-    uint8_t* D = src.pyr + (int64_t)f * g->pyrFrameBytes + L.pyrOff + (int64_t)dy * L.stride;
-    const short4 yt = tabs.ytab[level][dy];
-    const uint8_t* S0 = S + (int64_t)yt.x * sstride;
-    const uint8_t* S1 = S + (int64_t)yt.y * sstride;
-    const int b0 = yt.z, b1 = yt.w;
-    uint32_t packed = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int dx = x4 + i;
-        int v = 0;
-        if (dx < L.w) {
-            const short4 xt = tabs.xtab[level][dx];
-            const int sx = (uint16_t)xt.x;
-            int r0, r1;
-            if (xt.w) {
-                r0 = S0[sx] * xt.y + S0[sx + 1] * xt.z;
-                r1 = S1[sx] * xt.y + S1[sx + 1] * xt.z;
-            } else {
-                r0 = S0[sx] * 2048;
-                r1 = S1[sx] * 2048;
-            }
-            v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        }
-        packed |= (uint32_t)(v & 0xFF) << (8 * i);
-    }
-    *(uint32_t*)(D + x4) = packed;  // rows are 64-byte aligned and padded
-}
-
 // ------------------------------------------------------------------ fused pyramid
 // All 7 resizes in ONE launch.  A block owns the same fractional rectangle of every
 // level; per level it computes the pixels it owns plus the small halo the next level
@@ -103,7 +67,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     const int offBuf[2] = {0, bufAWords * 4};            // even / odd levels (bytes)
     uint2* const sxt = (uint2*)(plds + bufAWords + bufBWords);  // staged {sx,a0 | a1,interp}
     uint2* const syt = sxt + tabCap;                              // staged {sy0,sy1 | b0,b1}
-    const int f = blockIdx.y;
+    const int f = blockIdx.y + src.f0;
     const int nl = g->nlevels;
     const PyrRange* R = ranges + (int64_t)blockIdx.x * nl;
     const int tid = threadIdx.x;
@@ -191,27 +155,45 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
 // runs on all pixels and COMPACTS the survivors (about a quarter of a busy image) into
 // an LDS list; the exact 16-arc score, the 3x3 non-max suppression and the emission
 // then run on the dense list, so no lane idles through the heavy part.
+// Packed 16-bit formulation: lane register j holds (d[j], d[j+8]); the windowed minima
+// and maxima of the 16-ring are built with v_pk_min/max_i16 on 8 registers instead of 16
+// (half swaps fold into op_sel).
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk_swap(pk16 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+
 __device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p, const int* off)
 {
-    const int v = p[0];
-    int d[16];
+    const short v = (short)p[0];
+    const pk16 vv = {v, v};
+    pk16 X[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - p[off[k]];
-    int mn2[16], mx2[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-    int mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-    int A = -256, Bn = 256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        A = max(A, mn9);
-        Bn = min(Bn, mx9);
+    for (int k = 0; k < 8; k++) {
+        const pk16 pr = {(short)p[off[k]], (short)p[off[k + 8]]};
+        X[k] = vv - pr;            // (d[k], d[k+8])
+        X[k + 8] = pk_swap(X[k]);  // (d[k+8], d[k])
     }
-    const int S = max(A, -Bn);
+    pk16 mn2[10], mx2[10];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { mn2[k] = pk_min(X[k], X[k + 1]); mx2[k] = pk_max(X[k], X[k + 1]); }
+    mn2[8] = pk_swap(mn2[0]); mn2[9] = pk_swap(mn2[1]);
+    mx2[8] = pk_swap(mx2[0]); mx2[9] = pk_swap(mx2[1]);
+    pk16 mn4[12], mx4[12];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { mn4[k] = pk_min(mn2[k], mn2[k + 2]); mx4[k] = pk_max(mx2[k], mx2[k + 2]); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { mn4[8 + k] = pk_swap(mn4[k]); mx4[8 + k] = pk_swap(mx4[k]); }
+    pk16 A = {-256, -256}, Bn = {256, 256};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const pk16 mn9 = pk_min(pk_min(mn4[k], mn4[k + 4]), X[k + 8]);
+        const pk16 mx9 = pk_max(pk_max(mx4[k], mx4[k + 4]), X[k + 8]);
+        A = pk_max(A, mn9);
+        Bn = pk_min(Bn, mx9);
+    }
+    const int a = max((int)A.x, (int)A.y), bn = min((int)Bn.x, (int)Bn.y);
+    const int S = max(a, -bn);
     return S < 0 ? 0 : S;
 }
 
@@ -222,7 +204,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
 {
     extern __shared__ uint32_t lds[];
     const Cell c = cells[blockIdx.x];
-    const int f = blockIdx.y;
+    const int f = blockIdx.y + src.f0;
     const int lane = threadIdx.x;
     const int level = c.level;
     const LevelGeom& L = g->lv[level];
@@ -309,34 +291,44 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
 #undef NB
         return sc > m;
     };
+    // first pass at iniThFAST (retry at minThFAST only when the cell stays empty); the
+    // keep decision is remembered in bit 15 of the list entry, so emission needs no recompute
     const int cntUp = (cnt + 63) & ~63;
     int total = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         total = 0;
         for (int i = lane; i < cntUp; i += 64) {
             int sc;
-            const bool keep = i < cnt && nms_keep(list[i], sc);
+            bool keep = false;
+            if (i < cnt) {
+                const int e = list[i] & 0x7FFF;
+                keep = nms_keep(e, sc);
+                if (keep) list[i] = (uint16_t)(e | 0x8000);
+            }
             total += __popcll(__ballot(keep));
         }
         if (total > 0 || th == th2) break;
         th = th2;
     }
     if (total == 0) return;
+    __syncthreads();
 
     int basePos = 0;
     if (lane == 0) basePos = atomicAdd(&candCount[f * g->nlevels + level], total);
     basePos = __shfl(basePos, 0);
     uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff;
+    const int candCap = L.candCap;
     int run = 0;
     for (int i = lane; i < cntUp; i += 64) {
-        int sc = 0, e = 0;
+        int e = 0;
         bool keep = false;
-        if (i < cnt) { e = list[i]; keep = nms_keep(e, sc); }
+        if (i < cnt) { e = list[i]; keep = (e & 0x8000) != 0; e &= 0x7FFF; }
         const uint64_t bal = __ballot(keep);
         if (keep) {
             const int p = basePos + run + __popcll(bal & lt);
-            if (p < L.candCap) {
+            if (p < candCap) {
                 const uint32_t xr = (e & 0xFF) + 3, yr = (e >> 8) + 3;  // ROI coordinates
+                const int sc = smap[pos0 + (e >> 8) * tsb + (e & 0xFF)];
                 out[p] = pack_cand(c.x0 - kMinBorder + xr, c.y0 - kMinBorder + yr, sc - 1, cand_order(c.seq, yr, xr));
             } else {
                 atomicOr(errFlag, 1);
@@ -438,10 +430,10 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                                                             uint64_t* __restrict__ candA, uint64_t* __restrict__ candB,
                                                             const int32_t* __restrict__ candCount,
                                                             uint64_t* __restrict__ kept, int32_t* __restrict__ keptCount,
-                                                            int32_t* __restrict__ errFlag, int cap)
+                                                            int32_t* __restrict__ errFlag, int cap, int f0)
 {
     extern __shared__ uint32_t smem[];
-    const int l = blockIdx.x, f = blockIdx.y;
+    const int l = blockIdx.x, f = blockIdx.y + f0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kDistThreads / 64;
     const LevelGeom& L = g->lv[l];
@@ -701,7 +693,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     constexpr int RP_STRIDE = TW / 2 + 2;     // 66 dwords (u16 pairs), even for b64 reads
     __shared__ uint32_t in[(TH + 6) * IN_STRIDE];
     __shared__ uint32_t rp[(TH + 6) * RP_STRIDE];
-    const int f = blockIdx.y;
+    const int f = blockIdx.y + src.f0;
     int l = 0;
     while (l + 1 < g->nlevels && (int)blockIdx.x >= bt.base[l + 1]) l++;
     const int tIdx = blockIdx.x - bt.base[l];
@@ -825,9 +817,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
                                                     uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount)
 {
     __shared__ int32_t spat[256];  // 256 tests x (x0,y0,x1,y1) int8
+    __shared__ int32_t sumax[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f = blockIdx.y;
+    const int f = blockIdx.y + src.f0;
     spat[tid] = ((const int32_t*)d_pattern)[tid];
+    if (tid < 16) sumax[tid] = g->umax[tid];
     __syncthreads();
     int l = 0;
     while (l + 1 < g->nlevels && (int)blockIdx.x >= kb.base[l + 1]) l++;
@@ -850,21 +844,27 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     const uint8_t* img = level_ptr(g, src, f, l, stride);
     const uint8_t* center = img + (int64_t)cy * stride + cx;
 
-    // IC_Angle: integer moments over the radius-15 disc of the raw level
+    // IC_Angle: integer moments over the radius-15 disc of the raw level.  Two patch rows per
+    // step over the 64 lanes; all 16 loads are issued before the first use (clamped address
+    // for masked lanes) so the wave pays one memory round trip, not sixteen.
     int m10 = 0, m01 = 0;
     {
         const int half = lane >> 5, u = (lane & 31) - kHalfPatch;
+        int val[16];
+#pragma unroll
         for (int it = 0; it < 16; it++) {
             const int v = -kHalfPatch + 2 * it + half;
-            if (v <= kHalfPatch && (lane & 31) <= 30) {
-                const int av = v < 0 ? -v : v;
-                const int d = g->umax[av];
-                if (u >= -d && u <= d) {
-                    const int val = center[v * stride + u];
-                    m10 += u * val;
-                    m01 += v * val;
-                }
-            }
+            const int av = v < 0 ? -v : v;
+            const bool ok = av <= kHalfPatch && (lane & 31) <= 30 && abs(u) <= sumax[av & 15];
+            const uint8_t* ptr = ok ? center + v * stride + u : center;  // unconditional load, safe address
+            const int x = *ptr;
+            val[it] = ok ? x : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int v = -kHalfPatch + 2 * it + half;
+            m10 += u * val[it];
+            m01 += v * val[it];
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
@@ -875,9 +875,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
     const float a = (float)cos((double)ang), b = (float)sin((double)ang);
-    const uint8_t* bc = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)cy * L.blurStride + cx;
     const int bs = L.blurStride;
-    uint64_t bits[4];
+    const uint8_t* bc = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)cy * bs + cx;
+    int t0[4], t1[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int32_t pk = spat[lane + 64 * r];
@@ -887,9 +887,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
         const int rx0 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int ry1 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int rx1 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[ry0 * bs + rx0], t1 = bc[ry1 * bs + rx1];
-        bits[r] = __ballot(t0 < t1);
+        t0[r] = bc[ry0 * bs + rx0];
+        t1[r] = bc[ry1 * bs + rx1];
     }
+    uint64_t bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bits[r] = __ballot(t0[r] < t1[r]);
     if (lane < 4) ((uint64_t*)(outDesc + ((int64_t)f * g->maxKp + o) * 32))[lane] =
         lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
     if (lane == 0) {
