@@ -652,18 +652,28 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // ---- best response per node, first pushed wins ties (:742-760) == max record
     uint64_t* outk = kept + (int64_t)f * g->keptFrameRecs + L.keptOff;
     if (m > L.keptCap) { if (tid == 0) atomicOr(errFlag, 4); m = L.keptCap; }
-    for (int i = wave; i < m; i += NW) {
-        const uint32_t cb = nc[cur][i];
-        const uint32_t cnt = cb & 0x7FFFFFFFu;
-        const uint64_t* srcb = bufs[cb >> 31] + ns[cur][i];
+    // 8 lanes per node (final nodes hold ~15 keys): 8 nodes per wave step, loads batched
+    for (int i0 = wave * 8; i0 < m; i0 += NW * 8) {
+        const int i = i0 + (lane >> 3), sub = lane & 7;
         uint64_t best = 0;
-        for (uint32_t p = lane; p < cnt; p += 64) { const uint64_t k = srcb[p]; best = k > best ? k : best; }
+        if (i < m) {
+            const uint32_t cb = nc[cur][i];
+            const uint32_t cnt = cb & 0x7FFFFFFFu;
+            const uint64_t* srcb = ((cb >> 31) ? bufs[1] : bufs[0]) + ns[cur][i];
+            for (uint32_t p = sub; p < cnt; p += 32) {
+                uint64_t k[4];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
+                for (int u = 0; u < 4; u++) k[u] = p + 8 * u < cnt ? srcb[p + 8 * u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++) best = k[u] > best ? k[u] : best;
+            }
+        }
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) {
             const uint64_t o = __shfl_xor((unsigned long long)best, d);
             best = o > best ? o : best;
         }
-        if (lane == 0) outk[i] = best;
+        if (i < m && sub == 0) outk[i] = best;
     }
     if (tid == 0) keptCount[f * g->nlevels + l] = m;
 }
