@@ -81,12 +81,21 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
         const int ndw = (p.nx1 - p.nx0 + 3) >> 2, rows = p.ny1 - p.ny0;
         pstride = ndw * 4;
         const uint8_t* S0 = S + (int64_t)p.ny0 * stride0 + p.nx0;
-        int r = tid / ndw, c = tid - r * ndw;
-        const int dr = 256 / ndw, dc = 256 - dr * ndw;
-        while (r < rows) {
-            plds[r * ndw + c] = *(const uint32_t*)(S0 + (int64_t)r * stride0 + 4 * c);
-            r += dr; c += dc;
-            if (c >= ndw) { c -= ndw; r++; }
+        // 8 loads per thread in flight
+        const int total = rows * ndw;
+        for (int i0 = 0; i0 < total; i0 += 256 * 8) {
+            uint32_t regs[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = min(i0 + k * 256 + tid, total - 1);
+                const int r = i / ndw, c = i - r * ndw;
+                regs[k] = *(const uint32_t*)(S0 + (int64_t)r * stride0 + 4 * c);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + k * 256 + tid;
+                if (i < total) plds[i] = regs[k];
+            }
         }
     }
     for (int l = 1; l < nl; l++) {
@@ -220,12 +229,27 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     const int cw = c.w, ch = c.h;
     const int shift = c.x0 & 3;
     const int ndw = (shift + cw + 3) >> 2;
-    // coalesced aligned dword loads of the ROI rows; zero the S map
+    // coalesced aligned dword loads of the ROI rows, 12 per lane in flight (clamped addresses,
+    // predicated LDS stores) so the wave pays one memory round trip; zero the S map
     {
         const uint8_t* rowbase = base + (int64_t)c.y0 * stride + (c.x0 & ~3);
-        for (int r = lane >> 4; r < ch; r += 4)
-            for (int dd = lane & 15; dd < ndw; dd += 16)
-                tile[r * tileStrideDw + dd] = *(const uint32_t*)(rowbase + (int64_t)r * stride + 4 * dd);
+        for (int d0 = 0; d0 < ndw; d0 += 16) {
+            const int dd = d0 + (lane & 15);
+            const int ddc = min(dd, ndw - 1);
+            for (int rb = 0; rb < ch; rb += 48) {
+                uint32_t regs[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const int r = min(rb + (lane >> 4) + 4 * k, ch - 1);
+                    regs[k] = *(const uint32_t*)(rowbase + (int64_t)r * stride + 4 * ddc);
+                }
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const int r = rb + (lane >> 4) + 4 * k;
+                    if (r < ch && dd < ndw) tile[r * tileStrideDw + dd] = regs[k];
+                }
+            }
+        }
         uint32_t* sm32 = (uint32_t*)smap;
         for (int i = lane; i < ch * tileStrideDw; i += 64) sm32[i] = 0;
     }
@@ -686,6 +710,8 @@ struct BlurTiles { int32_t base[ORBX_MAXL + 1]; int32_t tilesX[ORBX_MAXL]; };
 __device__ __forceinline__ int reflect101(int p, int n)
 {
     if (n == 1) return 0;
+    p = p < 0 ? -p : p;               // one reflection each side covers every tile of a level
+    p = p >= n ? 2 * n - 2 - p : p;   // that is larger than the 3 px halo; tiny levels loop
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
     return p;
 }
@@ -714,20 +740,38 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     const uint8_t* S = level_ptr(g, src, f, l, stride);
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < (TH + 6) * IN_DW; i += 256) {
-        const int r = i / IN_DW, c = i - r * IN_DW;
-        const int sy = reflect101(ty0 + r - 3, h);
-        const int x0 = tx0 - 4 + 4 * c;
-        const uint8_t* row = S + (int64_t)sy * stride;
-        uint32_t v;
-        if (x0 >= 0 && x0 + 3 < w) {
-            v = *(const uint32_t*)(row + x0);
-        } else {
-            v = 0;
+    // (TH+6)*IN_DW = 1292 dwords: 6 per thread, all loads issued before the first LDS store
+    {
+        constexpr int N = (TH + 6) * IN_DW, PER = (N + 255) / 256;
+        uint32_t regs[PER];
+        bool edge[PER];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect101(x0 + k, w)] << (8 * k);
+        for (int k = 0; k < PER; k++) {
+            const int i = min(tid + 256 * k, N - 1);
+            const int r = i / IN_DW, c = i - r * IN_DW;
+            const int sy = reflect101(ty0 + r - 3, h);
+            const int x0 = tx0 - 4 + 4 * c;
+            edge[k] = !(x0 >= 0 && x0 + 3 < w);
+            const int xs = min(max(x0, 0), (w - 1) & ~3);   // valid aligned address for every lane
+            regs[k] = *(const uint32_t*)(S + (int64_t)sy * stride + xs);
         }
-        in[r * IN_STRIDE + c] = v;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = tid + 256 * k;
+            if (i < N) {
+                const int r = i / IN_DW, c = i - r * IN_DW;
+                uint32_t v = regs[k];
+                if (edge[k]) {  // dword straddles the image border: reflect byte by byte
+                    const int sy = reflect101(ty0 + r - 3, h);
+                    const int x0 = tx0 - 4 + 4 * c;
+                    const uint8_t* row = S + (int64_t)sy * stride;
+                    v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(x0 + b, w)] << (8 * b);
+                }
+                in[r * IN_STRIDE + c] = v;
+            }
+        }
     }
     __syncthreads();
 
