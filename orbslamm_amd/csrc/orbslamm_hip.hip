@@ -151,6 +151,7 @@ struct orbx_handle {
     uint8_t* d_blur = nullptr; size_t blurCapFrame = 0;
     uint64_t* d_candRaw = nullptr; uint64_t* d_candA = nullptr; uint64_t* d_candB = nullptr; size_t candCapFrame = 0;
     int32_t* d_candCount = nullptr;
+    int32_t* d_cellCount = nullptr;      // [maxB][cellsCap] survivors per FAST cell
     uint64_t* d_kept = nullptr; size_t keptCapFrame = 0;
     int32_t* d_keptCount = nullptr;
     int32_t* d_err = nullptr;
@@ -239,7 +240,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     if (w > 8191 || h0 > 8191) return fail(ORBX_E_UNSUPPORTED, "frame larger than 8191 px");
     out.cells.clear();
     out.tabs.clear();
-    int pyrOff = 0, blurOff = 0, candOff = 0, keptOff = 0, maxRoiW = 8, maxRoiH = 8, nodeCap = 16;
+    int pyrOff = 0, blurOff = 0, candOff = 0, keptOff = 0, maxRoiW = 8, maxRoiH = 8, nodeCap = 16, maxCells = 1;
     for (int l = 0; l < g.nlevels; l++) {
         LevelGeom& L = g.lv[l];
         const float scale = h->mvInvScaleFactor[l];
@@ -287,6 +288,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
                     c.w = (uint16_t)((int)maxX - (int)iniX); c.h = (uint16_t)((int)maxY - (int)iniY);
                     c.ci = (uint16_t)i; c.cj = (uint16_t)j;
                     c.seq = seq++;
+                    c.candOff = (uint32_t)candCap;
                     if (c.w < 7 || c.h < 7) continue;  // cv::FAST finds nothing in such a ROI
                     if (c.w > 127 || c.h > 127 || c.seq >= 65536u)
                         return fail(ORBX_E_UNSUPPORTED, "cell geometry out of range");
@@ -298,6 +300,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
                 }
             }
         }
+        maxCells = std::max(maxCells, L.nCells);
         L.candOff = candOff;
         L.candCap = align_up(candCap + 8, 8);
         candOff += L.candCap;
@@ -315,6 +318,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
         nodeCap = std::max(nodeCap, L.keptCap + 8);
     }
     g.totalCells = (int)out.cells.size();
+    g.maxCellsPerLevel = maxCells;
     g.pyrFrameBytes = std::max(pyrOff, 256);
     g.blurFrameBytes = blurOff;
     g.candFrameRecs = candOff;
@@ -433,7 +437,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
 
 static constexpr int kMatchChunks = 4;  // train chunks per query block (wave count x4)
 
-static size_t dist_lds_bytes(int cap) { return (size_t)(17 * cap + 8) * 4; }
+static size_t dist_lds_bytes(int cap, int maxCells) { return (size_t)(17 * cap + 8 + 2 * (maxCells + 1)) * 4; }
 
 // ------------------------------------------------------------------ create / destroy
 static void free_device(orbx_handle* h)
@@ -448,7 +452,7 @@ static void free_device(orbx_handle* h)
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     h->prof.destroy();
     void* ptrs[] = {h->d_pyrRanges, h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
-                    h->d_candCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
+                    h->d_candCount, h->d_cellCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
                     h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -524,6 +528,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_candA, h->candCapFrame * B * sizeof(uint64_t)));
     CRT(hipMalloc(&h->d_candB, h->candCapFrame * B * sizeof(uint64_t)));
     CRT(hipMalloc(&h->d_candCount, B * ORBX_MAXL * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_cellCount, B * h->cellsCap * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_kept, h->keptCapFrame * B * sizeof(uint64_t)));
     CRT(hipMalloc(&h->d_keptCount, B * ORBX_MAXL * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_err, sizeof(int32_t)));
@@ -611,10 +616,10 @@ static int configure_shape(orbx_handle* h, int w, int hh)
         (size_t)hg.g.blurFrameBytes > h->blurCapFrame || (size_t)hg.g.candFrameRecs > h->candCapFrame ||
         (size_t)hg.g.keptFrameRecs > h->keptCapFrame || hg.g.maxKp > h->maxKp)
         return fail(ORBX_E_INVALID, "frame %dx%d needs more scratch than the handle was created with", w, hh);
-    if (dist_lds_bytes(hg.nodeCap) > 156 * 1024)
+    if (dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel) > 156 * 1024)
         return fail(ORBX_E_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree (%d nodes)", hg.nodeCap);
-    if (dist_lds_bytes(hg.nodeCap) > 48 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)k_distribute, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dist_lds_bytes(hg.nodeCap)));
+    if (dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel) > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)k_distribute, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel)));
     hg.g.maxKp = h->maxKp;  // output slots keep their create-time pitch
     if ((rc = sync_all(h))) return rc;
     HIPCHK(hipMemcpy(h->d_geom, &hg.g, sizeof(Geom), hipMemcpyHostToDevice));
@@ -669,7 +674,6 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     src.pyr = h->d_pyr; src.blur = h->d_blur; src.f0 = 0;
     // the pyramid/blur buffers use the geometry's per-frame sizes as pitch
     hipStream_t s0 = h->stream;
-    HIPCHK(hipMemsetAsync(h->d_candCount, 0, (size_t)B * g.nlevels * sizeof(int32_t), s0));
     const int nsplit = h->serial ? 1 : std::min(h->nsplit, B);
     if (nsplit > 1) HIPCHK(hipEventRecord(h->evStart, s0));
     for (int part = 0; part < nsplit; part++) {
@@ -698,13 +702,13 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
             const size_t lds = (size_t)2 * h->tileRows * h->tileStrideDw * 4 + (size_t)h->fastListCap * 2;
             h->prof.begin(P_FAST, s);
             hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nb), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
-                               h->d_candCount, h->d_err, h->tileStrideDw, h->tileRows, h->fastListCap);
+                               h->d_cellCount, h->d_err, h->tileStrideDw, h->tileRows, h->fastListCap);
             h->prof.end(s);
         }
         h->prof.begin(P_DISTRIBUTE, s);
-        hipLaunchKernelGGL(k_distribute, dim3(g.nlevels, nb), dim3(kDistThreads), dist_lds_bytes(h->nodeCap), s, h->d_geom,
-                           h->d_candRaw, h->d_candA, h->d_candB, h->d_candCount, h->d_kept, h->d_keptCount, h->d_err,
-                           h->nodeCap, f0);
+        hipLaunchKernelGGL(k_distribute, dim3(g.nlevels, nb), dim3(kDistThreads), dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel), s, h->d_geom,
+                           h->d_candRaw, h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept,
+                           h->d_keptCount, h->d_err, h->nodeCap, f0);
         h->prof.end(s);
         HIPCHK(hipStreamWaitEvent(s, h->evBlur[part], 0));
         // the output slots are still being read by the previous batch's matching on stream3
@@ -878,12 +882,20 @@ extern "C" int orbx_level_candidates(orbx_t* h, int frame, int level, uint64_t* 
     int rc = orbx_sync(h);
     if (rc) return rc;
     if (h->curW == 0 || level < 0 || level >= h->geom.nlevels || frame < 0 || frame >= h->lastB) return fail(ORBX_E_INVALID, "bad frame/level");
-    int32_t cnt = 0;
-    HIPCHK(hipMemcpy(&cnt, h->d_candCount + frame * h->geom.nlevels + level, sizeof cnt, hipMemcpyDeviceToHost));
-    if (n) *n = cnt;
+    // FAST leaves every cell's survivors in the cell's own segment: gather them
+    const LevelGeom& L = h->geom.lv[level];
+    std::vector<int32_t> counts(std::max(L.nCells, 1));
+    if (L.nCells) HIPCHK(hipMemcpy(counts.data(), h->d_cellCount + (size_t)frame * h->geom.totalCells + L.cellBase, (size_t)L.nCells * 4, hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int c = 0; c < L.nCells; c++) total += counts[c];
+    if (n) *n = total;
     if (!dst) return ORBX_OK;
-    if (cnt > cap) return fail(ORBX_E_CAPACITY, "%d candidates, capacity %d", cnt, cap);
-    HIPCHK(hipMemcpy(dst, h->d_candRaw + (size_t)frame * h->geom.candFrameRecs + h->geom.lv[level].candOff, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    if (total > cap) return fail(ORBX_E_CAPACITY, "%d candidates, capacity %d", total, cap);
+    std::vector<uint64_t> seg(L.candCap);
+    HIPCHK(hipMemcpy(seg.data(), h->d_candRaw + (size_t)frame * h->geom.candFrameRecs + L.candOff, (size_t)L.candCap * 8, hipMemcpyDeviceToHost));
+    int o = 0;
+    for (int c = 0; c < L.nCells; c++)
+        for (int i = 0; i < counts[c]; i++) dst[o++] = seg[h->cells[L.cellBase + c].candOff + i];
     return ORBX_OK;
 }
 

@@ -50,6 +50,7 @@ struct Geom {
     int32_t candFrameRecs;
     int32_t keptFrameRecs;
     int32_t maxKp;            // output capacity per frame
+    int32_t maxCellsPerLevel;
     int32_t umax[16];         // :452-469
     LevelGeom lv[ORBX_MAXL];
 };
@@ -62,6 +63,7 @@ struct Cell {
     uint16_t w, h;     // maxX-iniX, maxY-iniY
     uint16_t ci, cj;   // i (row), j (col)
     uint32_t seq;      // rank of the cell in the reference's visiting order (within level)
+    uint32_t candOff;  // first record of this cell's segment inside the level's candidate segment
 };
 
 // Candidate record (u64), see DESIGN.md:

@@ -208,7 +208,7 @@ __device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p, const int* 
 
 __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const Cell* __restrict__ cells,
                                             FrameSrc src, uint64_t* __restrict__ cand,
-                                            int32_t* __restrict__ candCount, int32_t* __restrict__ errFlag,
+                                            int32_t* __restrict__ cellCount, int32_t* __restrict__ errFlag,
                                             int tileStrideDw, int tileRows, int listCap)
 {
     extern __shared__ uint32_t lds[];
@@ -293,7 +293,9 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     }
     if (cnt > listCap) { if (lane == 0) atomicOr(errFlag, 8); cnt = listCap; }
     __syncthreads();
-    if (cnt == 0) return;
+    // every cell owns a fixed segment of the candidate buffer (no atomics, deterministic layout)
+    int32_t* myCount = cellCount + (int64_t)f * g->totalCells + blockIdx.x;
+    if (cnt == 0) { if (lane == 0) *myCount = 0; return; }
 
     // stage 2: exact score on the dense list
     for (int i = lane; i < cnt; i += 64) {
@@ -334,14 +336,13 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
         if (total > 0 || th == th2) break;
         th = th2;
     }
+    if (lane == 0) *myCount = total;
     if (total == 0) return;
     __syncthreads();
 
-    int basePos = 0;
-    if (lane == 0) basePos = atomicAdd(&candCount[f * g->nlevels + level], total);
-    basePos = __shfl(basePos, 0);
-    uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff;
-    const int candCap = L.candCap;
+    uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff + c.candOff;
+    const int basePos = 0;
+    const int candCap = ((cw - 6 + 1) >> 1) * ((ch - 6 + 1) >> 1);  // NMS bound = segment size
     int run = 0;
     for (int i = lane; i < cntUp; i += 64) {
         int e = 0;
@@ -452,7 +453,9 @@ __device__ __forceinline__ void wave_divide(const uint64_t* __restrict__ srcb, u
 __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restrict__ g,
                                                             const uint64_t* __restrict__ candRaw,
                                                             uint64_t* __restrict__ candA, uint64_t* __restrict__ candB,
-                                                            const int32_t* __restrict__ candCount,
+                                                            const Cell* __restrict__ cells,
+                                                            const int32_t* __restrict__ cellCount,
+                                                            int32_t* __restrict__ candCount,
                                                             uint64_t* __restrict__ kept, int32_t* __restrict__ keptCount,
                                                             int32_t* __restrict__ errFlag, int cap, int f0)
 {
@@ -462,12 +465,21 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     constexpr int NW = kDistThreads / 64;
     const LevelGeom& L = g->lv[l];
     const int N = L.nFeat;
-    int n = candCount[f * g->nlevels + l];
-    if (n > L.candCap) n = L.candCap;
-    if (n <= 0 || L.nIni < 1) {
-        if (tid == 0) keptCount[f * g->nlevels + l] = 0;
-        return;
+    // candidates of this level = the per-cell segments FAST filled; prefix of the cell counts
+    // in LDS turns a flat index into (cell, slot) by binary search
+    const int nCells = L.nCells;
+    uint32_t* cellPref = smem + 17 * cap + 8;            // [maxCells + 1]
+    uint32_t* cellOffs = cellPref + g->maxCellsPerLevel + 1;  // [maxCells]
+    uint32_t* wtmp0 = smem + 17 * cap;
+    for (int i = tid; i < nCells; i += kDistThreads) {
+        cellPref[i] = (uint32_t)cellCount[(int64_t)f * g->totalCells + L.cellBase + i];
+        cellOffs[i] = cells[L.cellBase + i].candOff;
     }
+    __syncthreads();
+    int n = (int)block_excl_scan(cellPref, nCells, wtmp0);
+    if (tid == 0) { cellPref[nCells] = (uint32_t)n; candCount[f * g->nlevels + l] = n; }
+    __syncthreads();
+    if (n > L.candCap) n = L.candCap;
     uint64_t* bufs[2] = {candA + (int64_t)f * g->candFrameRecs + L.candOff,
                          candB + (int64_t)f * g->candFrameRecs + L.candOff};
 
@@ -506,7 +518,9 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                 int r = -1;
                 uint64_t key = 0;
                 if (p < n) {
-                    key = srcb[p];
+                    int lo = 0, hi = nCells;  // largest c with cellPref[c] <= p
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cellPref[mid] <= (uint32_t)p) lo = mid; else hi = mid; }
+                    key = srcb[cellOffs[lo] + (p - cellPref[lo])];
                     r = (int)__fdiv_rn((float)cand_x(key), hX);
                     if (r >= nIni) r = nIni - 1;
                 }
