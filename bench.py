@@ -41,6 +41,7 @@ def algorithmic_bytes(ex, w, h, nfeat):
         "k_orient_desc": 749 * nfeat + 512 * nfeat + (32 + 28) * nfeat,
         "k_distribute": 0,  # works on candidate records, not counted in the SURVEY figure
         "k_match_best2": 2 * 32 * nfeat + 8 * nfeat,
+        "k_match_accept": 0,
         "k_match_prune": 0,
     }
     return per, sum(per.values())
@@ -124,6 +125,21 @@ def main():
     kps_last, _ = ex.download(B - 1)
     gathered, dt_max = streams.gather_stats((B * args.steps, len(kps_last), nmatch_last, dt), world, device)
 
+    # serialized replay (untimed): the same steps with every kernel alone on the GPU, to tell
+    # kernel cost from overlap.  `value` above is NOT affected by it.
+    prof_serial = {}
+    if rank == 0 and not args.no_profile:
+        ex.set_serial(True)
+        step()
+        ex.sync()
+        ex.profile_enable(True)
+        ex.profile_read(reset=True)
+        for _ in range(args.steps):
+            step()
+        prof_serial = ex.profile_read(reset=True)
+        ex.profile_enable(False)
+        ex.set_serial(False)
+
     if rank == 0:
         fps, total_frames = streams.aggregate(gathered, dt_max)
         per, bytes_frame = algorithmic_bytes(ex, W, H, NFEAT)
@@ -137,20 +153,36 @@ def main():
             "keypoints_last_frame": [int(g[1]) for g in gathered],
             "matches_last_frame": [int(g[2]) for g in gathered],
         }
-        if prof:
+
+        def roofline_of(prof, dom=None):
             kern = {k: v for k, v in prof.items() if v[1] > 0 and k.startswith("k_")}
-            dom = max(kern, key=lambda k: kern[k][0])
+            if dom is None:
+                dom = max(kern, key=lambda k: kern[k][0])
             avg_ms = kern[dom][0] / kern[dom][1]
-            launches_per_step = kern[dom][1] / args.steps
-            alg_launch = per[dom] * B / launches_per_step
+            frames_per_launch = B * args.steps / kern[dom][1]
+            alg_launch = per.get(dom, 0) * frames_per_launch
             achieved = alg_launch / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_launch,
-                               "pipeline_bytes_per_frame": bytes_frame,
-                               "pipeline_achieved_GBs": fps / world * bytes_frame / 1e9,
-                               "pipeline_frac": fps / world * bytes_frame / 1e9 / HBM_PEAK_GBS,
-                               "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()}}
+            traffic = None
+            try:  # PMC pass (separate rocprofv3 --pmc runs), KB per 64-frame launch as reported
+                t = json.load(open(os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")))[dom]
+                traffic = (t["fetch_kb"] + t["write_kb"]) * 1024.0 * frames_per_launch / t["frames_per_launch"]
+            except Exception:
+                pass
+            return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                    "frames_per_launch": frames_per_launch, "algorithmic_bytes_per_launch": alg_launch,
+                    "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()}}
+
+        if prof_serial:
+            # the dominant kernel is picked where kernels run alone; its figure inside the timed
+            # (overlapped) region is reported as `roofline`, the isolated one beside it
+            iso = roofline_of(prof_serial)
+            out["roofline"] = roofline_of(prof, iso["kernel"]) if prof else iso
+            out["roofline"]["overlapped_streams"] = True
+            out["roofline"]["isolated"] = {k: iso[k] for k in ("achieved", "frac", "avg_launch_ms", "frames_per_launch", "kernel_ms_per_step")}
+            out["roofline"]["pipeline_bytes_per_frame"] = bytes_frame
+            out["roofline"]["pipeline_achieved_GBs"] = fps / world * bytes_frame / 1e9
+            out["roofline"]["pipeline_frac"] = fps / world * bytes_frame / 1e9 / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)
         print(json.dumps(out))

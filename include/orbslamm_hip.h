@@ -145,6 +145,9 @@ typedef struct {
     double ms[ORBX_PROF_MAX];
     int64_t launches[ORBX_PROF_MAX];
 } OrbxProfile;
+/* serial != 0: every kernel of a call runs on the handle's main stream (no overlap of
+ * blur / matching / sub-batches); used to time kernels in isolation. */
+int orbx_set_serial(orbx_t* h, int serial);
 int orbx_profile_enable(orbx_t* h, int enable);
 int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset);
 

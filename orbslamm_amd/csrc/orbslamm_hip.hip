@@ -978,6 +978,15 @@ extern "C" int orbx_reset_stream(orbx_t* h)
     return ORBX_OK;
 }
 
+extern "C" int orbx_set_serial(orbx_t* h, int serial)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if ((rc = sync_all(h))) return rc;
+    h->serial = serial != 0;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_profile_enable(orbx_t* h, int enable)
 {
     int rc = check_device(h);

@@ -172,6 +172,9 @@ class ORBextractor:
         return out[:n.value]
 
     # ---- profiling
+    def set_serial(self, on=True):
+        check(self._L.orbx_set_serial(self._h, int(bool(on))))
+
     def profile_enable(self, on=True):
         check(self._L.orbx_profile_enable(self._h, int(bool(on))))
 
