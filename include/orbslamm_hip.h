@@ -220,6 +220,44 @@ int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
                               const uint8_t* tdesc, int nt,
                               uint8_t* t_occ, int32_t* assign, int* nmatches);
 
+/* ---- the remaining ORBmatcher entry points on the same primitive ---- */
+
+/* Independent windowed best search, the device part of
+ *   int ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, float th)               src/ORBmatcher.cc:827-975  (chi2 = 1)
+ *   int ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float, vector<MapPoint*>&)  :977-1102 (chi2 = 0)
+ *   int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>&, s12, R12, t12, th)   :1104-1328 (both passes, chi2 = 0)
+ * Per projected map point: (u, v, radius), predicted level (window [pred-1, pred]), descriptor,
+ * valid flag; optional stereo terms (q_ur, t_uright = mvuRight, NULL for mono).
+ * inv_sigma2 = mvInvLevelSigma2 (nlevels floats, needed when chi2).  best_idx = -1 if none
+ * (best_dist = 256).  The caller applies bestDist <= TH_LOW / TH_HIGH and edits the map. */
+int orbm_window_best(orbm_t* h, const float* q_uvr, const float* q_ur, const int8_t* q_pred,
+                     const uint8_t* qdesc, const uint8_t* qvalid, int nq,
+                     const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc,
+                     const float* t_uright, int nt, const float* inv_sigma2, int nlevels, int chi2,
+                     int32_t* best_idx, int32_t* best_dist);
+
+/* int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched,
+ *                                         vector<int>& vnMatches12, int windowSize)   src/ORBmatcher.cc:407-522
+ * q_xy = vbPrevMatched (nq x 2).  matches12[nq] = index in F2 or -1; the caller refreshes
+ * vbPrevMatched from it (:517-519). */
+int orbm_search_for_initialization(orbm_t* h, const float* q_xy, float window_size,
+                                   const OrbxKeyPoint* q_keys_un, const uint8_t* qdesc, int nq,
+                                   const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc, int nt,
+                                   float nnratio, int check_ori, int32_t* matches12, int* nmatches);
+
+/* int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12,
+ *              vector<pair<size_t,size_t>>& vMatchedPairs, bool bOnlyStereo)          src/ORBmatcher.cc:659-825
+ * skip1/skip2: the feature already has a MapPoint; uright = mvuRight (NULL for mono);
+ * F12 row-major; (ex, ey) = epipole in image 2 (:666-672, cv::Mat algebra stays in the caller);
+ * sf2 / sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2.  matches12[n1] = index in KF2 or -1. */
+int orbm_search_for_triangulation(orbm_t* h,
+                                  const OrbxKeyPoint* k1, const uint8_t* d1, const uint8_t* skip1, const float* uright1, int n1,
+                                  const OrbmFeatVec* fv1,
+                                  const OrbxKeyPoint* k2, const uint8_t* d2, const uint8_t* skip2, const float* uright2, int n2,
+                                  const OrbmFeatVec* fv2,
+                                  const float F12[9], float ex, float ey, const float* sf2, const float* sigma2_2, int nlevels,
+                                  int only_stereo, int check_ori, int32_t* matches12, int* nmatches);
+
 /* GetFeaturesInArea on the device grid, for tests: out[cap] indices in reference order */
 int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const OrbxKeyPoint* keys_un, int n,
                           float x, float y, float r, int minLevel, int maxLevel,

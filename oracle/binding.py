@@ -77,6 +77,9 @@ def lib(path=None):
         L.orc_features_in_area.restype = C.c_int
         L.orc_search_by_bow.restype = C.c_int
         L.orc_search_by_projection.restype = C.c_int
+        L.orc_window_best.restype = C.c_int
+        L.orc_search_for_initialization.restype = C.c_int
+        L.orc_search_for_triangulation.restype = C.c_int
         if path is not None:
             return L
         _lib = L
@@ -276,3 +279,62 @@ def search_by_projection(mode, nnratio, check_ori, th_dist, q_uvr, q_lvl, qdesc,
                                    q_uvr.shape[0], C.byref(gp), _p(t_keys_un), _p(start), _p(idx),
                                    _p(tdesc), t_keys_un.shape[0], _p(t_occ), _p(assign))
     return assign, t_occ, n
+
+
+def window_best(q_uvr, q_pred, qdesc, qvalid, gp, t_keys_un, start, idx, tdesc, inv_sigma2=None, chi2=False,
+                q_ur=None, t_uright=None, L=None):
+    L = L or lib()
+    q_uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
+    q_pred = np.ascontiguousarray(q_pred, dtype=np.int8)
+    qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+    qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+    t_keys_un = np.ascontiguousarray(t_keys_un, dtype=KP_DTYPE)
+    tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+    sig = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, dtype=np.float32)
+    qur = None if q_ur is None else np.ascontiguousarray(q_ur, dtype=np.float32)
+    tur = None if t_uright is None else np.ascontiguousarray(t_uright, dtype=np.float32)
+    nq = q_uvr.shape[0]
+    bi = np.full(max(nq, 1), -1, np.int32)
+    bd = np.full(max(nq, 1), 256, np.int32)
+    L.orc_window_best(_p(q_uvr), _p(qur), _p(q_pred), _p(qdesc), _p(qv), nq, C.byref(gp), _p(t_keys_un), _p(start), _p(idx),
+                      _p(tdesc), _p(tur), t_keys_un.shape[0], _p(sig), int(bool(chi2)), _p(bi), _p(bd))
+    return bi[:nq], bd[:nq]
+
+
+def search_for_initialization(q_xy, window, q_keys_un, qdesc, gp, t_keys_un, start, idx, tdesc, nnratio, check_ori, L=None):
+    L = L or lib()
+    q_xy = np.ascontiguousarray(q_xy, dtype=np.float32)
+    q_keys_un = np.ascontiguousarray(q_keys_un, dtype=KP_DTYPE)
+    qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+    t_keys_un = np.ascontiguousarray(t_keys_un, dtype=KP_DTYPE)
+    tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+    nq = q_keys_un.shape[0]
+    m12 = np.full(max(nq, 1), -1, np.int32)
+    n = L.orc_search_for_initialization(_p(q_xy), C.c_float(window), _p(q_keys_un), _p(qdesc), nq, C.byref(gp), _p(t_keys_un),
+                                        _p(start), _p(idx), _p(tdesc), t_keys_un.shape[0], C.c_float(nnratio),
+                                        int(bool(check_ori)), _p(m12))
+    return m12[:nq], n
+
+
+def search_for_triangulation(k1, d1, skip1, fv1, k2, d2, skip2, fv2, F12, ex, ey, sf2, sigma2_2, only_stereo, check_ori,
+                             uright1=None, uright2=None, L=None):
+    L = L or lib()
+    k1 = np.ascontiguousarray(k1, dtype=KP_DTYPE)
+    k2 = np.ascontiguousarray(k2, dtype=KP_DTYPE)
+    d1 = np.ascontiguousarray(d1, dtype=np.uint8)
+    d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+    s1 = None if skip1 is None else np.ascontiguousarray(skip1, dtype=np.uint8)
+    s2 = None if skip2 is None else np.ascontiguousarray(skip2, dtype=np.uint8)
+    u1 = None if uright1 is None else np.ascontiguousarray(uright1, dtype=np.float32)
+    u2 = None if uright2 is None else np.ascontiguousarray(uright2, dtype=np.float32)
+    F = np.ascontiguousarray(F12, dtype=np.float32).reshape(9)
+    sf2 = np.ascontiguousarray(sf2, dtype=np.float32)
+    sg2 = np.ascontiguousarray(sigma2_2, dtype=np.float32)
+    f1, keep1 = _featvec(*fv1)
+    f2, keep2 = _featvec(*fv2)
+    n1 = k1.shape[0]
+    m12 = np.full(max(n1, 1), -1, np.int32)
+    n = L.orc_search_for_triangulation(_p(k1), _p(d1), _p(s1), _p(u1), n1, C.byref(f1), _p(k2), _p(d2), _p(s2), _p(u2),
+                                       k2.shape[0], C.byref(f2), _p(F), C.c_float(ex), C.c_float(ey), _p(sf2), _p(sg2),
+                                       int(bool(only_stereo)), int(bool(check_ori)), _p(m12))
+    return m12[:n1], n

@@ -284,3 +284,168 @@ int orc_search_by_projection(const OrcProjParams* pp,
     free(cand);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------ SURVEY 8(f).1 */
+/* Fuse :908-946 / :1053-1079, SearchBySim3 :1196-1222 / :1276-1302 */
+int orc_window_best(const float* q_uvr, const float* q_ur, const int8_t* q_pred,
+                    const uint8_t* qdesc, const uint8_t* qvalid, int nq,
+                    const OrcGridParams* gp, const OrcKeyPoint* tk,
+                    const int32_t* cell_start, const int32_t* cell_idx,
+                    const uint8_t* tdesc, const float* t_uright, int nt,
+                    const float* inv_sigma2, int chi2,
+                    int32_t* best_idx, int32_t* best_dist)
+{
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt + 1));
+    for (int q = 0; q < nq; q++) {
+        best_idx[q] = -1;
+        best_dist[q] = 256;
+        if (qvalid && !qvalid[q]) continue;
+        const float u = q_uvr[3 * q], v = q_uvr[3 * q + 1], radius = q_uvr[3 * q + 2];
+        const int pred = q_pred[q];
+        const int nc = orc_features_in_area(gp, tk, cell_start, cell_idx, u, v, radius, -1, -1, cand, nt);
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            const int kpLevel = tk[idx].octave;
+            if (kpLevel < pred - 1 || kpLevel > pred) continue;
+            if (chi2) {
+                const float ex = u - tk[idx].x, ey = v - tk[idx].y;
+                if (t_uright && t_uright[idx] >= 0) {
+                    const float er = q_ur[q] - t_uright[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if ((double)(e2 * inv_sigma2[kpLevel]) > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if ((double)(e2 * inv_sigma2[kpLevel]) > 5.99) continue;
+                }
+            }
+            const int dist = orc_descriptor_distance(qdesc + 32 * (size_t)q, tdesc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[q] = bestIdx;
+        best_dist[q] = bestDist;
+    }
+    free(cand);
+    return 0;
+}
+
+/* :407-522 */
+int orc_search_for_initialization(const float* q_xy, float window, const OrcKeyPoint* qk,
+                                  const uint8_t* qdesc, int nq,
+                                  const OrcGridParams* gp, const OrcKeyPoint* tk,
+                                  const int32_t* cell_start, const int32_t* cell_idx,
+                                  const uint8_t* tdesc, int nt,
+                                  float nnratio, int check_ori, int32_t* m12)
+{
+    int nmatches = 0;
+    RotHist rh; rh_init(&rh);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt + 1));
+    int* matchedDist = (int*)malloc(sizeof(int) * (size_t)(nt + 1));
+    int* m21 = (int*)malloc(sizeof(int) * (size_t)(nt + 1));
+    for (int i = 0; i < nt; i++) { matchedDist[i] = 0x7FFFFFFF; m21[i] = -1; }
+    for (int i = 0; i < nq; i++) m12[i] = -1;
+    for (int i1 = 0; i1 < nq; i1++) {
+        const int level1 = qk[i1].octave;
+        if (level1 > 0) continue;
+        const int nc = orc_features_in_area(gp, tk, cell_start, cell_idx, q_xy[2 * i1], q_xy[2 * i1 + 1],
+                                            window, level1, level1, cand, nt);
+        if (nc == 0) continue;
+        int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            const int dist = orc_descriptor_distance(qdesc + 32 * (size_t)i1, tdesc + 32 * (size_t)i2);
+            if (matchedDist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if ((float)bestDist < (float)bestDist2 * nnratio) {
+                if (m21[bestIdx2] >= 0) { m12[m21[bestIdx2]] = -1; nmatches--; }
+                m12[i1] = bestIdx2;
+                m21[bestIdx2] = i1;
+                matchedDist[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_ori) rh_push(&rh, orc_rot_bin(qk[i1].angle, tk[bestIdx2].angle), i1);
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        orc_three_maxima(rh.n, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < rh.n[i]; j++) {
+                const int idx1 = rh.v[i][j];
+                if (m12[idx1] >= 0) { m12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    rh_free(&rh);
+    free(cand); free(matchedDist); free(m21);
+    return nmatches;
+}
+
+/* :141-157 CheckDistEpipolarLine */
+static int check_dist_epipolar(const OrcKeyPoint* kp1, const OrcKeyPoint* kp2, const float* F, const float* sigma2_2)
+{
+    const float a = kp1->x * F[0] + kp1->y * F[3] + F[6];
+    const float b = kp1->x * F[1] + kp1->y * F[4] + F[7];
+    const float c = kp1->x * F[2] + kp1->y * F[5] + F[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)sigma2_2[kp2->octave];
+}
+
+/* :659-825.  vbMatched2 is never set in the reference, so queries are independent. */
+int orc_search_for_triangulation(const OrcKeyPoint* k1, const uint8_t* d1, const uint8_t* skip1,
+                                 const float* uright1, int n1, const OrcFeatVec* fv1,
+                                 const OrcKeyPoint* k2, const uint8_t* d2, const uint8_t* skip2,
+                                 const float* uright2, int n2, const OrcFeatVec* fv2,
+                                 const float F12[9], float ex, float ey,
+                                 const float* sf2, const float* sigma2_2,
+                                 int only_stereo, int check_ori, int32_t* m12)
+{
+    int nmatches = 0;
+    RotHist rh; rh_init(&rh);
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    int a = 0, b = 0;
+    while (a < fv1->n_nodes && b < fv2->n_nodes) {
+        if (fv1->node_id[a] == fv2->node_id[b]) {
+            for (int i1 = fv1->start[a]; i1 < fv1->start[a + 1]; i1++) {
+                const int idx1 = fv1->idx[i1];
+                if (skip1 && skip1[idx1]) continue;
+                const int bStereo1 = uright1 && uright1[idx1] >= 0;
+                if (only_stereo && !bStereo1) continue;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = fv2->start[b]; i2 < fv2->start[b + 1]; i2++) {
+                    const int idx2 = fv2->idx[i2];
+                    if (skip2 && skip2[idx2]) continue;
+                    const int bStereo2 = uright2 && uright2[idx2] >= 0;
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = orc_descriptor_distance(d1 + 32 * (size_t)idx1, d2 + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - k2[idx2].x, distey = ey - k2[idx2].y;
+                        if (distex * distex + distey * distey < 100 * sf2[k2[idx2].octave]) continue;
+                    }
+                    if (check_dist_epipolar(&k1[idx1], &k2[idx2], F12, sigma2_2)) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    m12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_ori) rh_push(&rh, orc_rot_bin(k1[idx1].angle, k2[bestIdx2].angle), idx1);
+                }
+            }
+            a++; b++;
+        } else if (fv1->node_id[a] < fv2->node_id[b]) {
+            while (a < fv1->n_nodes && fv1->node_id[a] < fv2->node_id[b]) a++;
+        } else {
+            while (b < fv2->n_nodes && fv2->node_id[b] < fv1->node_id[a]) b++;
+        }
+    }
+    if (check_ori) nmatches -= rh_prune(&rh, m12);
+    rh_free(&rh);
+    return nmatches;
+}

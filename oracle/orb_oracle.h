@@ -162,6 +162,41 @@ int  orc_search_by_projection(const OrcProjParams* pp,
                               const uint8_t* tdesc, int nt,
                               uint8_t* t_occ, int32_t* assign);
 
+/* ---- the remaining matchers on the same primitive ---- */
+
+/* Independent windowed best search shared by Fuse (ORBmatcher.cc:827-975, chi2=1),
+ * Fuse(KF,Scw,...) (:977-1102, chi2=0) and both passes of SearchBySim3 (:1104-1328, chi2=0):
+ * candidates = KeyFrame::GetFeaturesInArea(u,v,radius) (no level filter), keep octave in
+ * [pred-1, pred], optional reprojection chi-square test, best = strict <, first wins.
+ * best_idx[q] = -1 when no candidate survives (best_dist then 256). */
+int  orc_window_best(const float* q_uvr, const float* q_ur, const int8_t* q_pred,
+                     const uint8_t* qdesc, const uint8_t* qvalid, int nq,
+                     const OrcGridParams* gp, const OrcKeyPoint* tk,
+                     const int32_t* cell_start, const int32_t* cell_idx,
+                     const uint8_t* tdesc, const float* t_uright, int nt,
+                     const float* inv_sigma2, int chi2,
+                     int32_t* best_idx, int32_t* best_dist);
+
+/* SearchForInitialization, ORBmatcher.cc:407-522.  q_xy = vbPrevMatched; only octave-0
+ * queries search; a better later match steals the train feature (:466-470). */
+int  orc_search_for_initialization(const float* q_xy, float window, const OrcKeyPoint* qk,
+                                   const uint8_t* qdesc, int nq,
+                                   const OrcGridParams* gp, const OrcKeyPoint* tk,
+                                   const int32_t* cell_start, const int32_t* cell_idx,
+                                   const uint8_t* tdesc, int nt,
+                                   float nnratio, int check_ori, int32_t* matches12);
+
+/* SearchForTriangulation, ORBmatcher.cc:659-825.  skip1/skip2: feature already has a
+ * MapPoint; uright = mvuRight (NULL for mono); F12 row-major 3x3; (ex,ey) epipole in
+ * image 2; sf2/sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2. */
+int  orc_search_for_triangulation(const OrcKeyPoint* k1, const uint8_t* d1, const uint8_t* skip1,
+                                  const float* uright1, int n1, const OrcFeatVec* fv1,
+                                  const OrcKeyPoint* k2, const uint8_t* d2, const uint8_t* skip2,
+                                  const float* uright2, int n2, const OrcFeatVec* fv2,
+                                  const float F12[9], float ex, float ey,
+                                  const float* sf2, const float* sigma2_2,
+                                  int only_stereo, int check_ori, int32_t* matches12);
+
 #ifdef __cplusplus
 }
 #endif

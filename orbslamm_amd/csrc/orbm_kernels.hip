@@ -563,4 +563,193 @@ __global__ void k_features_in_area(GridDev g, const KeyDev* keys, const int32_t*
     *nout = n;
 }
 
+// ------------------------------------------------------------------ remaining matchers
+// Independent windowed best search: Fuse (:908-946, chi2 = 1), Fuse(KF,Scw) (:1053-1079) and both
+// passes of SearchBySim3 (:1196-1222, :1276-1302).  One thread per projected map point.
+struct WinArgs {
+    GridDev grid;
+    const KeyDev* tkeys; const int32_t* cellStart; const int32_t* cellIdx;
+    const float* quvr; const float* qur; const int8_t* qpred; const uint8_t* qdesc; const uint8_t* qvalid;
+    const uint8_t* tdesc; const float* turight; const float* invSigma2;
+    int32_t nq; int32_t chi2;
+    int32_t* bestIdx; int32_t* bestDist;
+};
+
+__global__ void k_window_best(WinArgs a)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.nq) return;
+    int bestDist = 256, bestIdx = -1;
+    if (!a.qvalid || a.qvalid[q]) {
+        const float u = a.quvr[3 * q], v = a.quvr[3 * q + 1], radius = a.quvr[3 * q + 2];
+        const int pred = a.qpred[q];
+        const float ur = a.qur ? a.qur[q] : 0.f;
+        uint32_t qw[8];
+        const uint32_t* qp = (const uint32_t*)(a.qdesc + (int64_t)q * 32);
+#pragma unroll
+        for (int i = 0; i < 8; i++) qw[i] = qp[i];
+        for_each_in_area(a.grid, a.tkeys, a.cellStart, a.cellIdx, u, v, radius, -1, -1, [&](int idx) {
+            const KeyDev& kp = a.tkeys[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < pred - 1 || kpLevel > pred) return;
+            if (a.chi2) {
+                const float ex = __fsub_rn(u, kp.x), ey = __fsub_rn(v, kp.y);
+                if (a.turight && a.turight[idx] >= 0) {
+                    const float er = __fsub_rn(ur, a.turight[idx]);
+                    const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                    if ((double)__fmul_rn(e2, a.invSigma2[kpLevel]) > 7.8) return;
+                } else {
+                    const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                    if ((double)__fmul_rn(e2, a.invSigma2[kpLevel]) > 5.99) return;
+                }
+            }
+            const int d = hamming256(qw, (const uint32_t*)(a.tdesc + (int64_t)idx * 32));
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        });
+    }
+    a.bestIdx[q] = bestIdx;
+    a.bestDist[q] = bestDist;
+}
+
+// SearchForInitialization (:407-522): sequential over the queries; per-train best distance so
+// far lives in LDS.  Candidates/distances come from k_proj_candidates (window, octave 0).
+__global__ __launch_bounds__(64) void k_init_resolve(ProjArgs a, int32_t* __restrict__ m12, int32_t* __restrict__ m21)
+{
+    extern __shared__ uint32_t ilds[];
+    uint16_t* matchedDist = (uint16_t*)ilds;  // [nt], 0xFFFF = INT_MAX
+    __shared__ int hist[32];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < a.nt; i += 64) { matchedDist[i] = 0xFFFF; m21[i] = -1; }
+    for (int i = lane; i < a.nq; i += 64) m12[i] = -1;
+    if (lane < 32) hist[lane] = 0;
+    __syncthreads();
+    int nPush = 0;  // the match count is recounted from m12 at the end (steals and pruning clear entries)
+    for (int q = 0; q < a.nq; q++) {
+        const int cs = a.candOff[q], ce = a.candOff[q + 1];
+        if (ce == cs) continue;
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        for (int c = cs + lane; c < ce; c += 64) {
+            const uint32_t key = a.candKey[c];
+            if ((uint32_t)matchedDist[a.candIdx[c]] <= (key >> 22)) continue;  // :441-442
+            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const uint32_t o1 = __shfl_xor(k1, dd), o2 = __shfl_xor(k2, dd);
+            top2_merge(k1, k2, o1, o2);
+        }
+        if (k1 == 0xFFFFFFFFu) continue;
+        const int best = (int)(k1 >> 22);
+        const float best2f = k2 == 0xFFFFFFFFu ? 2147483648.0f : (float)(int)(k2 >> 22);
+        if (best <= a.thDist && (float)best < __fmul_rn(best2f, a.nnratio)) {
+            const int t = a.candIdx[cs + (int)((k1 >> 4) & 0x3FFFF)];
+            if (lane == 0) {
+                const int prev = m21[t];
+                if (prev >= 0) m12[prev] = -1;
+                m12[q] = t;
+                m21[t] = q;
+                matchedDist[t] = (uint16_t)best;
+                if (a.checkOri) {
+                    const int bin = rot_bin(a.qang[q], a.tkeys[t].angle);
+                    a.pushT[nPush] = q;
+                    a.pushBin[nPush] = (uint8_t)bin;
+                    hist[bin]++;
+                }
+            }
+            if (a.checkOri) nPush++;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (a.checkOri && lane == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < kHistoLength; i++) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        for (int p = 0; p < nPush; p++) {
+            const int bin = a.pushBin[p];
+            if (bin != ind1 && bin != ind2 && bin != ind3) m12[a.pushT[p]] = -1;
+        }
+    }
+    __syncthreads();
+    int local = 0;
+    for (int i = lane; i < a.nq; i += 64) local += m12[i] >= 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if (lane == 0) *a.nmatch = local;
+}
+
+// SearchForTriangulation (:659-825): vbMatched2 is never set in the reference, so every query
+// is independent: best = smallest distance among candidates that pass the epipole-distance and
+// epipolar-line tests, LAST one wins ties (the scan keeps dist <= bestDist).
+struct TriArgs {
+    const KeyDev* k1; const uint8_t* d1; const uint8_t* skip1; const float* ur1;
+    const KeyDev* k2; const uint8_t* d2; const uint8_t* skip2; const float* ur2;
+    const int32_t* start1; const int32_t* idx1; const int32_t* start2; const int32_t* idx2;
+    const int32_t* pairA; const int32_t* pairB;
+    float F[9]; float ex, ey;
+    float sf2[16]; float sigma2[16];
+    int32_t onlyStereo, checkOri;
+    int32_t* m12; uint8_t* binOf; int32_t* hist;
+};
+
+__global__ __launch_bounds__(64) void k_triangulation_pairs(TriArgs a)
+{
+    const int lane = threadIdx.x;
+    const int na = a.pairA[blockIdx.x], nb = a.pairB[blockIdx.x];
+    const int s1 = a.start1[na], e1 = a.start1[na + 1], s2 = a.start2[nb], e2 = a.start2[nb + 1];
+    for (int i1 = s1; i1 < e1; i1++) {
+        const int q = a.idx1[i1];
+        if (a.skip1 && a.skip1[q]) continue;
+        const bool st1 = a.ur1 && a.ur1[q] >= 0;
+        if (a.onlyStereo && !st1) continue;
+        const KeyDev kp1 = a.k1[q];
+        uint32_t qw[8];
+        const uint32_t* qp = (const uint32_t*)(a.d1 + (int64_t)q * 32);
+#pragma unroll
+        for (int i = 0; i < 8; i++) qw[i] = qp[i];
+        // epipolar line in image 2: l = x1' F12 (:141-146)
+        const float la = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[0]), __fmul_rn(kp1.y, a.F[3])), a.F[6]);
+        const float lb = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[1]), __fmul_rn(kp1.y, a.F[4])), a.F[7]);
+        const float lc = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[2]), __fmul_rn(kp1.y, a.F[5])), a.F[8]);
+        const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+        uint32_t best = 0xFFFFFFFFu;
+        for (int i2 = s2 + lane; i2 < e2; i2 += 64) {
+            const int t = a.idx2[i2];
+            if (a.skip2 && a.skip2[t]) continue;
+            const bool st2 = a.ur2 && a.ur2[t] >= 0;
+            if (a.onlyStereo && !st2) continue;
+            const int d = hamming256(qw, (const uint32_t*)(a.d2 + (int64_t)t * 32));
+            if (d > 50) continue;  // TH_LOW
+            const KeyDev& kp2 = a.k2[t];
+            if (!st1 && !st2) {
+                const float dx = __fsub_rn(a.ex, kp2.x), dy = __fsub_rn(a.ey, kp2.y);
+                if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, a.sf2[kp2.octave & 15])) continue;
+            }
+            if (den == 0) continue;
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, kp2.x), __fmul_rn(lb, kp2.y)), lc);
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < 3.84 * (double)a.sigma2[kp2.octave & 15])) continue;
+            const uint32_t key = ((uint32_t)d << 22) | (0x3FFFFFu - (uint32_t)(i2 - s2));
+            best = min(best, key);
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) best = min(best, (uint32_t)__shfl_xor(best, dd));
+        if (best != 0xFFFFFFFFu && lane == 0) {
+            const int t = a.idx2[s2 + (int)(0x3FFFFFu - (best & 0x3FFFFFu))];
+            a.m12[q] = t;
+            if (a.checkOri) {
+                const int bin = rot_bin(kp1.angle, a.k2[t].angle);
+                a.binOf[q] = (uint8_t)bin;
+                atomicAdd(&a.hist[bin], 1);
+            }
+        }
+    }
+}
+
 }  // namespace orbm

@@ -1325,4 +1325,189 @@ extern "C" int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
     if (nmatches) *nmatches = nm;
     return ORBX_OK;
 }
+
+// ------------------------------------------------------------------ SURVEY 8(f).1 entry points
+extern "C" int orbm_window_best(orbm_t* h, const float* q_uvr, const float* q_ur, const int8_t* q_pred,
+                                const uint8_t* qdesc, const uint8_t* qvalid, int nq,
+                                const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc,
+                                const float* t_uright, int nt, const float* inv_sigma2, int nlevels, int chi2,
+                                int32_t* best_idx, int32_t* best_dist)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (nq < 0 || nt < 0 || (nq && (!q_uvr || !q_pred || !qdesc || !best_idx || !best_dist)) || (nt && (!t_keys_un || !tdesc)))
+        return fail(ORBX_E_INVALID, "bad argument");
+    if (chi2 && (!inv_sigma2 || nlevels < 1 || nlevels > 16)) return fail(ORBX_E_INVALID, "inv_sigma2 required for the chi-square test");
+    if (chi2 && t_uright && !q_ur) return fail(ORBX_E_INVALID, "q_ur required with t_uright");
+    for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    orbm::GridDev gd;
+    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, gd))) return rc;
+    enum { S_UVR, S_UR, S_PRED, S_QD, S_QV, S_TD, S_TUR, S_SIG, S_BI, S_BD };
+    const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 4, (size_t)nq, (size_t)nq * 32, (size_t)nq, (size_t)nt * 32,
+                            (size_t)nt * 4, 64, (size_t)nq * 4, (size_t)nq * 4};
+    for (int i = 0; i < 10; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    hipStream_t s = h->stream;
+    UP(S_UVR, q_uvr, (size_t)nq * 12); UP(S_PRED, q_pred, (size_t)nq); UP(S_QD, qdesc, (size_t)nq * 32); UP(S_TD, tdesc, (size_t)nt * 32);
+    if (q_ur) UP(S_UR, q_ur, (size_t)nq * 4);
+    if (qvalid) UP(S_QV, qvalid, (size_t)nq);
+    if (t_uright) UP(S_TUR, t_uright, (size_t)nt * 4);
+    if (chi2) UP(S_SIG, inv_sigma2, (size_t)nlevels * 4);
+    orbm::WinArgs a;
+    a.grid = gd;
+    a.tkeys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
+    a.cellStart = (const int32_t*)h->d_buf[G_START]; a.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    a.quvr = (const float*)h->d_buf[S_UVR]; a.qur = q_ur ? (const float*)h->d_buf[S_UR] : nullptr;
+    a.qpred = (const int8_t*)h->d_buf[S_PRED]; a.qdesc = (const uint8_t*)h->d_buf[S_QD];
+    a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
+    a.tdesc = (const uint8_t*)h->d_buf[S_TD]; a.turight = t_uright ? (const float*)h->d_buf[S_TUR] : nullptr;
+    a.invSigma2 = (const float*)h->d_buf[S_SIG];
+    a.nq = nq; a.chi2 = chi2;
+    a.bestIdx = (int32_t*)h->d_buf[S_BI]; a.bestDist = (int32_t*)h->d_buf[S_BD];
+    hipLaunchKernelGGL(orbm::k_window_best, dim3((nq + 63) / 64), dim3(64), 0, s, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(best_idx, a.bestIdx, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(best_dist, a.bestDist, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_for_initialization(orbm_t* h, const float* q_xy, float window_size,
+                                              const OrbxKeyPoint* q_keys_un, const uint8_t* qdesc, int nq,
+                                              const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc, int nt,
+                                              float nnratio, int check_ori, int32_t* matches12, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (nq < 0 || nt < 0 || (nq && (!q_xy || !q_keys_un || !qdesc || !matches12)) || (nt && (!t_keys_un || !tdesc)))
+        return fail(ORBX_E_INVALID, "bad argument");
+    for (int i = 0; i < nq; i++) matches12[i] = -1;
+    if (nmatches) *nmatches = 0;
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    if ((size_t)nt * 2 > 150 * 1024) return fail(ORBX_E_UNSUPPORTED, "too many train features for the LDS distance table");
+    orbm::GridDev gd;
+    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, gd))) return rc;
+    // flatten: window query (x, y, windowSize), levels (0, 0), only octave-0 queries search (:424-426)
+    std::vector<float> uvr((size_t)nq * 3), ang(nq);
+    std::vector<int8_t> lvl((size_t)nq * 2, 0);
+    std::vector<uint8_t> valid(nq);
+    for (int i = 0; i < nq; i++) {
+        uvr[3 * i] = q_xy[2 * i]; uvr[3 * i + 1] = q_xy[2 * i + 1]; uvr[3 * i + 2] = window_size;
+        valid[i] = q_keys_un[i].octave <= 0;
+        ang[i] = q_keys_un[i].angle;
+    }
+    enum { S_UVR, S_LVL, S_QD, S_QA, S_QV, S_TD, S_CNT, S_OFF, S_KEY, S_CIDX, S_M12, S_M21, S_NM, S_PUSHT, S_PUSHB };
+    const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 2, (size_t)nq * 32, (size_t)nq * 4, (size_t)nq, (size_t)nt * 32,
+                            (size_t)nq * 4, (size_t)(nq + 1) * 4, 16, 16, (size_t)nq * 4, (size_t)nt * 4, 16, (size_t)nq * 4, (size_t)nq};
+    for (int i = 0; i < 15; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    hipStream_t s = h->stream;
+    UP(S_UVR, uvr.data(), (size_t)nq * 12); UP(S_LVL, lvl.data(), (size_t)nq * 2); UP(S_QD, qdesc, (size_t)nq * 32);
+    UP(S_QA, ang.data(), (size_t)nq * 4); UP(S_QV, valid.data(), (size_t)nq); UP(S_TD, tdesc, (size_t)nt * 32);
+    orbm::ProjArgs a;
+    a.grid = gd;
+    a.tkeys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
+    a.cellStart = (const int32_t*)h->d_buf[G_START]; a.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    a.quvr = (const float*)h->d_buf[S_UVR]; a.qlvl = (const int8_t*)h->d_buf[S_LVL];
+    a.qdesc = (const uint8_t*)h->d_buf[S_QD]; a.qang = (const float*)h->d_buf[S_QA];
+    a.qvalid = (const uint8_t*)h->d_buf[S_QV]; a.qobs = nullptr;
+    a.tdesc = (const uint8_t*)h->d_buf[S_TD];
+    a.nq = nq; a.nt = nt;
+    a.candCnt = (int32_t*)h->d_buf[S_CNT]; a.candOff = (int32_t*)h->d_buf[S_OFF];
+    a.candKey = nullptr; a.candIdx = nullptr;
+    a.tocc = nullptr; a.assign = nullptr; a.nmatch = (int32_t*)h->d_buf[S_NM];
+    a.pushT = (int32_t*)h->d_buf[S_PUSHT]; a.pushBin = (uint8_t*)h->d_buf[S_PUSHB];
+    a.mode = 7; a.nnratio = nnratio; a.checkOri = check_ori; a.thDist = 50;
+    hipLaunchKernelGGL(orbm::k_proj_candidates, dim3((nq + 63) / 64), dim3(64), 0, s, a, 0);
+    hipLaunchKernelGGL(orbm::k_scan_small, dim3(1), dim3(1024), 0, s, (const int32_t*)a.candCnt, nq, a.candOff);
+    HIPCHK(hipGetLastError());
+    int32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, a.candOff + nq, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = orbm_reserve(h, S_KEY, (size_t)std::max(total, 1) * 4)) || (rc = orbm_reserve(h, S_CIDX, (size_t)std::max(total, 1) * 4))) return rc;
+    a.candKey = (uint32_t*)h->d_buf[S_KEY]; a.candIdx = (int32_t*)h->d_buf[S_CIDX];
+    hipLaunchKernelGGL(orbm::k_proj_candidates, dim3((nq + 63) / 64), dim3(64), 0, s, a, 1);
+    const size_t lds = ((size_t)nt * 2 + 3) & ~(size_t)3;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)orbm::k_init_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(orbm::k_init_resolve, dim3(1), dim3(64), lds, s, a, (int32_t*)h->d_buf[S_M12], (int32_t*)h->d_buf[S_M21]);
+    HIPCHK(hipGetLastError());
+    int32_t nm = 0;
+    HIPCHK(hipMemcpyAsync(matches12, h->d_buf[S_M12], (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nm, a.nmatch, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_for_triangulation(orbm_t* h,
+                                             const OrbxKeyPoint* k1, const uint8_t* d1, const uint8_t* skip1, const float* uright1, int n1,
+                                             const OrbmFeatVec* fv1,
+                                             const OrbxKeyPoint* k2, const uint8_t* d2, const uint8_t* skip2, const float* uright2, int n2,
+                                             const OrbmFeatVec* fv2,
+                                             const float F12[9], float ex, float ey, const float* sf2, const float* sigma2_2, int nlevels,
+                                             int only_stereo, int check_ori, int32_t* matches12, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (n1 < 0 || n2 < 0 || !fv1 || !fv2 || !F12 || !sf2 || !sigma2_2 || nlevels < 1 || nlevels > 16 ||
+        (n1 && (!k1 || !d1 || !matches12)) || (n2 && (!k2 || !d2)))
+        return fail(ORBX_E_INVALID, "bad argument");
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (nmatches) *nmatches = 0;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    std::vector<int32_t> pa, pb;
+    {
+        int a = 0, b = 0;
+        while (a < fv1->n_nodes && b < fv2->n_nodes) {
+            if (fv1->node_id[a] == fv2->node_id[b]) { pa.push_back(a); pb.push_back(b); a++; b++; }
+            else if (fv1->node_id[a] < fv2->node_id[b]) a++;
+            else b++;
+        }
+    }
+    const int npairs = (int)pa.size();
+    if (npairs == 0) return ORBX_OK;
+    const int ni1 = fv1->start[fv1->n_nodes], ni2 = fv2->start[fv2->n_nodes];
+    for (int i = 0; i < ni1; i++) if (fv1->idx[i] < 0 || fv1->idx[i] >= n1) return fail(ORBX_E_INVALID, "feature index out of range");
+    for (int i = 0; i < ni2; i++) if (fv2->idx[i] < 0 || fv2->idx[i] >= n2) return fail(ORBX_E_INVALID, "feature index out of range");
+    enum { S_K1, S_D1, S_S1, S_U1, S_K2, S_D2, S_S2, S_U2, S_ST1, S_I1, S_ST2, S_I2, S_PA, S_PB, S_M12, S_BIN, S_HIST };
+    const size_t sizes[] = {(size_t)n1 * 28, (size_t)n1 * 32, (size_t)n1, (size_t)n1 * 4, (size_t)n2 * 28, (size_t)n2 * 32, (size_t)n2,
+                            (size_t)n2 * 4, (size_t)(fv1->n_nodes + 1) * 4, (size_t)std::max(ni1, 1) * 4,
+                            (size_t)(fv2->n_nodes + 1) * 4, (size_t)std::max(ni2, 1) * 4, (size_t)npairs * 4, (size_t)npairs * 4,
+                            (size_t)n1 * 4, (size_t)n1, 34 * 4};
+    for (int i = 0; i < 17; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    hipStream_t s = h->stream;
+    UP(S_K1, k1, (size_t)n1 * 28); UP(S_D1, d1, (size_t)n1 * 32); UP(S_K2, k2, (size_t)n2 * 28); UP(S_D2, d2, (size_t)n2 * 32);
+    if (skip1) UP(S_S1, skip1, (size_t)n1);
+    if (skip2) UP(S_S2, skip2, (size_t)n2);
+    if (uright1) UP(S_U1, uright1, (size_t)n1 * 4);
+    if (uright2) UP(S_U2, uright2, (size_t)n2 * 4);
+    UP(S_ST1, fv1->start, (size_t)(fv1->n_nodes + 1) * 4);
+    if (ni1) UP(S_I1, fv1->idx, (size_t)ni1 * 4);
+    UP(S_ST2, fv2->start, (size_t)(fv2->n_nodes + 1) * 4);
+    if (ni2) UP(S_I2, fv2->idx, (size_t)ni2 * 4);
+    UP(S_PA, pa.data(), (size_t)npairs * 4); UP(S_PB, pb.data(), (size_t)npairs * 4);
+    HIPCHK(hipMemsetAsync(h->d_buf[S_M12], 0xFF, (size_t)n1 * 4, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[S_HIST], 0, 34 * 4, s));
+    orbm::TriArgs a;
+    a.k1 = (const orbm::KeyDev*)h->d_buf[S_K1]; a.d1 = (const uint8_t*)h->d_buf[S_D1];
+    a.skip1 = skip1 ? (const uint8_t*)h->d_buf[S_S1] : nullptr; a.ur1 = uright1 ? (const float*)h->d_buf[S_U1] : nullptr;
+    a.k2 = (const orbm::KeyDev*)h->d_buf[S_K2]; a.d2 = (const uint8_t*)h->d_buf[S_D2];
+    a.skip2 = skip2 ? (const uint8_t*)h->d_buf[S_S2] : nullptr; a.ur2 = uright2 ? (const float*)h->d_buf[S_U2] : nullptr;
+    a.start1 = (const int32_t*)h->d_buf[S_ST1]; a.idx1 = (const int32_t*)h->d_buf[S_I1];
+    a.start2 = (const int32_t*)h->d_buf[S_ST2]; a.idx2 = (const int32_t*)h->d_buf[S_I2];
+    a.pairA = (const int32_t*)h->d_buf[S_PA]; a.pairB = (const int32_t*)h->d_buf[S_PB];
+    for (int i = 0; i < 9; i++) a.F[i] = F12[i];
+    a.ex = ex; a.ey = ey;
+    for (int i = 0; i < 16; i++) { a.sf2[i] = i < nlevels ? sf2[i] : 0.f; a.sigma2[i] = i < nlevels ? sigma2_2[i] : 0.f; }
+    a.onlyStereo = only_stereo; a.checkOri = check_ori;
+    a.m12 = (int32_t*)h->d_buf[S_M12]; a.binOf = (uint8_t*)h->d_buf[S_BIN]; a.hist = (int32_t*)h->d_buf[S_HIST];
+    hipLaunchKernelGGL(orbm::k_triangulation_pairs, dim3(npairs), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(orbm::k_prune_flat, dim3(1), dim3(256), 0, s, a.m12, n1, check_ori, (const uint8_t*)a.binOf, a.hist, a.hist + 32);
+    HIPCHK(hipGetLastError());
+    int32_t nm = 0;
+    HIPCHK(hipMemcpyAsync(matches12, a.m12, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nm, a.hist + 32, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBX_OK;
+}
 #undef UP

@@ -113,6 +113,67 @@ class ORBmatcher:
                                                 ptr(tdesc), t_keys_un.shape[0], ptr(t_occ), ptr(assign), C.byref(n)))
         return assign, t_occ, n.value
 
+    # ---- SURVEY.md 8(f) rank 1
+    def window_best(self, q_uvr, q_pred, qdesc, qvalid, grid, t_keys_un, tdesc, inv_sigma2=None, chi2=False,
+                    q_ur=None, t_uright=None):
+        """device part of Fuse (ORBmatcher.cc:827, chi2=True), Fuse(KF,Scw) (:977) and SearchBySim3 (:1104)"""
+        q_uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
+        q_pred = np.ascontiguousarray(q_pred, dtype=np.int8)
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+        qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+        t_keys_un = np.ascontiguousarray(t_keys_un, dtype=KP_DTYPE)
+        tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+        sig = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, dtype=np.float32)
+        qur = None if q_ur is None else np.ascontiguousarray(q_ur, dtype=np.float32)
+        tur = None if t_uright is None else np.ascontiguousarray(t_uright, dtype=np.float32)
+        nq = q_uvr.shape[0]
+        bi = np.full(max(nq, 1), -1, np.int32)
+        bd = np.full(max(nq, 1), 256, np.int32)
+        check(self._L.orbm_window_best(self._h, ptr(q_uvr), ptr(qur), ptr(q_pred), ptr(qdesc), ptr(qv), nq, C.byref(grid),
+                                       ptr(t_keys_un), ptr(tdesc), ptr(tur), t_keys_un.shape[0], ptr(sig),
+                                       0 if sig is None else sig.shape[0], int(bool(chi2)), ptr(bi), ptr(bd)))
+        return bi[:nq], bd[:nq]
+
+    def SearchForInitialization(self, q_xy, window_size, q_keys_un, qdesc, grid, t_keys_un, tdesc):
+        """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) -- ORBmatcher.cc:407"""
+        q_xy = np.ascontiguousarray(q_xy, dtype=np.float32)
+        q_keys_un = np.ascontiguousarray(q_keys_un, dtype=KP_DTYPE)
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+        t_keys_un = np.ascontiguousarray(t_keys_un, dtype=KP_DTYPE)
+        tdesc = np.ascontiguousarray(tdesc, dtype=np.uint8)
+        nq = q_keys_un.shape[0]
+        m12 = np.full(max(nq, 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbm_search_for_initialization(self._h, ptr(q_xy), C.c_float(window_size), ptr(q_keys_un), ptr(qdesc), nq,
+                                                     C.byref(grid), ptr(t_keys_un), ptr(tdesc), t_keys_un.shape[0],
+                                                     C.c_float(self.mfNNratio), int(self.mbCheckOrientation), ptr(m12), C.byref(n)))
+        return m12[:nq], n.value
+
+    def SearchForTriangulation(self, k1, d1, skip1, fv1, k2, d2, skip2, fv2, F12, ex, ey, sf2, sigma2_2,
+                               only_stereo=False, uright1=None, uright2=None):
+        """SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) -- ORBmatcher.cc:659"""
+        k1 = np.ascontiguousarray(k1, dtype=KP_DTYPE)
+        k2 = np.ascontiguousarray(k2, dtype=KP_DTYPE)
+        d1 = np.ascontiguousarray(d1, dtype=np.uint8)
+        d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+        s1 = None if skip1 is None else np.ascontiguousarray(skip1, dtype=np.uint8)
+        s2 = None if skip2 is None else np.ascontiguousarray(skip2, dtype=np.uint8)
+        u1 = None if uright1 is None else np.ascontiguousarray(uright1, dtype=np.float32)
+        u2 = None if uright2 is None else np.ascontiguousarray(uright2, dtype=np.float32)
+        F = np.ascontiguousarray(F12, dtype=np.float32).reshape(9)
+        sf2 = np.ascontiguousarray(sf2, dtype=np.float32)
+        sg2 = np.ascontiguousarray(sigma2_2, dtype=np.float32)
+        f1, keep1 = self._fv(*fv1)
+        f2, keep2 = self._fv(*fv2)
+        n1 = k1.shape[0]
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbm_search_for_triangulation(self._h, ptr(k1), ptr(d1), ptr(s1), ptr(u1), n1, C.byref(f1),
+                                                    ptr(k2), ptr(d2), ptr(s2), ptr(u2), k2.shape[0], C.byref(f2),
+                                                    ptr(F), C.c_float(ex), C.c_float(ey), ptr(sf2), ptr(sg2), sf2.shape[0],
+                                                    int(bool(only_stereo)), int(self.mbCheckOrientation), ptr(m12), C.byref(n)))
+        return m12[:n1], n.value
+
     def GetFeaturesInArea(self, grid, keys_un, x, y, r, minLevel=-1, maxLevel=-1):
         """Frame::GetFeaturesInArea (Frame.cc:327-380) evaluated on the device grid"""
         keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)

@@ -116,3 +116,52 @@ def make_proj_case(rng, nq, nt, w=1241.0, h=376.0):
     return dict(uvr=uvr, lvl=lvl, qd=qd, qa=qa, qv=(rng.uniform(size=nq) < 0.9).astype(np.uint8),
                 qo=(rng.uniform(size=nq) < 0.7).astype(np.uint8), gp=gp, tk=tk, start=start, idx=idx, td=td,
                 occ=(rng.uniform(size=nt) < 0.1).astype(np.uint8), w=w, h=h)
+
+
+def make_init_case(rng, n1, n2, w=640.0, h=480.0):
+    """two frames for SearchForInitialization: F2 = F1 shifted by a few pixels"""
+    from oracle import binding as ob
+    k1 = np.zeros(n1, dtype=ob.KP_DTYPE)
+    k1["x"] = rng.uniform(20, w - 20, n1).astype(np.float32)
+    k1["y"] = rng.uniform(20, h - 20, n1).astype(np.float32)
+    k1["octave"] = (rng.uniform(size=n1) < 0.4) * rng.integers(1, 8, n1)  # 60 % on octave 0
+    k1["angle"] = rng.uniform(0, 360, n1).astype(np.float32)
+    d1 = rng.integers(0, 256, size=(n1, 32), dtype=np.uint8)
+    src = rng.integers(0, n1, n2)
+    k2 = np.zeros(n2, dtype=ob.KP_DTYPE)
+    k2["x"] = np.clip(k1["x"][src] + rng.normal(0, 12, n2), 0, w - 1).astype(np.float32)
+    k2["y"] = np.clip(k1["y"][src] + rng.normal(0, 12, n2), 0, h - 1).astype(np.float32)
+    k2["octave"] = k1["octave"][src]
+    k2["angle"] = ((k1["angle"][src] + rng.normal(0, 5, n2)) % 360).astype(np.float32)
+    d2 = noisy_copies(rng, d1[src], 12)
+    gp = ob.make_grid_params(0.0, 0.0, w, h)
+    start, idx = ob.grid_build(gp, k2)
+    q_xy = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+    return dict(k1=k1, d1=d1, k2=k2, d2=d2, gp=gp, start=start, idx=idx, q_xy=q_xy, w=w, h=h)
+
+
+def make_tri_case(rng, n1, n2, nnodes, w=640.0, h=480.0):
+    """two keyframes related by a pure x-translation: F12 = [t]x, epipolar lines are image rows"""
+    from oracle import binding as ob
+    c = make_bow_case(rng, n1, n2, nnodes)
+    k1 = np.zeros(n1, dtype=ob.KP_DTYPE)
+    k2 = np.zeros(n2, dtype=ob.KP_DTYPE)
+    k1["x"] = rng.uniform(0, w, n1).astype(np.float32)
+    k1["y"] = rng.uniform(0, h, n1).astype(np.float32)
+    k1["angle"] = c["qa"]
+    k1["octave"] = rng.integers(0, 8, n1)
+    k2["x"] = rng.uniform(0, w, n2).astype(np.float32)
+    k2["y"] = rng.uniform(0, h, n2).astype(np.float32)
+    k2["angle"] = c["ta"]
+    k2["octave"] = rng.integers(0, 8, n2)
+    # true correspondences (nearest descriptor) lie near the same row: noise partly inside,
+    # partly outside the chi-square gate of the epipolar test
+    lut = np.array([bin(i).count("1") for i in range(256)], np.uint8)
+    for i in range(n1):
+        d = lut[np.bitwise_xor(c["qd"][i][None, :], c["td"])].sum(axis=1)
+        j = int(np.argmin(d))
+        if d[j] <= 50:
+            k2["y"][j] = np.float32(k1["y"][i] + rng.normal(0, 2.5))
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)  # l = (0, -1, y1): |y2 - y1| distance
+    return dict(c=c, k1=k1, k2=k2, F=F, ex=np.float32(-5000.0), ey=np.float32(h / 2), sf2=sf, sigma2=(sf * sf).astype(np.float32))

@@ -128,3 +128,59 @@ def test_projection_overwrite_semantics(gpu, oracle):
         wa, wocc, wn = oracle.search_by_projection(4, 0.9, False, 100, uvr, lvl, qd, np.zeros(3, np.float32), None,
                                                    np.array(obs, np.uint8), gp, tk, start, idx, td, occ0, a0)
         assert gn == wn == want_n and np.array_equal(ga, wa) and np.array_equal(gocc, wocc)
+
+
+@pytest.mark.parametrize("chi2", [False, True])
+def test_window_best_parity(gpu, oracle, chi2):
+    from orbslamm_amd import ORBmatcher, make_grid
+    rng = np.random.default_rng(200 + chi2)
+    m = ORBmatcher(0.8, True, device=0)
+    inv = (1.0 / (np.float32(1.2) ** np.arange(8)) ** 2).astype(np.float32)
+    for nq, nt, stereo in ((300, 900, False), (2000, 2000, False), (500, 1500, True)):
+        c = make_proj_case(rng, nq, nt)
+        g = make_grid(0.0, 0.0, c["w"], c["h"])
+        pred = np.clip(c["lvl"][:, 0] + 1, 0, 7).astype(np.int8)
+        q_ur = t_ur = None
+        if stereo:
+            t_ur = np.where(rng.uniform(size=nt) < 0.6, c["tk"]["x"] - rng.uniform(5, 40, nt), -1).astype(np.float32)
+            q_ur = (c["uvr"][:, 0] - rng.uniform(5, 40, nq)).astype(np.float32)
+        gi, gd = m.window_best(c["uvr"], pred, c["qd"], c["qv"], g, c["tk"], c["td"], inv, chi2, q_ur, t_ur)
+        wi, wd = oracle.window_best(c["uvr"], pred, c["qd"], c["qv"], c["gp"], c["tk"], c["start"], c["idx"], c["td"], inv, chi2, q_ur, t_ur)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+        assert (wi >= 0).sum() > 10
+
+
+@pytest.mark.parametrize("ratio,ori,win", [(0.9, True, 100.0), (0.9, False, 100.0), (0.6, True, 30.0)])
+def test_search_for_initialization_parity(gpu, oracle, ratio, ori, win):
+    from matcher_cases import make_init_case
+    from orbslamm_amd import ORBmatcher, make_grid
+    rng = np.random.default_rng(int(ratio * 100 + win))
+    total = 0
+    for n1, n2 in ((500, 600), (2000, 2000), (50, 1200)):
+        ic = make_init_case(rng, n1, n2)
+        g = make_grid(0.0, 0.0, ic["w"], ic["h"])
+        gm_, gn = ORBmatcher(ratio, ori, device=0).SearchForInitialization(ic["q_xy"], win, ic["k1"], ic["d1"], g, ic["k2"], ic["d2"])
+        wm, wn = oracle.search_for_initialization(ic["q_xy"], win, ic["k1"], ic["d1"], ic["gp"], ic["k2"], ic["start"], ic["idx"],
+                                                  ic["d2"], ratio, ori)
+        assert gn == wn and np.array_equal(gm_, wm)
+        total += wn
+    assert total > 20
+
+
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_for_triangulation_parity(gpu, oracle, ori):
+    from matcher_cases import make_tri_case
+    from orbslamm_amd import ORBmatcher
+    rng = np.random.default_rng(300 + ori)
+    total = 0
+    for n1, n2, nn in ((400, 450, 19), (2000, 2000, 60), (300, 300, 1)):
+        tc = make_tri_case(rng, n1, n2, nn)
+        c = tc["c"]
+        # rows of true partners made consistent so that some pairs pass the epipolar gate
+        gm_, gn = ORBmatcher(0.6, ori, device=0).SearchForTriangulation(tc["k1"], c["qd"], 1 - c["qv"], c["qfv"], tc["k2"], c["td"],
+                                                                        1 - c["tv"], c["tfv"], tc["F"], tc["ex"], tc["ey"], tc["sf2"], tc["sigma2"])
+        wm, wn = oracle.search_for_triangulation(tc["k1"], c["qd"], 1 - c["qv"], c["qfv"], tc["k2"], c["td"], 1 - c["tv"], c["tfv"],
+                                                 tc["F"], tc["ex"], tc["ey"], tc["sf2"], tc["sigma2"], False, ori)
+        assert gn == wn and np.array_equal(gm_, wm)
+        total += wn
+    assert total > 100

@@ -105,3 +105,31 @@ def test_projection_modes_smoke(oracle):
         assert n >= 0
         if mode in (5, 6):
             assert n == (assign >= 0).sum()
+
+
+def test_window_best_and_init_and_triangulation_oracle(oracle):
+    from matcher_cases import make_init_case, make_tri_case
+    rng = np.random.default_rng(17)
+    c = make_proj_case(rng, nq=200, nt=800)
+    pred = np.clip(c["lvl"][:, 0] + 1, 0, 7).astype(np.int8)
+    inv = (1.0 / (np.float32(1.2) ** np.arange(8)) ** 2).astype(np.float32)
+    for chi2 in (False, True):
+        bi, bd = oracle.window_best(c["uvr"], pred, c["qd"], c["qv"], c["gp"], c["tk"], c["start"], c["idx"], c["td"], inv, chi2)
+        ok = bi >= 0
+        assert ok.sum() > 20
+        # recompute the distance of the reported best
+        for q in np.nonzero(ok)[0][:30]:
+            assert bd[q] == oracle.descriptor_distance(c["qd"][q], c["td"][bi[q]])
+            assert c["tk"]["octave"][bi[q]] in (pred[q] - 1, pred[q])
+    ic = make_init_case(rng, 500, 600)
+    m12, n = oracle.search_for_initialization(ic["q_xy"], 100.0, ic["k1"], ic["d1"], ic["gp"], ic["k2"], ic["start"], ic["idx"],
+                                              ic["d2"], 0.9, True)
+    assert n == (m12 >= 0).sum() and n > 50
+    used = m12[m12 >= 0]
+    assert len(set(used.tolist())) == len(used)          # a stolen feature un-matches its previous owner
+    assert (ic["k1"]["octave"][m12 >= 0] == 0).all()     # only octave-0 queries search
+    tc = make_tri_case(rng, 400, 450, 19)
+    m, n = oracle.search_for_triangulation(tc["k1"], tc["c"]["qd"], 1 - tc["c"]["qv"], tc["c"]["qfv"], tc["k2"], tc["c"]["td"],
+                                           1 - tc["c"]["tv"], tc["c"]["tfv"], tc["F"], tc["ex"], tc["ey"], tc["sf2"], tc["sigma2"],
+                                           False, False)
+    assert n == (m >= 0).sum()
