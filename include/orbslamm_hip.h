@@ -263,6 +263,25 @@ int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const OrbxKeyPoint* k
                           float x, float y, float r, int minLevel, int maxLevel,
                           int32_t* out, int cap, int* n_out);
 
+/* ---------------------------------------------------------------- vocabulary
+ * replaces ORBVocabulary::transform as called by Frame::ComputeBoW (src/Frame.cc:395-402):
+ *   void TemplatedVocabulary::transform(const vector<TDescriptor>&, BowVector&, FeatureVector&, int levelsup)
+ *   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1194 (+ :1218-1259)
+ * The tree is uploaded once; nodes come in loadFromTextFile order (:1338-1425): entry i is node
+ * id i+1 (root = 0), leaves receive word ids in file order.  scoring/weighting are DBoW2's enums. */
+typedef struct orbv_handle orbv_t;
+int orbv_create(int device, int k, int L, int scoring, int weighting, int n_nodes,
+                const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc /* n x 32 */,
+                const double* weight, orbv_t** out);
+/* bool TemplatedVocabulary::loadFromTextFile(const std::string&)  (ORBvoc.txt format) */
+int orbv_load_text(int device, const char* path, orbv_t** out);
+void orbv_destroy(orbv_t* v);
+/* BowVector as (word id ascending, value); FeatureVector as CSR (node id ascending, feature
+ * indices ascending).  Capacities: n for word_id/word_value/fv_node/fv_idx, n+1 for fv_start. */
+int orbv_transform(orbv_t* v, const uint8_t* desc, int n, int levelsup,
+                   uint32_t* word_id, double* word_value, int* n_words,
+                   uint32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int* n_fv_nodes);
+
 #ifdef __cplusplus
 }
 #endif

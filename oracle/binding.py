@@ -40,7 +40,7 @@ def build(march_native=False, out_dir=None):
     """compile the oracle; returns the path of the .so"""
     out_dir = out_dir or _HERE
     so = os.path.join(out_dir, "liborb_oracle_native.so" if march_native else "liborb_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orb_extract.c", "orb_match.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb_extract.c", "orb_match.c", "orb_vocab.c")]
     deps = srcs + [os.path.join(_HERE, f) for f in ("orb_oracle.h", "brief_pattern.inc")]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps):
         return so
@@ -80,6 +80,8 @@ def lib(path=None):
         L.orc_window_best.restype = C.c_int
         L.orc_search_for_initialization.restype = C.c_int
         L.orc_search_for_triangulation.restype = C.c_int
+        L.orc_vocab_create.restype = C.c_void_p
+        L.orc_vocab_transform.restype = C.c_int
         if path is not None:
             return L
         _lib = L
@@ -338,3 +340,36 @@ def search_for_triangulation(k1, d1, skip1, fv1, k2, d2, skip2, fv2, F12, ex, ey
                                        k2.shape[0], C.byref(f2), _p(F), C.c_float(ex), C.c_float(ey), _p(sf2), _p(sg2),
                                        int(bool(only_stereo)), int(bool(check_ori)), _p(m12))
     return m12[:n1], n
+
+
+class Vocabulary:
+    """DBoW2 vocabulary on the oracle (nodes in loadFromTextFile order)"""
+
+    def __init__(self, k, Lv, scoring, weighting, parent, is_leaf, desc, weight, L=None):
+        self.L = L or lib()
+        parent = np.ascontiguousarray(parent, dtype=np.int32)
+        is_leaf = np.ascontiguousarray(is_leaf, dtype=np.uint8)
+        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        self.v = C.c_void_p(self.L.orc_vocab_create(int(k), int(Lv), int(scoring), int(weighting), parent.shape[0],
+                                                    _p(parent), _p(is_leaf), _p(desc), _p(weight)))
+        if not self.v.value:
+            raise ValueError("bad vocabulary")
+
+    def __del__(self):
+        try:
+            self.L.orc_vocab_free(self.v)
+        except Exception:
+            pass
+
+    def transform(self, desc, levelsup):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        n = desc.shape[0]
+        wid = np.zeros(max(n, 1), np.uint32)
+        ww = np.zeros(max(n, 1), np.float64)
+        fn = np.zeros(max(n, 1), np.uint32)
+        fs = np.zeros(n + 1, np.int32)
+        fi = np.zeros(max(n, 1), np.int32)
+        nw, nf = C.c_int(), C.c_int()
+        self.L.orc_vocab_transform(self.v, _p(desc), n, int(levelsup), _p(wid), _p(ww), C.byref(nw), _p(fn), _p(fs), _p(fi), C.byref(nf))
+        return (wid[:nw.value].copy(), ww[:nw.value].copy()), (fn[:nf.value].copy(), fs[:nf.value + 1].copy(), fi[:fs[nf.value]].copy())

@@ -197,6 +197,19 @@ int  orc_search_for_triangulation(const OrcKeyPoint* k1, const uint8_t* d1, cons
                                   const float* sf2, const float* sigma2_2,
                                   int only_stereo, int check_ori, int32_t* matches12);
 
+/* ---- vocabulary-tree descent (DBoW2 transform), orb_vocab.c ---- */
+typedef struct OrcVocab OrcVocab;
+/* nodes in loadFromTextFile order: line i becomes node id i+1 (root = 0); parent ids refer to
+ * that numbering; leaves get word ids in file order. */
+OrcVocab* orc_vocab_create(int k, int L, int scoring, int weighting, int n, const int32_t* parent,
+                           const uint8_t* is_leaf, const uint8_t* desc, const double* weight);
+void orc_vocab_free(OrcVocab* v);
+/* BowVector as (word_id ascending, weight), FeatureVector as CSR (node ascending, feature
+ * indices ascending).  Capacities: n entries each, fv_start n+1. */
+int  orc_vocab_transform(const OrcVocab* v, const uint8_t* desc, int n, int levelsup,
+                         uint32_t* word_id, double* word_w, int* n_words,
+                         uint32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int* n_fv);
+
 #ifdef __cplusplus
 }
 #endif

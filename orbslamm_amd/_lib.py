@@ -57,6 +57,7 @@ EXPORTS = [
     "orbx_profile_read", "orbm_create", "orbm_destroy", "orbm_distance_matrix", "orbm_match_bruteforce",
     "orbm_search_by_bow", "orbm_search_by_projection", "orbm_features_in_area", "orbm_window_best",
     "orbm_search_for_initialization", "orbm_search_for_triangulation",
+    "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_transform",
 ]
 
 

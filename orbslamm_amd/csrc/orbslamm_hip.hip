@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -20,6 +22,7 @@
 
 #include "orbx_kernels.hip"
 #include "orbm_kernels.hip"
+#include "orbv_kernels.hip"
 
 using namespace orbx;
 
@@ -1511,3 +1514,162 @@ extern "C" int orbm_search_for_triangulation(orbm_t* h,
     return ORBX_OK;
 }
 #undef UP
+
+// ------------------------------------------------------------------ vocabulary
+struct orbv_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int k = 0, L = 0, scoring = 0, weighting = 0, nNodes = 0, nWords = 0;
+    int32_t* d_childStart = nullptr; int32_t* d_childIdx = nullptr; uint8_t* d_desc = nullptr;
+    int32_t* d_wordId = nullptr; double* d_weight = nullptr;
+    void* d_buf[10] = {nullptr}; size_t d_cap[10] = {0};
+};
+
+static int orbv_reserve(orbv_handle* h, int slot, size_t bytes)
+{
+    if (bytes <= h->d_cap[slot]) return ORBX_OK;
+    if (h->d_buf[slot]) HIPCHK(hipFree(h->d_buf[slot]));
+    h->d_buf[slot] = nullptr; h->d_cap[slot] = 0;
+    const size_t want = std::max<size_t>(bytes * 3 / 2, 4096);
+    HIPCHK(hipMalloc(&h->d_buf[slot], want));
+    h->d_cap[slot] = want;
+    return ORBX_OK;
+}
+
+extern "C" void orbv_destroy(orbv_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    void* ptrs[] = {h->d_childStart, h->d_childIdx, h->d_desc, h->d_wordId, h->d_weight};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto p : h->d_buf) if (p) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int orbv_create(int device, int k, int L, int scoring, int weighting, int n,
+                           const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc,
+                           const double* weight, orbv_t** out)
+{
+    if (!out) return fail(ORBX_E_INVALID, "null argument");
+    *out = nullptr;
+    // same sanity window as loadFromTextFile (:1360)
+    if (k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3 || n < 0 ||
+        (n && (!parent || !is_leaf || !desc || !weight)))
+        return fail(ORBX_E_INVALID, "not a correct vocabulary");
+    int ndev = orbx_device_count();
+    if (ndev == 0) return fail(ORBX_E_NO_DEVICE, "no HIP device visible: the vocabulary transform has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(ORBX_E_INVALID, "device %d out of range", device);
+    const int nNodes = n + 1;
+    std::vector<int32_t> cnt(nNodes + 1, 0), childStart(nNodes + 1, 0), childIdx(std::max(n, 1)), wordId(nNodes, -1);
+    std::vector<double> w(nNodes, 0.0);
+    std::vector<uint8_t> d((size_t)nNodes * 32, 0);
+    for (int i = 0; i < n; i++) {
+        if (parent[i] < 0 || parent[i] > i) return fail(ORBX_E_INVALID, "node %d: parent %d does not precede it", i + 1, parent[i]);
+        cnt[parent[i]]++;
+    }
+    for (int i = 0; i < nNodes; i++) childStart[i + 1] = childStart[i] + cnt[i];
+    std::fill(cnt.begin(), cnt.end(), 0);
+    int nWords = 0;
+    for (int i = 0; i < n; i++) {
+        const int nid = i + 1, pid = parent[i];
+        childIdx[childStart[pid] + cnt[pid]++] = nid;     // m_nodes[pid].children.push_back(nid)
+        memcpy(&d[(size_t)nid * 32], desc + (size_t)i * 32, 32);
+        w[nid] = weight[i];
+        if (is_leaf[i]) wordId[nid] = nWords++;
+    }
+    // every inner node must have children, every childless node must be a word (else the descent of :1236-1253 derails)
+    for (int i = 1; i < nNodes; i++)
+        if ((childStart[i + 1] == childStart[i]) != (wordId[i] >= 0)) return fail(ORBX_E_INVALID, "node %d: leaf flag and children disagree", i);
+    orbv_handle* h = new orbv_handle();
+    h->device = device; h->k = k; h->L = L; h->scoring = scoring; h->weighting = weighting; h->nNodes = nNodes; h->nWords = nWords;
+#define VCRT(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int r_ = fail(ORBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); orbv_destroy(h); return r_; } } while (0)
+    VCRT(hipSetDevice(device));
+    VCRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    VCRT(hipMalloc(&h->d_childStart, (size_t)(nNodes + 1) * 4));
+    VCRT(hipMalloc(&h->d_childIdx, (size_t)std::max(n, 1) * 4));
+    VCRT(hipMalloc(&h->d_desc, (size_t)nNodes * 32));
+    VCRT(hipMalloc(&h->d_wordId, (size_t)nNodes * 4));
+    VCRT(hipMalloc(&h->d_weight, (size_t)nNodes * 8));
+    VCRT(hipMemcpy(h->d_childStart, childStart.data(), (size_t)(nNodes + 1) * 4, hipMemcpyHostToDevice));
+    VCRT(hipMemcpy(h->d_childIdx, childIdx.data(), (size_t)std::max(n, 1) * 4, hipMemcpyHostToDevice));
+    VCRT(hipMemcpy(h->d_desc, d.data(), (size_t)nNodes * 32, hipMemcpyHostToDevice));
+    VCRT(hipMemcpy(h->d_wordId, wordId.data(), (size_t)nNodes * 4, hipMemcpyHostToDevice));
+    VCRT(hipMemcpy(h->d_weight, w.data(), (size_t)nNodes * 8, hipMemcpyHostToDevice));
+#undef VCRT
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" int orbv_load_text(int device, const char* path, orbv_t** out)
+{
+    if (!path || !out) return fail(ORBX_E_INVALID, "null argument");
+    std::ifstream f(path);
+    if (!f.is_open()) return fail(ORBX_E_INVALID, "cannot open %s", path);
+    std::string s;
+    std::getline(f, s);
+    std::stringstream ss(s);
+    int k = -1, L = -1, n1 = -1, n2 = -1;
+    ss >> k >> L >> n1 >> n2;
+    if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3)
+        return fail(ORBX_E_INVALID, "Vocabulary loading failure: This is not a correct text file!");
+    std::vector<int32_t> parent; std::vector<uint8_t> leaf, desc; std::vector<double> weight;
+    while (std::getline(f, s)) {
+        if (s.find_first_not_of(" \t\r\n") == std::string::npos) continue;  // the reference trips over a trailing newline
+        std::stringstream sn(s);
+        int pid = -1, isLeaf = 0;
+        sn >> pid >> isLeaf;
+        parent.push_back(pid); leaf.push_back(isLeaf > 0);
+        for (int i = 0; i < 32; i++) { int b = 0; sn >> b; desc.push_back((uint8_t)b); }  // FORB::fromString
+        double w = 0; sn >> w; weight.push_back(w);
+        if (sn.fail()) return fail(ORBX_E_INVALID, "malformed vocabulary line %zu", parent.size() + 1);
+    }
+    return orbv_create(device, k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), out);
+}
+
+extern "C" int orbv_transform(orbv_t* h, const uint8_t* desc, int n, int levelsup,
+                              uint32_t* word_id, double* word_value, int* n_words,
+                              uint32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int* n_fv_nodes)
+{
+    if (!h) return fail(ORBX_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (n < 0 || (n && (!desc || !word_id || !word_value || !fv_node || !fv_idx)) || !fv_start || !n_words || !n_fv_nodes)
+        return fail(ORBX_E_INVALID, "bad argument");
+    *n_words = 0; *n_fv_nodes = 0; fv_start[0] = 0;
+    if (h->nWords == 0 || n == 0) return ORBX_OK;  // empty(): v and fv stay cleared (:1133-1136)
+    if (n > 8192) return fail(ORBX_E_UNSUPPORTED, "more than 8192 descriptors per transform");
+    int P = 1;
+    while (P < n) P <<= 1;
+    enum { S_DESC, S_WORD, S_NODE, S_W, S_OW, S_OV, S_FN, S_FS, S_FI, S_CNT };
+    const size_t sizes[] = {(size_t)n * 32, (size_t)n * 4, (size_t)n * 4, (size_t)n * 8, (size_t)n * 4, (size_t)n * 8,
+                            (size_t)n * 4, (size_t)(n + 1) * 4, (size_t)n * 4, 16};
+    int rc;
+    for (int i = 0; i < 10; i++) if ((rc = orbv_reserve(h, i, sizes[i]))) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_buf[S_DESC], desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    orbv::VocDev v{h->d_childStart, h->d_childIdx, h->d_desc, h->d_wordId, h->d_weight, h->L, h->scoring, h->weighting};
+    hipLaunchKernelGGL(orbv::k_voc_descend, dim3((n + 63) / 64), dim3(64), 0, s, v, (const uint8_t*)h->d_buf[S_DESC], n, levelsup,
+                       (uint32_t*)h->d_buf[S_WORD], (uint32_t*)h->d_buf[S_NODE], (double*)h->d_buf[S_W]);
+    const size_t lds = (size_t)P * 12;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)orbv::k_voc_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(orbv::k_voc_aggregate, dim3(1), dim3(orbv::kAggThreads), lds, s, v, n, P, (const uint32_t*)h->d_buf[S_WORD],
+                       (const uint32_t*)h->d_buf[S_NODE], (const double*)h->d_buf[S_W], (uint32_t*)h->d_buf[S_OW],
+                       (double*)h->d_buf[S_OV], (uint32_t*)h->d_buf[S_FN], (int32_t*)h->d_buf[S_FS], (int32_t*)h->d_buf[S_FI],
+                       (int32_t*)h->d_buf[S_CNT]);
+    HIPCHK(hipGetLastError());
+    int32_t counts[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(counts, h->d_buf[S_CNT], 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_words = counts[0]; *n_fv_nodes = counts[1];
+    if (counts[0]) {
+        HIPCHK(hipMemcpy(word_id, h->d_buf[S_OW], (size_t)counts[0] * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(word_value, h->d_buf[S_OV], (size_t)counts[0] * 8, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemcpy(fv_start, h->d_buf[S_FS], (size_t)(counts[1] + 1) * 4, hipMemcpyDeviceToHost));
+    if (counts[1]) {
+        HIPCHK(hipMemcpy(fv_node, h->d_buf[S_FN], (size_t)counts[1] * 4, hipMemcpyDeviceToHost));
+        const int m = fv_start[counts[1]];
+        if (m) HIPCHK(hipMemcpy(fv_idx, h->d_buf[S_FI], (size_t)m * 4, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}

@@ -1,0 +1,180 @@
+// orbv_kernels.hip -- vocabulary-tree descent (DBoW2 transform) on gfx950, SURVEY.md 8(f) rank 2.
+//
+// Reference: /root/reference/SingleRobotScenario/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h
+//   transform(feature, word_id, weight, nid, levelsup) :1218-1259  -> k_voc_descend
+//   transform(features, BowVector, FeatureVector, levelsup) :1127-1194 -> k_voc_aggregate
+// called per frame by Frame::ComputeBoW (src/Frame.cc:395-402, levelsup = 4).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace orbv {
+
+struct VocDev {
+    const int32_t* childStart;  // n_nodes + 1
+    const int32_t* childIdx;    // children in push_back order
+    const uint8_t* desc;        // n_nodes x 32
+    const int32_t* wordId;      // -1 for inner nodes
+    const double* weight;
+    int32_t L, scoring, weighting;
+};
+
+__device__ __forceinline__ int ham256(const uint32_t q[8], const uint32_t* __restrict__ t)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d += __popc(q[i] ^ t[i]);
+    return d;
+}
+
+// one thread per feature: L sequential k-way Hamming argmins, first child wins ties
+__global__ void k_voc_descend(VocDev v, const uint8_t* __restrict__ desc, int n, int levelsup,
+                              uint32_t* __restrict__ word, uint32_t* __restrict__ node, double* __restrict__ w)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[8];
+    const uint32_t* qp = (const uint32_t*)(desc + (int64_t)i * 32);
+#pragma unroll
+    for (int k = 0; k < 8; k++) q[k] = qp[k];
+    const int nidLevel = v.L - levelsup;
+    uint32_t nid = 0;
+    int finalId = 0, level = 0;
+    do {
+        ++level;
+        const int cs = v.childStart[finalId], ce = v.childStart[finalId + 1];
+        finalId = v.childIdx[cs];
+        int best = ham256(q, (const uint32_t*)(v.desc + (int64_t)finalId * 32));
+        for (int c = cs + 1; c < ce; c++) {
+            const int id = v.childIdx[c];
+            const int d = ham256(q, (const uint32_t*)(v.desc + (int64_t)id * 32));
+            if (d < best) { best = d; finalId = id; }
+        }
+        if (level == nidLevel) nid = (uint32_t)finalId;
+    } while (v.childStart[finalId + 1] > v.childStart[finalId]);
+    word[i] = (uint32_t)v.wordId[finalId];
+    node[i] = nid;
+    w[i] = v.weight[finalId];
+}
+
+constexpr int kAggThreads = 1024;
+
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int P)
+{
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += kAggThreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = a[i], y = a[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// block-wide exclusive scan of flags over the sorted keys (boundary = new key value)
+__device__ __forceinline__ int boundaries_scan(const uint64_t* a, int m, uint32_t* pos, int* wsum)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (m + kAggThreads - 1) / kAggThreads;
+    const int b = min(tid * per, m), e = min(b + per, m);
+    int s = 0;
+    for (int i = b; i < e; i++) s += (i == 0 || (a[i] >> 32) != (a[i - 1] >> 32)) ? 1 : 0;
+    int incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int k = 0; k < kAggThreads / 64; k++) { if (k < wave) woff += wsum[k]; tot += wsum[k]; }
+    int run = woff + incl - s;
+    for (int i = b; i < e; i++) {
+        const bool nb = (i == 0 || (a[i] >> 32) != (a[i - 1] >> 32));
+        if (nb) run++;
+        pos[i] = (uint32_t)(run - 1);  // group index of entry i
+    }
+    __syncthreads();
+    return tot;
+}
+
+// BowVector + FeatureVector of one descriptor set.  P = power of two >= n, LDS: P*8 + P*4 bytes.
+__global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, int P,
+                                                              const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
+                                                              const double* __restrict__ w,
+                                                              uint32_t* __restrict__ outWord, double* __restrict__ outW,
+                                                              uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
+                                                              int32_t* __restrict__ fvIdx, int32_t* __restrict__ counts)
+{
+    extern __shared__ uint64_t alds[];
+    uint64_t* keys = alds;
+    uint32_t* pos = (uint32_t*)(alds + P);
+    __shared__ int wsum[kAggThreads / 64];
+    __shared__ int sM;
+    const int tid = threadIdx.x;
+    const bool tf = v.weighting == 0 || v.weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
+    const bool must = v.scoring != 5;                       // DotProductScoring does not normalise
+    const bool l2 = v.scoring == 1;
+
+    // ---- BowVector: sort (word, feature) of the features with w > 0 ("not stopped", :1156)
+    for (int i = tid; i < P; i += kAggThreads)
+        keys[i] = (i < n && w[i] > 0) ? (((uint64_t)word[i] << 32) | (uint32_t)i) : ~0ull;
+    if (tid == 0) sM = 0;
+    __syncthreads();
+    {
+        int c = 0;
+        for (int i = tid; i < n; i += kAggThreads) c += w[i] > 0 ? 1 : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+        if ((tid & 63) == 0) atomicAdd(&sM, c);
+    }
+    bitonic_sort_lds(keys, P);
+    const int m = sM;
+    const int nw = boundaries_scan(keys, m, pos, wsum);
+    for (int i = tid; i < m; i += kAggThreads) {
+        if (i == 0 || pos[i] != pos[i - 1]) {
+            int cnt = 1;
+            while (i + cnt < m && pos[i + cnt] == pos[i]) cnt++;
+            const double wi = w[(uint32_t)keys[i]];
+            double acc = wi;                     // addWeight: += in feature order (BowVector.cpp:34-46)
+            if (tf) for (int k = 1; k < cnt; k++) acc += wi;
+            outWord[pos[i]] = (uint32_t)(keys[i] >> 32);
+            outW[pos[i]] = acc;
+        }
+    }
+    __syncthreads();
+    if (tf && nw > 0 && !must) {
+        const double nd = (double)nw;
+        for (int i = tid; i < nw; i += kAggThreads) outW[i] /= nd;
+        __syncthreads();
+    }
+    if (must) {  // BowVector::normalize: the sum runs in map (word id) order, sequentially
+        __shared__ double sNorm;
+        if (tid == 0) {
+            double norm = 0.0;
+            if (!l2) { for (int i = 0; i < nw; i++) norm += fabs(outW[i]); }
+            else { for (int i = 0; i < nw; i++) norm += outW[i] * outW[i]; norm = sqrt(norm); }
+            sNorm = norm;
+        }
+        __syncthreads();
+        const double norm = sNorm;
+        if (norm > 0.0) for (int i = tid; i < nw; i += kAggThreads) outW[i] /= norm;
+    }
+    __syncthreads();
+
+    // ---- FeatureVector: sort (node, feature); addFeature appends in feature order (:1159)
+    for (int i = tid; i < P; i += kAggThreads)
+        keys[i] = (i < n && w[i] > 0) ? (((uint64_t)node[i] << 32) | (uint32_t)i) : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(keys, P);
+    const int nf = boundaries_scan(keys, m, pos, wsum);
+    for (int i = tid; i < m; i += kAggThreads) {
+        fvIdx[i] = (int32_t)(uint32_t)keys[i];
+        if (i == 0 || pos[i] != pos[i - 1]) { fvNode[pos[i]] = (uint32_t)(keys[i] >> 32); fvStart[pos[i]] = i; }
+    }
+    if (tid == 0) { fvStart[nf] = m; counts[0] = nw; counts[1] = nf; }
+}
+
+}  // namespace orbv

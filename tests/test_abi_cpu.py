@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     src = open(os.path.join(ROOT, "include", "orbslamm_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(orb[xm]_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(orb[xmv]_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():

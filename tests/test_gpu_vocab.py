@@ -1,0 +1,56 @@
+"""GPU parity of ORBVocabulary::transform (through the C ABI) against the oracle."""
+import numpy as np
+import pytest
+
+from vocab_cases import make_vocab, write_text
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scoring,weighting", [(0, 0), (1, 1), (5, 0), (0, 2), (5, 3), (3, 0)])
+def test_transform_parity(gpu, oracle, scoring, weighting):
+    from orbslamm_amd import ORBVocabulary
+    rng = np.random.default_rng(60 + scoring * 4 + weighting)
+    for k, L, n in ((10, 3, 2000), (6, 4, 333), (3, 6, 1), (10, 4, 4097)):
+        voc = make_vocab(rng, k, L)
+        G = ORBVocabulary(k, L, scoring, weighting, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], device=0)
+        O = oracle.Vocabulary(k, L, scoring, weighting, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+        desc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        for levelsup in (4, 0, L + 2):
+            (gi, gv), (gn, gs, gx) = G.transform(desc, levelsup)
+            (oi, ov), (on, os_, ox) = O.transform(desc, levelsup)
+            assert np.array_equal(gi, oi)
+            assert gv.tobytes() == ov.tobytes()   # double values bit-for-bit
+            assert np.array_equal(gn, on) and np.array_equal(gs, os_) and np.array_equal(gx, ox)
+        assert len(oi) > 0
+
+
+def test_text_loader_and_bow_search(gpu, oracle, tmp_path):
+    """ORBvoc.txt-format file -> transform -> FeatureVector drives SearchByBoW"""
+    from orbslamm_amd import ORBmatcher, ORBVocabulary
+    from matcher_cases import noisy_copies
+    rng = np.random.default_rng(77)
+    voc = make_vocab(rng, 10, 3, ragged=False)
+    path = tmp_path / "voc.txt"
+    write_text(path, voc, 0, 0)
+    G = ORBVocabulary.loadFromTextFile(path)
+    O = oracle.Vocabulary(10, 3, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    base = rng.integers(0, 256, size=(800, 32), dtype=np.uint8)
+    d1, d2 = noisy_copies(rng, base, 6), noisy_copies(rng, base, 6)[rng.permutation(800)]
+    (w1, v1), fv1 = G.transform(d1, 2)
+    (w2, v2), fv2 = G.transform(d2, 2)
+    (ow1, ov1), ofv1 = O.transform(d1, 2)
+    assert np.array_equal(w1, ow1) and v1.tobytes() == ov1.tobytes() and all(np.array_equal(a, b) for a, b in zip(fv1, ofv1))
+    ang = np.zeros(800, np.float32)
+    m = ORBmatcher(0.8, False, device=0)
+    got, n = m.SearchByBoW(d1, ang, None, fv1, d2, ang, None, fv2, True)
+    want, nw = oracle.search_by_bow(d1, ang, None, fv1, d2, ang, None, fv2, 0.8, False, True)
+    assert n == nw and np.array_equal(got, want) and n > 300
+
+
+def test_bad_vocabulary_is_rejected(gpu):
+    from orbslamm_amd import ORBVocabulary, OrbError
+    with pytest.raises(OrbError):
+        ORBVocabulary(10, 3, 0, 0, np.array([5], np.int32), np.array([1], np.uint8), np.zeros((1, 32), np.uint8), np.ones(1), device=0)
+    with pytest.raises(OrbError):
+        ORBVocabulary(99, 3, 0, 0, np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 32), np.uint8), np.zeros(0), device=0)
