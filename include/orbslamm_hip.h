@@ -258,6 +258,12 @@ int orbm_search_for_triangulation(orbm_t* h,
                                   const float F12[9], float ex, float ey, const float* sf2, const float* sigma2_2, int nlevels,
                                   int only_stereo, int check_ori, int32_t* matches12, int* nmatches);
 
+/* void MapPoint::ComputeDistinctiveDescriptors()   src/MapPoint.cc:242-307, batched over map points.
+ * desc = the observations' descriptors of all points back to back, start[npoints+1] = CSR.
+ * best_idx[p] = index (inside point p's list) of the descriptor with the least median distance
+ * to the others, -1 for a point without observations. */
+int orbm_distinctive_descriptors(orbm_t* h, const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx);
+
 /* GetFeaturesInArea on the device grid, for tests: out[cap] indices in reference order */
 int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const OrbxKeyPoint* keys_un, int n,
                           float x, float y, float r, int minLevel, int maxLevel,

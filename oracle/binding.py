@@ -373,3 +373,12 @@ class Vocabulary:
         nw, nf = C.c_int(), C.c_int()
         self.L.orc_vocab_transform(self.v, _p(desc), n, int(levelsup), _p(wid), _p(ww), C.byref(nw), _p(fn), _p(fs), _p(fi), C.byref(nf))
         return (wid[:nw.value].copy(), ww[:nw.value].copy()), (fn[:nf.value].copy(), fs[:nf.value + 1].copy(), fi[:fs[nf.value]].copy())
+
+
+def distinctive_descriptors(desc, start, L=None):
+    L = L or lib()
+    desc = np.ascontiguousarray(desc, dtype=np.uint8)
+    start = np.ascontiguousarray(start, dtype=np.int32)
+    out = np.full(max(len(start) - 1, 1), -1, np.int32)
+    L.orc_distinctive_descriptors(_p(desc), _p(start), len(start) - 1, _p(out))
+    return out[:len(start) - 1]

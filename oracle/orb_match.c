@@ -449,3 +449,29 @@ int orc_search_for_triangulation(const OrcKeyPoint* k1, const uint8_t* d1, const
     rh_free(&rh);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------ SURVEY 8(f).4
+ * MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched over map points:
+ * all-pairs distances, per row the element [0.5*(N-1)] of the sorted row, least median wins
+ * (strict <, first index).  desc = concatenated observation descriptors, start = CSR. */
+static int cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+int orc_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx)
+{
+    for (int p = 0; p < npoints; p++) {
+        const int N = start[p + 1] - start[p];
+        best_idx[p] = -1;
+        if (N <= 0) continue;
+        const uint8_t* D = desc + 32 * (size_t)start[p];
+        int* row = (int*)malloc(sizeof(int) * (size_t)N);
+        int bestMedian = 0x7FFFFFFF, bestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            for (int j = 0; j < N; j++) row[j] = i == j ? 0 : orc_descriptor_distance(D + 32 * (size_t)i, D + 32 * (size_t)j);
+            qsort(row, (size_t)N, sizeof(int), cmp_int);
+            const int median = row[(int)(0.5 * (N - 1))];
+            if (median < bestMedian) { bestMedian = median; bestIdx = i; }
+        }
+        free(row);
+        best_idx[p] = bestIdx;
+    }
+    return 0;
+}

@@ -197,6 +197,9 @@ int  orc_search_for_triangulation(const OrcKeyPoint* k1, const uint8_t* d1, cons
                                   const float* sf2, const float* sigma2_2,
                                   int only_stereo, int check_ori, int32_t* matches12);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched */
+int  orc_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx);
+
 /* ---- vocabulary-tree descent (DBoW2 transform), orb_vocab.c ---- */
 typedef struct OrcVocab OrcVocab;
 /* nodes in loadFromTextFile order: line i becomes node id i+1 (root = 0); parent ids refer to

@@ -752,4 +752,40 @@ __global__ __launch_bounds__(64) void k_triangulation_pairs(TriArgs a)
     }
 }
 
+// ------------------------------------------------------------------ SURVEY 8(f).4
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), one wave per map point.
+// Row i's "median" is element k = (int)(0.5*(N-1)) of the sorted row = the value whose stable
+// rank is k; the row with the least median wins (strict <, first index).
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ start,
+                                                   int32_t* __restrict__ bestIdx)
+{
+    extern __shared__ int32_t rowd[];  // N distances of the current row
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int s0 = start[p], N = start[p + 1] - s0;
+    if (N <= 0) { if (lane == 0) bestIdx[p] = -1; return; }
+    const uint8_t* D = desc + (int64_t)s0 * 32;
+    const int k = (int)(0.5 * (N - 1));
+    int bestMedian = 0x7FFFFFFF, best = 0;
+    for (int i = 0; i < N; i++) {
+        uint32_t qw[8];
+        const uint32_t* qp = (const uint32_t*)(D + (int64_t)i * 32);
+#pragma unroll
+        for (int t = 0; t < 8; t++) qw[t] = qp[t];
+        for (int j = lane; j < N; j += 64) rowd[j] = i == j ? 0 : hamming256(qw, (const uint32_t*)(D + (int64_t)j * 32));
+        __syncthreads();
+        int median = -1;
+        for (int j = lane; j < N; j += 64) {
+            const int v = rowd[j];
+            int rank = 0;
+            for (int t = 0; t < N; t++) { const int u = rowd[t]; rank += (u < v || (u == v && t < j)) ? 1 : 0; }
+            if (rank == k) median = v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) median = max(median, __shfl_xor(median, d));
+        if (median < bestMedian) { bestMedian = median; best = i; }
+        __syncthreads();
+    }
+    if (lane == 0) bestIdx[p] = best;
+}
+
 }  // namespace orbm

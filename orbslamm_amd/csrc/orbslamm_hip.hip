@@ -1515,6 +1515,35 @@ extern "C" int orbm_search_for_triangulation(orbm_t* h,
 }
 #undef UP
 
+extern "C" int orbm_distinctive_descriptors(orbm_t* h, const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (npoints < 0 || !start || (npoints && !best_idx)) return fail(ORBX_E_INVALID, "bad argument");
+    if (npoints == 0) return ORBX_OK;
+    const int total = start[npoints];
+    int maxN = 0;
+    for (int p = 0; p < npoints; p++) {
+        if (start[p + 1] < start[p]) return fail(ORBX_E_INVALID, "start must be non-decreasing");
+        maxN = std::max(maxN, start[p + 1] - start[p]);
+    }
+    if (total && !desc) return fail(ORBX_E_INVALID, "null descriptors");
+    if ((size_t)maxN * 4 > 150 * 1024) return fail(ORBX_E_UNSUPPORTED, "more than 38400 observations of one map point");
+    if ((rc = orbm_reserve(h, 0, (size_t)std::max(total, 1) * 32)) || (rc = orbm_reserve(h, 1, (size_t)(npoints + 1) * 4)) ||
+        (rc = orbm_reserve(h, 2, (size_t)npoints * 4))) return rc;
+    hipStream_t s = h->stream;
+    if (total) HIPCHK(hipMemcpyAsync(h->d_buf[0], desc, (size_t)total * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->d_buf[1], start, (size_t)(npoints + 1) * 4, hipMemcpyHostToDevice, s));
+    const size_t lds = (size_t)std::max(maxN, 1) * 4;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)orbm::k_distinctive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(orbm::k_distinctive, dim3(npoints), dim3(64), lds, s, (const uint8_t*)h->d_buf[0], (const int32_t*)h->d_buf[1],
+                       (int32_t*)h->d_buf[2]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(best_idx, h->d_buf[2], (size_t)npoints * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
 // ------------------------------------------------------------------ vocabulary
 struct orbv_handle {
     int device = 0;

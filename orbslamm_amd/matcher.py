@@ -174,6 +174,16 @@ class ORBmatcher:
                                                     int(bool(only_stereo)), int(self.mbCheckOrientation), ptr(m12), C.byref(n)))
         return m12[:n1], n.value
 
+    def ComputeDistinctiveDescriptors(self, desc, start):
+        """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242), batched: desc = all observations'
+        descriptors back to back, start = CSR offsets per map point; returns the winning index per point"""
+        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        npts = start.shape[0] - 1
+        out = np.full(max(npts, 1), -1, np.int32)
+        check(self._L.orbm_distinctive_descriptors(self._h, ptr(desc), ptr(start), npts, ptr(out)))
+        return out[:npts]
+
     def GetFeaturesInArea(self, grid, keys_un, x, y, r, minLevel=-1, maxLevel=-1):
         """Frame::GetFeaturesInArea (Frame.cc:327-380) evaluated on the device grid"""
         keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)

@@ -184,3 +184,16 @@ def test_search_for_triangulation_parity(gpu, oracle, ori):
         assert gn == wn and np.array_equal(gm_, wm)
         total += wn
     assert total > 100
+
+
+def test_distinctive_descriptors_parity(gm, oracle):
+    rng = np.random.default_rng(401)
+    sizes = [0, 1, 2, 3, 7, 64, 65, 130] + rng.integers(1, 40, 300).tolist()
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = random_descriptors(rng, len(sizes))
+    desc = np.concatenate([noisy_copies(rng, np.repeat(base[i:i + 1], s, axis=0), 20) if s else np.zeros((0, 32), np.uint8)
+                           for i, s in enumerate(sizes)])
+    got = gm.ComputeDistinctiveDescriptors(desc, start)
+    want = oracle.distinctive_descriptors(desc, start)
+    assert np.array_equal(got, want)
+    assert got[0] == -1 and got[1] == 0
