@@ -132,6 +132,7 @@ struct orbx_handle {
     KpBlocks kpBlocks;
     int kpBlocksTotal = 0;
     int pyrBlocks = 0, pyrBufA = 0, pyrBufB = 0, pyrTabCap = 0;
+    bool pyrFused = true;
     PyrRange* d_pyrRanges = nullptr; size_t pyrRangesCap = 0;
 
     hipStream_t stream = nullptr;
@@ -154,6 +155,7 @@ struct orbx_handle {
     uint8_t* d_blur = nullptr; size_t blurCapFrame = 0;
     uint64_t* d_candRaw = nullptr; uint64_t* d_candA = nullptr; uint64_t* d_candB = nullptr; size_t candCapFrame = 0;
     int32_t* d_candCount = nullptr;
+    uint32_t* d_distScratch = nullptr; size_t distScratchBytes = 0; bool distInLds = true;
     int32_t* d_cellCount = nullptr;      // [maxB][cellsCap] survivors per FAST cell
     uint64_t* d_kept = nullptr; size_t keptCapFrame = 0;
     int32_t* d_keptCount = nullptr;
@@ -230,6 +232,7 @@ struct HostGeom {
     int kbTotal;
     std::vector<PyrRange> pyrRanges;   // [block][level]
     int pyrBlocks, pyrBufA, pyrBufB, pyrTabCap;
+    bool pyrFused;
 };
 
 static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
@@ -381,11 +384,14 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     out.kbTotal = kb;
 
     // fused pyramid: every block owns the same fractional rectangle of each level;
-    // the computed range of level l = owned range + what level l+1's computed range reads
-    {
+    // the computed range of level l = owned range + what level l+1's computed range reads.
+    // The block grid is refined until the LDS tiles fit; if the halo chain cannot fit at all
+    // (scale factors near 2, huge frames) the per-level kernel is used instead.
+    out.pyrFused = false;
+    for (int refine = 0; refine < 4 && !out.pyrFused; refine++) {
         const int nl = g.nlevels;
         const int top = nl - 1;
-        int BX = 8, BY = 4;
+        int BX = 8 << refine, BY = 4 << refine;
         while (BX > 1 && g.lv[top].w / BX < 8) BX >>= 1;
         while (BY > 1 && g.lv[top].h / BY < 8) BY >>= 1;
         out.pyrBlocks = BX * BY;
@@ -434,6 +440,8 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
                 }
             }
         out.pyrBufA = maxA; out.pyrBufB = maxB; out.pyrTabCap = (tabCap + 3) & ~3;
+        const size_t pl = ((size_t)maxA + maxB) * 4 + (size_t)out.pyrTabCap * 16;
+        out.pyrFused = pl <= 64 * 1024 || (refine == 3 && pl <= 156 * 1024);
     }
     return ORBX_OK;
 }
@@ -454,7 +462,7 @@ static void free_device(orbx_handle* h)
     }
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     h->prof.destroy();
-    void* ptrs[] = {h->d_pyrRanges, h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
+    void* ptrs[] = {h->d_distScratch, h->d_pyrRanges, h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
                     h->d_candCount, h->d_cellCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
                     h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -619,21 +627,37 @@ static int configure_shape(orbx_handle* h, int w, int hh)
         (size_t)hg.g.blurFrameBytes > h->blurCapFrame || (size_t)hg.g.candFrameRecs > h->candCapFrame ||
         (size_t)hg.g.keptFrameRecs > h->keptCapFrame || hg.g.maxKp > h->maxKp)
         return fail(ORBX_E_INVALID, "frame %dx%d needs more scratch than the handle was created with", w, hh);
-    if (dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel) > 156 * 1024)
-        return fail(ORBX_E_UNSUPPORTED, "nfeatures too large for the LDS-resident quadtree (%d nodes)", hg.nodeCap);
-    if (dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel) > 48 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)k_distribute, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel)));
+    h->distInLds = dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel) <= 156 * 1024;
+    if (h->distInLds) {
+        if (dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel) > 48 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void*)k_distribute<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel)));
+    } else {
+        // per-level target too large for LDS: node list in a global scratch region per (frame, level)
+        const size_t need = dist_lds_bytes(hg.nodeCap, hg.g.maxCellsPerLevel) * (size_t)h->maxB * hg.g.nlevels;
+        if (need > h->distScratchBytes) {
+            if ((rc = sync_all(h))) return rc;
+            if (h->d_distScratch) HIPCHK(hipFree(h->d_distScratch));
+            h->d_distScratch = nullptr; h->distScratchBytes = 0;
+            HIPCHK(hipMalloc(&h->d_distScratch, need));
+            h->distScratchBytes = need;
+        }
+    }
     hg.g.maxKp = h->maxKp;  // output slots keep their create-time pitch
     if ((rc = sync_all(h))) return rc;
     HIPCHK(hipMemcpy(h->d_geom, &hg.g, sizeof(Geom), hipMemcpyHostToDevice));
     if (!hg.cells.empty()) HIPCHK(hipMemcpy(h->d_cells, hg.cells.data(), hg.cells.size() * sizeof(Cell), hipMemcpyHostToDevice));
     if (!hg.tabs.empty()) HIPCHK(hipMemcpy(h->d_tabs, hg.tabs.data(), hg.tabs.size() * sizeof(short4), hipMemcpyHostToDevice));
-    if (hg.pyrRanges.size() > h->pyrRangesCap) return fail(ORBX_E_INVALID, "pyramid range table overflow");
-    HIPCHK(hipMemcpy(h->d_pyrRanges, hg.pyrRanges.data(), hg.pyrRanges.size() * sizeof(PyrRange), hipMemcpyHostToDevice));
-    h->pyrBlocks = hg.pyrBlocks; h->pyrBufA = hg.pyrBufA; h->pyrBufB = hg.pyrBufB; h->pyrTabCap = hg.pyrTabCap;
-    {
+    h->pyrFused = hg.pyrFused;
+    if (hg.pyrFused) {
+        if (hg.pyrRanges.size() > h->pyrRangesCap) {
+            if (h->d_pyrRanges) HIPCHK(hipFree(h->d_pyrRanges));
+            h->d_pyrRanges = nullptr; h->pyrRangesCap = 0;
+            HIPCHK(hipMalloc(&h->d_pyrRanges, hg.pyrRanges.size() * sizeof(PyrRange)));
+            h->pyrRangesCap = hg.pyrRanges.size();
+        }
+        HIPCHK(hipMemcpy(h->d_pyrRanges, hg.pyrRanges.data(), hg.pyrRanges.size() * sizeof(PyrRange), hipMemcpyHostToDevice));
+        h->pyrBlocks = hg.pyrBlocks; h->pyrBufA = hg.pyrBufA; h->pyrBufB = hg.pyrBufB; h->pyrTabCap = hg.pyrTabCap;
         const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
-        if (pl > 156 * 1024) return fail(ORBX_E_UNSUPPORTED, "frame too large for the LDS-tiled pyramid");
         if (pl > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl));
     }
     for (int l = 0; l < ORBX_MAXL; l++) {
@@ -687,12 +711,19 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         hipStream_t s2 = h->serial ? s : h->streamB[part];
         if (part > 0) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
         src.f0 = f0;
-        if (g.nlevels > 1) {
+        if (g.nlevels > 1 && h->pyrFused) {
             const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
             h->prof.begin(P_RESIZE, s);
             hipLaunchKernelGGL(k_pyramid, dim3(h->pyrBlocks, nb), dim3(256), pl, s, h->d_geom, src, h->tabs,
                                (const PyrRange*)h->d_pyrRanges, h->pyrBufA, h->pyrBufB, h->pyrTabCap);
             h->prof.end(s);
+        } else {
+            for (int l = 1; l < g.nlevels; l++) {
+                h->prof.begin(P_RESIZE, s);
+                hipLaunchKernelGGL(k_resize_level, dim3((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nb), dim3(64, 4, 1), 0, s,
+                                   h->d_geom, src, h->tabs, l);
+                h->prof.end(s);
+            }
         }
         // blur only needs the pyramid: run it on a second stream beside FAST + quadtree
         HIPCHK(hipEventRecord(h->evPyr[part], s));
@@ -709,9 +740,17 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
             h->prof.end(s);
         }
         h->prof.begin(P_DISTRIBUTE, s);
-        hipLaunchKernelGGL(k_distribute, dim3(g.nlevels, nb), dim3(kDistThreads), dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel), s, h->d_geom,
-                           h->d_candRaw, h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept,
-                           h->d_keptCount, h->d_err, h->nodeCap, f0);
+        {
+            const size_t dl = dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel);
+            if (h->distInLds)
+                hipLaunchKernelGGL(k_distribute<true>, dim3(g.nlevels, nb), dim3(kDistThreads), dl, s, h->d_geom, h->d_candRaw,
+                                   h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept, h->d_keptCount,
+                                   h->d_err, h->nodeCap, f0, (uint32_t*)nullptr, 0);
+            else
+                hipLaunchKernelGGL(k_distribute<false>, dim3(g.nlevels, nb), dim3(kDistThreads), 0, s, h->d_geom, h->d_candRaw,
+                                   h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept, h->d_keptCount,
+                                   h->d_err, h->nodeCap, f0, h->d_distScratch + (size_t)f0 * g.nlevels * (dl / 4), (int)(dl / 4));
+        }
         h->prof.end(s);
         HIPCHK(hipStreamWaitEvent(s, h->evBlur[part], 0));
         // the output slots are still being read by the previous batch's matching on stream3

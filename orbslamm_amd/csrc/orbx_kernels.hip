@@ -46,6 +46,41 @@ struct ResizeTabs {
     const short4* ytab[ORBX_MAXL];
 };
 
+// One level from the previous one in HBM.  Fallback for shapes/scale factors whose halo chain
+// does not fit the LDS-tiled fused kernel below (very large frames, scale factors near 2).
+__global__ __launch_bounds__(256) void k_resize_level(const Geom* __restrict__ g, FrameSrc src, ResizeTabs tabs, int level)
+{
+    const int lw = g->lv[level].w, lh = g->lv[level].h, dstStride = g->lv[level].stride;
+    const int f = blockIdx.z + src.f0;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= lw || dy >= lh) return;
+    int sstride;
+    const uint8_t* S = level_ptr(g, src, f, level - 1, sstride);
+    uint8_t* D = src.pyr + (int64_t)f * g->pyrFrameBytes + g->lv[level].pyrOff + (int64_t)dy * dstStride;
+    const short4 yt = tabs.ytab[level][dy];
+    const uint8_t* S0 = S + (int64_t)yt.x * sstride;
+    const uint8_t* S1 = S + (int64_t)yt.y * sstride;
+    const int b0 = yt.z, b1 = yt.w;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const short4 xt = tabs.xtab[level][min(x4 + i, lw - 1)];
+        const int sx = (uint16_t)xt.x;
+        int r0, r1;
+        if (xt.w) {
+            r0 = S0[sx] * xt.y + S0[sx + 1] * xt.z;
+            r1 = S1[sx] * xt.y + S1[sx + 1] * xt.z;
+        } else {
+            r0 = S0[sx] * 2048;
+            r1 = S1[sx] * 2048;
+        }
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 0xFF) << (8 * i);
+    }
+    *(uint32_t*)(D + x4) = packed;  // rows are 64-byte aligned and padded
+}
+
 // ------------------------------------------------------------------ fused pyramid
 // All 7 resizes in ONE launch.  A block owns the same fractional rectangle of every
 // level; per level it computes the pixels it owns plus the small halo the next level
@@ -450,6 +485,9 @@ __device__ __forceinline__ void wave_divide(const uint64_t* __restrict__ srcb, u
     c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
 }
 
+// LDS = true: node list and scratch live in LDS (every shipped configuration);
+// LDS = false: same code over a per-block global scratch region, for very large per-level targets.
+template <bool LDS>
 __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restrict__ g,
                                                             const uint64_t* __restrict__ candRaw,
                                                             uint64_t* __restrict__ candA, uint64_t* __restrict__ candB,
@@ -457,9 +495,11 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                                                             const int32_t* __restrict__ cellCount,
                                                             int32_t* __restrict__ candCount,
                                                             uint64_t* __restrict__ kept, int32_t* __restrict__ keptCount,
-                                                            int32_t* __restrict__ errFlag, int cap, int f0)
+                                                            int32_t* __restrict__ errFlag, int cap, int f0,
+                                                            uint32_t* __restrict__ gscratch, int scratchWords)
 {
-    extern __shared__ uint32_t smem[];
+    extern __shared__ uint32_t smem_lds[];
+    uint32_t* const smem = LDS ? smem_lds : gscratch + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * scratchWords;
     const int l = blockIdx.x, f = blockIdx.y + f0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kDistThreads / 64;

@@ -30,7 +30,7 @@ def assert_same(ref, kps, desc):
 
 
 @pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (1241, 376, 2000), (320, 240, 500), (401, 263, 700),
-                                    (752, 480, 1200), (1241, 376, 4000), (480, 640, 800)])
+                                    (752, 480, 1200), (1241, 376, 4000), (480, 640, 800), (1920, 1080, 3000)])
 def test_extract_bit_exact(gpu, oracle, w, h, nf):
     fr = frames_for(w, h, 2, stream=w % 7)
     gex = gpu_extractor(nf, w, h, B=2)
@@ -41,7 +41,9 @@ def test_extract_bit_exact(gpu, oracle, w, h, nf):
 
 
 @pytest.mark.parametrize("sf,nl,ini,mn,nf", [(1.5, 5, 20, 7, 600), (1.1, 12, 30, 10, 1500), (1.2, 8, 12, 12, 900),
-                                             (1.2, 1, 20, 7, 300), (1.3, 6, 40, 5, 50)])
+                                             (1.2, 1, 20, 7, 300), (1.3, 6, 40, 5, 50),
+                                             (1.2, 1, 20, 7, 2700), (1.2, 2, 15, 5, 6000),   # quadtree node list outside LDS
+                                             (1.9, 7, 20, 7, 800)])   # halo chain too long for the fused pyramid: per-level kernel
 def test_extract_other_parameters(gpu, oracle, sf, nl, ini, mn, nf):
     w, h = 640, 480
     fr = frames_for(w, h, 1, stream=9)
@@ -211,3 +213,66 @@ def test_properties_full_size(gpu):
     kept = m[:len(k)]
     assert nm == (kept >= 0).sum() and nm > 0.8 * len(k)
     assert (kept[kept >= 0] == np.nonzero(kept >= 0)[0]).all()
+
+
+def test_fuzz_parameters_and_shapes(gpu, oracle):
+    """random ORBextractor parameters x frame shapes (incl. tiny top levels) against the oracle"""
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 16:
+        w, h = int(rng.integers(120, 900)), int(rng.integers(120, 700))
+        if (w - 32) / max(h - 32, 1) < 0.5 or w * h > 500000:
+            continue
+        nf = int(rng.integers(50, 3000))
+        sf = float(np.float32(rng.uniform(1.1, 1.9)))
+        nl = int(rng.integers(1, 11))
+        ini, mn = int(rng.integers(8, 60)), int(rng.integers(2, 25))
+        # the quadtree root count must be >= 1 on every level that has cells (else UNSUPPORTED)
+        try:
+            gex = gpu_extractor(nf, w, h, 1, sf, nl, ini, mn)
+        except Exception as e:
+            assert getattr(e, "code", 0) == -5
+            continue
+        img = frames_for(w, h, 1, stream=done + 20)[0]
+        if done % 4 == 3:  # low-contrast variant exercises the minThFAST retry
+            img = (img // 8 + 100).astype(np.uint8)
+        try:
+            ref = oracle.Extractor(nf, sf, nl, ini, mn)(img)
+        except RuntimeError:
+            continue
+        k, d = gex(img)
+        assert_same(ref, k, d)
+        done += 1
+
+
+def test_two_handles_on_two_threads(gpu, oracle):
+    """distinct handles are fully concurrent (stereo L/R threads, one tracker per robot)"""
+    import threading
+    w, h = 640, 480
+    frames = [frames_for(w, h, 6, stream=s) for s in (11, 12)]
+    out = [None, None]
+
+    def work(i):
+        gex = gpu_extractor(1000, w, h, 1)
+        out[i] = [gex(frames[i][t]) for t in range(6)]
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    for i in range(2):
+        for t in range(6):
+            assert_same(oex(frames[i][t]), *out[i][t])
+
+
+def test_errors_do_not_poison_the_handle(gpu, oracle):
+    from orbslamm_amd import OrbError
+    gex = gpu_extractor(500, 320, 240, 2)
+    img = frames_for(320, 240, 1)[0]
+    with pytest.raises(OrbError):
+        gex(frames_for(640, 480, 1)[0])          # larger than the handle's maximum
+    with pytest.raises(OrbError):
+        gex.extract_batch(np.stack([img] * 3))   # batch larger than max_batch
+    with pytest.raises(OrbError):
+        gex.download(5)                          # frame outside the last batch
+    assert_same(oracle.Extractor(500, 1.2, 8, 20, 7)(img), *gex(img))  # still works, still exact
