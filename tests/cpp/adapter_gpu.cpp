@@ -1,0 +1,68 @@
+// GPU run of the two C++ adapters against the C oracle (linked in as the checker):
+// extractor (flat operator()) + ORBmatcher::SearchByBoW / SearchForInitialization.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "ORBextractor_hip.hpp"
+#include "ORBmatcher_hip.hpp"
+#include "../../oracle/orb_oracle.h"
+
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+
+int main()
+{
+    const int W = 640, H = 480;
+    std::mt19937 rng(7);
+    std::vector<uint8_t> img((size_t)W * H);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) img[(size_t)y * W + x] = (uint8_t)((((x / 13) ^ (y / 11)) * 37 + (rng() & 7)) & 0xFF);
+    iORB_SLAM::ORBextractor ex(1000, 1.2f, 8, 20, 7, W, H, 0);
+    std::vector<OrbxKeyPoint> kps; std::vector<uint8_t> desc;
+    ex(img.data(), W, H, W, kps, desc);
+    OrcExtractor oex;
+    orc_extractor_init(&oex, 1000, 1.2f, 8, 20, 7);
+    std::vector<OrcKeyPoint> okps(2000); std::vector<uint8_t> odesc(2000 * 32);
+    const int on = orc_extract(&oex, img.data(), W, H, W, okps.data(), odesc.data(), 2000, nullptr, nullptr, nullptr);
+    EXPECT(on > 100 && (size_t)on == kps.size());
+    EXPECT(std::memcmp(okps.data(), kps.data(), (size_t)on * 28) == 0);
+    EXPECT(std::memcmp(odesc.data(), desc.data(), (size_t)on * 32) == 0);
+
+    // SearchByBoW on a std::map-shaped FeatureVector
+    const int n = (int)kps.size();
+    std::map<unsigned, std::vector<unsigned> > fvq, fvt;
+    std::vector<uint8_t> d2 = desc;
+    for (int i = 0; i < n; i++) { for (int b = 0; b < 6; b++) d2[(size_t)i * 32 + (rng() % 32)] ^= (uint8_t)(1u << (rng() % 8)); }
+    for (int i = 0; i < n; i++) { fvq[(unsigned)(i % 17) * 3].push_back(i); fvt[(unsigned)(i % 17) * 3].push_back(n - 1 - i < 0 ? 0 : i); }
+    std::vector<float> ang(n);
+    for (int i = 0; i < n; i++) ang[i] = kps[i].angle;
+    iORB_SLAM::FlatFeatVec fq = iORB_SLAM::FlatFeatVec::from(fvq), ft = iORB_SLAM::FlatFeatVec::from(fvt);
+    iORB_SLAM::ORBmatcher m(0.75f, true, 0);
+    std::vector<int32_t> match;
+    const int nm = m.SearchByBoW(desc.data(), ang.data(), nullptr, n, fq, d2.data(), ang.data(), nullptr, n, ft, true, match);
+    std::vector<int32_t> omatch(n);
+    OrcFeatVec oq = {fq.view().n_nodes, fq.node_id.data(), fq.start.data(), fq.idx.data()};
+    OrcFeatVec ot = {ft.view().n_nodes, ft.node_id.data(), ft.start.data(), ft.idx.data()};
+    const int onm = orc_search_by_bow(desc.data(), ang.data(), nullptr, n, &oq, d2.data(), ang.data(), nullptr, n, &ot, 0.75f, 1, 1, omatch.data());
+    EXPECT(nm == onm && nm > 100);
+    EXPECT(std::memcmp(match.data(), omatch.data(), (size_t)n * 4) == 0);
+    EXPECT(m.DescriptorDistance(desc.data(), d2.data()) == orc_descriptor_distance(desc.data(), d2.data()));
+
+    // SearchForInitialization against the same frame shifted in descriptor space
+    OrbmGrid g = {0.f, 0.f, 64.f / 640.f, 48.f / 480.f, 64, 48};
+    OrcGridParams og = {0.f, 0.f, 64.f / 640.f, 48.f / 480.f, 64, 48};
+    std::vector<float> xy((size_t)n * 2);
+    for (int i = 0; i < n; i++) { xy[2 * i] = kps[i].x; xy[2 * i + 1] = kps[i].y; }
+    std::vector<int> m12;
+    const int ni = m.SearchForInitialization(xy.data(), 100, kps.data(), desc.data(), n, g, kps.data(), d2.data(), n, m12);
+    std::vector<int32_t> cs(64 * 48 + 1), ci(n), om12(n);
+    orc_grid_build(&og, (const OrcKeyPoint*)kps.data(), n, cs.data(), ci.data());
+    const int oni = orc_search_for_initialization(xy.data(), 100.f, (const OrcKeyPoint*)kps.data(), desc.data(), n, &og,
+                                                  (const OrcKeyPoint*)kps.data(), cs.data(), ci.data(), d2.data(), n, 0.75f, 1, om12.data());
+    EXPECT(ni == oni && ni > 50);
+    EXPECT(std::memcmp(m12.data(), om12.data(), (size_t)n * 4) == 0);
+    std::printf(fails ? "adapter_gpu: %d failures\n" : "adapter_gpu ok (%d keypoints, %d BoW matches, %d init matches)\n", fails ? fails : on, nm, ni);
+    return fails ? 1 : 0;
+}

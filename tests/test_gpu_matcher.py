@@ -197,3 +197,22 @@ def test_distinctive_descriptors_parity(gm, oracle):
     want = oracle.distinctive_descriptors(desc, start)
     assert np.array_equal(got, want)
     assert got[0] == -1 and got[1] == 0
+
+
+def test_cpp_adapters_on_gpu(gpu, tmp_path):
+    """the C++ ORBextractor / ORBmatcher adapters (include/*.hpp) driven from a C++ program,
+    checked bit-for-bit against the C oracle linked into the test binary"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from oracle import binding as ob
+    ob.build()
+    exe = str(tmp_path / "adapter_gpu")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "adapter_gpu.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "orbslamm_amd"), "-lorbslamm_hip", "-L", os.path.join(root, "oracle"), "-lorb_oracle",
+                           "-Wl,-rpath," + os.path.join(root, "orbslamm_amd"), "-Wl,-rpath," + os.path.join(root, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapter_gpu ok" in out.stdout
