@@ -223,6 +223,19 @@ static int fast_corner_score(const uint8_t* p, const int* off, int threshold)
     return -b0 - 1;
 }
 
+/* corner predicate only (before score / non-max suppression), for the independent
+ * scikit-image fixture tests/golden/fast_detect_skimage.npz */
+void orc_fast_corner_mask(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* mask)
+{
+    int off[25];
+    for (int k = 0; k < 16; k++) off[k] = k_circle[k][0] + k_circle[k][1] * stride;
+    for (int k = 16; k < 25; k++) off[k] = off[k - 16];
+    memset(mask, 0, (size_t)w * h);
+    for (int y = 3; y < h - 3; y++)
+        for (int x = 3; x < w - 3; x++)
+            mask[(size_t)y * w + x] = (uint8_t)fast_is_corner(img + (size_t)y * stride + x, off, threshold);
+}
+
 int orc_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold,
                  OrcCorner* out, int cap)
 {

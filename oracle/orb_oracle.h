@@ -14,7 +14,8 @@
  * 2.4.3); its published generic C++ algorithm is restated here.
  * The reference holds no tests / golden vectors for this path, and
  * the reference cannot be built here without writing stand-ins for OpenCV, so
- * there is no oracle/_ref.  What IS pinned: the BRIEF pattern (sha256), the umax
+ * there is no oracle/_ref.  What IS pinned: the FAST-9 corner predicate (fixture from
+ * scikit-image's independent implementation), the BRIEF pattern (sha256), the umax
  * table, the per-level feature split, the matcher arithmetic (fully visible in
  * the reference source) -- see tests/test_oracle_*.py.
  *
@@ -78,6 +79,7 @@ void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
                           uint8_t* dst, int dw, int dh, int dstride);
 int  orc_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold,
                   OrcCorner* out, int cap);
+void orc_fast_corner_mask(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* mask);
 void orc_gaussian7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
 float orc_fast_atan2(float y, float x);
 float orc_ic_angle(const uint8_t* img, int stride, int x, int y, const int* umax);

@@ -187,3 +187,33 @@ def test_extract_counts_and_ranges(oracle):
     # level-0 keypoints stay >= 19 px inside (EDGE_THRESHOLD)
     k0 = kps[kps["octave"] == 0]
     assert k0["x"].min() >= 19 and k0["x"].max() <= 640 - 20 and k0["y"].min() >= 19 and k0["y"].max() <= 480 - 20
+
+
+def test_fast_predicate_against_scikit_image_fixture(oracle):
+    """FAST-9 segment test vs an independent published implementation (skimage.feature.corner_fast,
+    fixture + generating script under tests/golden/).  Pins the corner predicate; OpenCV's score,
+    NMS and border rules stay unpinned."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fast_detect_skimage.npz"))
+    img = np.ascontiguousarray(g["image"])
+    h, w = img.shape
+    L = oracle.lib()
+    for t in (20, 7):
+        mask = np.zeros((h, w), np.uint8)
+        L.orc_fast_corner_mask(img.ctypes.data_as(__import__("ctypes").c_void_p), w, h, w, t,
+                               mask.ctypes.data_as(__import__("ctypes").c_void_p))
+        want = g["corners_t%d" % t]
+        assert want.sum() > 300
+        assert np.array_equal(mask, want), "t=%d: %d pixels differ" % (t, int((mask != want).sum()))
+        # and the NMS survivors of cv::FAST are a subset of the predicate
+        kept = oracle.fast(img, t)
+        assert all(want[k["y"], k["x"]] for k in kept) and 0 < len(kept) < want.sum()
+
+
+def test_brief_pattern_equals_scikit_image_copy():
+    """second published copy of the ORB test pattern (present in the build container only)"""
+    path = "/opt/conda/lib/python3.9/site-packages/skimage/feature/orb_descriptor_positions.txt"
+    if not os.path.exists(path):
+        pytest.skip("scikit-image copy not present on this box")
+    theirs = np.loadtxt(path).astype(np.int64).reshape(-1)
+    ours = np.array(_read_pattern(os.path.join(ROOT, "oracle", "brief_pattern.inc")))
+    assert np.array_equal(theirs, ours)
