@@ -982,7 +982,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     // steered BRIEF on the blurred level: lane j owns tests j, j+64, j+128, j+192
     constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    double sn, cs;
+    sincos((double)ang, &sn, &cs);  // one argument reduction for both (same values as sin()/cos())
+    const float a = (float)cs, b = (float)sn;
     const int bs = L.blurStride;
     const uint8_t* bc = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)cy * bs + cx;
     int t0[4], t1[4];

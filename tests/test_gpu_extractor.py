@@ -86,7 +86,7 @@ def test_stage_parity(gpu, oracle):
 
 
 def test_golden_fixtures(gpu):
-    for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))):
+    for path in sorted(glob.glob(os.path.join(HERE, "golden", "*x*_*.npz"))):
         g = np.load(path)
         w, h, nf, nl, ini, mn, stream = [int(v) for v in g["params"]]
         fr = frames_for(w, h, 2, stream=stream)
