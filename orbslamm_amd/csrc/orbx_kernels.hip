@@ -199,45 +199,38 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
 // runs on all pixels and COMPACTS the survivors (about a quarter of a busy image) into
 // an LDS list; the exact 16-arc score, the 3x3 non-max suppression and the emission
 // then run on the dense list, so no lane idles through the heavy part.
-// Packed 16-bit formulation: lane register j holds (d[j], d[j+8]); the windowed minima
-// and maxima of the 16-ring are built with v_pk_min/max_i16 on 8 registers instead of 16
-// (half swaps fold into op_sel).
-typedef short pk16 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pk16 pk_swap(pk16 a) { return __builtin_shufflevector(a, a, 1, 0); }
-__device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+// Window-9 minima/maxima of the 16-ring with three-input min/max: m3[k] = min3(d[k..k+2]),
+// m9[k] = min3(m3[k], m3[k+3], m3[k+6]) -- 32 v_min3 + 32 v_max3 for all 16 arcs (full-rate
+// VOP3; packed i16 min/max issue at half rate on gfx950, tools/ubench/valu_rate.hip).
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
 __device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p, const int* off)
 {
-    const short v = (short)p[0];
-    const pk16 vv = {v, v};
-    pk16 X[16];
+    const int v = p[0];
+    int d[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const pk16 pr = {(short)p[off[k]], (short)p[off[k + 8]]};
-        X[k] = vv - pr;            // (d[k], d[k+8])
-        X[k + 8] = pk_swap(X[k]);  // (d[k+8], d[k])
+    for (int k = 0; k < 16; k++) d[k] = v - p[off[k]];
+    int mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        mx3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
     }
-    pk16 mn2[10], mx2[10];
+    int mn9[16], mx9[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { mn2[k] = pk_min(X[k], X[k + 1]); mx2[k] = pk_max(X[k], X[k + 1]); }
-    mn2[8] = pk_swap(mn2[0]); mn2[9] = pk_swap(mn2[1]);
-    mx2[8] = pk_swap(mx2[0]); mx2[9] = pk_swap(mx2[1]);
-    pk16 mn4[12], mx4[12];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { mn4[k] = pk_min(mn2[k], mn2[k + 2]); mx4[k] = pk_max(mx2[k], mx2[k + 2]); }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { mn4[8 + k] = pk_swap(mn4[k]); mx4[8 + k] = pk_swap(mx4[k]); }
-    pk16 A = {-256, -256}, Bn = {256, 256};
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const pk16 mn9 = pk_min(pk_min(mn4[k], mn4[k + 4]), X[k + 8]);
-        const pk16 mx9 = pk_max(pk_max(mx4[k], mx4[k + 4]), X[k + 8]);
-        A = pk_max(A, mn9);
-        Bn = pk_min(Bn, mx9);
+    for (int k = 0; k < 16; k++) {
+        mn9[k] = min3i(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+        mx9[k] = max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
     }
-    const int a = max((int)A.x, (int)A.y), bn = min((int)Bn.x, (int)Bn.y);
-    const int S = max(a, -bn);
+    // A = max_k mn9[k], Bn = min_k mx9[k] as three-input trees
+    int a5[6], b5[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { a5[k] = max3i(mn9[3 * k], mn9[3 * k + 1], mn9[3 * k + 2]); b5[k] = min3i(mx9[3 * k], mx9[3 * k + 1], mx9[3 * k + 2]); }
+    a5[5] = mn9[15]; b5[5] = mx9[15];
+    const int A = max(max3i(a5[0], a5[1], a5[2]), max3i(a5[3], a5[4], a5[5]));
+    const int Bn = min(min3i(b5[0], b5[1], b5[2]), min3i(b5[3], b5[4], b5[5]));
+    const int S = max(A, -Bn);
     return S < 0 ? 0 : S;
 }
 
@@ -314,9 +307,12 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             bool pass = false;
             if (x < dw && y < dh) {
                 const uint8_t* p = tb + pos0 + y * tsb + x;
+                // max(|v-p0|,|v-p8|) = max(v - min(p0,p8), max(p0,p8) - v); both pairs must exceed tq
                 const int v = p[0];
-                const int d0 = v - p[off[0]], d8 = v - p[off[8]], d4 = v - p[off[4]], d12 = v - p[off[12]];
-                pass = !(abs(d0) <= tq && abs(d8) <= tq) && !(abs(d4) <= tq && abs(d12) <= tq);
+                const int p0 = p[off[0]], p8 = p[off[8]], p4 = p[off[4]], p12 = p[off[12]];
+                const int e0 = max(v - min(p0, p8), max(p0, p8) - v);
+                const int e4 = max(v - min(p4, p12), max(p4, p12) - v);
+                pass = min(e0, e4) > tq;
             }
             const uint64_t bal = __ballot(pass);
             if (pass) {
