@@ -633,36 +633,50 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
             for (int e = tid; e < E; e += kDistThreads) ord[e] = ord2[e];
             __syncthreads();
         }
-        // divide every E node (tentatively in careful mode) into the other buffer
-        for (int t = wave; t < E; t += NW) {
-            const uint32_t i = ord[t];
-            const short4 b = nb[cur][i];
-            const uint32_t cb = nc[cur][i];
-            const uint32_t cnt = cb & 0x7FFFFFFFu, bid = cb >> 31;
-            const int xm = b.x + ((b.y - b.x + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  :483
-            const int ym = b.z + ((b.w - b.z + 1) >> 1);  // UL.y + ceil((BR.y-UL.y)/2)  :484
-            uint32_t c[4];
-            wave_divide(bufs[bid], bufs[bid ^ 1], ns[cur][i], cnt, xm, ym, c);
-            if (lane == 0) { cc[4 * t] = c[0]; cc[4 * t + 1] = c[1]; cc[4 * t + 2] = c[2]; cc[4 * t + 3] = c[3]; }
-        }
-        __syncthreads();
-        // k_t = non-empty children; prefix over processing order
-        for (int t = tid; t < E; t += kDistThreads) {
-            const uint32_t k = (cc[4 * t] ? 1 : 0) + (cc[4 * t + 1] ? 1 : 0) + (cc[4 * t + 2] ? 1 : 0) + (cc[4 * t + 3] ? 1 : 0);
-            tA[t] = k;
-            tB[t] = k;
-        }
+        // Divide the E nodes into the other buffer.  Main mode divides all of them.  The careful
+        // phase stops at the first node after which the list holds N nodes (:727-728): a split
+        // adds at most 3 nodes, so nodes are divided in sorted order in chunks of
+        // ceil(deficit / 3) until the cut is found -- typically a quarter of E, not all of it.
         if (tid == 0) sJ = E - 1;
-        __syncthreads();
-        block_excl_scan(tB, E, wtmp);  // tB[t] = sum_{u<t} k_u
-        if (careful) {
-            // stop as soon as the list holds N nodes (:727-728)
-            for (int t = tid; t < E; t += kDistThreads) {
+        int done = 0;
+        while (done < E) {
+            int chunk = E - done;
+            if (careful) {
+                int grown = 0;  // growth of the prefix [0, done): recomputed from tA (uniform)
+                if (done > 0) grown = (int)(tB[done - 1] + tA[done - 1]) - done;
+                const int deficit = N - (m + grown);
+                chunk = min(chunk, max(NW, (deficit + 2) / 3));
+            }
+            for (int t = done + wave; t < done + chunk; t += NW) {
+                const uint32_t i = ord[t];
+                const short4 b = nb[cur][i];
+                const uint32_t cb = nc[cur][i];
+                const uint32_t cnt = cb & 0x7FFFFFFFu, bid = cb >> 31;
+                const int xm = b.x + ((b.y - b.x + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  :483
+                const int ym = b.z + ((b.w - b.z + 1) >> 1);  // UL.y + ceil((BR.y-UL.y)/2)  :484
+                uint32_t c[4];
+                wave_divide(bufs[bid], bufs[bid ^ 1], ns[cur][i], cnt, xm, ym, c);
+                if (lane == 0) { cc[4 * t] = c[0]; cc[4 * t + 1] = c[1]; cc[4 * t + 2] = c[2]; cc[4 * t + 3] = c[3]; }
+            }
+            __syncthreads();
+            done += chunk;
+            // k_t = non-empty children; prefix over processing order for everything divided so far
+            for (int t = tid; t < done; t += kDistThreads) {
+                const uint32_t k = (cc[4 * t] ? 1 : 0) + (cc[4 * t + 1] ? 1 : 0) + (cc[4 * t + 2] ? 1 : 0) + (cc[4 * t + 3] ? 1 : 0);
+                tA[t] = k;
+                tB[t] = k;
+            }
+            __syncthreads();
+            block_excl_scan(tB, done, wtmp);  // tB[t] = sum_{u<t} k_u
+            if (!careful) break;
+            for (int t = tid; t < done; t += kDistThreads) {
                 const int sizeAfter = m + (int)(tB[t] + tA[t]) - (t + 1);
                 if (sizeAfter >= N) atomicMin(&sJ, t);
             }
             __syncthreads();
+            if (sJ < E - 1 || (sJ == E - 1 && done == E)) break;  // cut found (or everything divided)
         }
+        __syncthreads();
         const int J = sJ;
         const uint32_t K = tB[J] + tA[J];  // children of processed nodes
         // survivors: old nodes not processed keep their relative order behind the new ones
