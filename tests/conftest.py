@@ -21,10 +21,8 @@ def _gpu_count():
         return 0
 
 
-def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must FAIL loudly (no silent skip, no CPU fallback);
-    # without -m gpu, gpu tests are deselected by the marker expression the driver passes.
-    pass
+# `-m gpu` on a box without a GPU FAILS loudly (the `gpu` fixture asserts a device: no silent
+# skip, no CPU fallback); without -m gpu the marker expression deselects those tests.
 
 
 @pytest.fixture(scope="session")

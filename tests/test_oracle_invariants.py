@@ -114,11 +114,10 @@ def test_resize_constant_and_shape(oracle):
 
 def test_descriptor_constant_image_is_zero(oracle):
     # strict "<" on equal samples -> every bit 0
-    ex = oracle.Extractor(500, 1.2, 8, 20, 7)
+    import ctypes as C
     L = oracle.lib()
     img = np.full((64, 64), 9, np.uint8)
     desc = np.full(32, 0xAA, np.uint8)
-    import ctypes as C
     L.orc_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
     L.orc_brief(img.ctypes.data, 64, 32, 32, 33.0, desc.ctypes.data)
     assert (desc == 0).all()
