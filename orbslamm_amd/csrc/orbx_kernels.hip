@@ -962,27 +962,31 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     const uint8_t* img = level_ptr(g, src, f, l, stride);
     const uint8_t* center = img + (int64_t)cy * stride + cx;
 
-    // IC_Angle: integer moments over the radius-15 disc of the raw level.  Two patch rows per
-    // step over the 64 lanes; all 16 loads are issued before the first use (clamped address
-    // for masked lanes) so the wave pays one memory round trip, not sixteen.
+    // IC_Angle: integer moments over the radius-15 disc of the raw level.  The 31 x 32 patch is
+    // read as 248 (row, dword) items, 4 per lane, all loads in flight at once; the dwords are
+    // unaligned (gfx950 global loads allow it), each covers u0..u0+3 of one row.
     int m10 = 0, m01 = 0;
     {
-        const int half = lane >> 5, u = (lane & 31) - kHalfPatch;
-        int val[16];
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        uint32_t dw[4];
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = -kHalfPatch + 2 * it + half;
-            const int av = v < 0 ? -v : v;
-            const bool ok = av <= kHalfPatch && (lane & 31) <= 30 && abs(u) <= sumax[av & 15];
-            const uint8_t* ptr = ok ? center + v * stride + u : center;  // unconditional load, safe address
-            const int x = *ptr;
-            val[it] = ok ? x : 0;
+        for (int it = 0; it < 4; it++) {
+            const int item = lane + 64 * it;
+            const int r = item < 248 ? (item >> 3) : 15, c = item & 7;
+            dw[it] = ((const U32*)(center + (r - kHalfPatch) * stride + (4 * c - 16)))->v;
         }
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = -kHalfPatch + 2 * it + half;
-            m10 += u * val[it];
-            m01 += v * val[it];
+        for (int it = 0; it < 4; it++) {
+            const int item = lane + 64 * it;
+            const int v = (item >> 3) - kHalfPatch, u0 = 4 * (item & 7) - 16;
+            const int d = item < 248 ? sumax[(v < 0 ? -v : v) & 15] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int u = u0 + j;
+                const int val = (u >= -d && u <= d) ? (int)((dw[it] >> (8 * j)) & 0xFF) : 0;
+                m10 += u * val;
+                m01 += v * val;
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
