@@ -276,3 +276,32 @@ def test_errors_do_not_poison_the_handle(gpu, oracle):
     with pytest.raises(OrbError):
         gex.download(5)                          # frame outside the last batch
     assert_same(oracle.Extractor(500, 1.2, 8, 20, 7)(img), *gex(img))  # still works, still exact
+
+
+def test_soak_256_frames_bit_exact(gpu, oracle):
+    """4 streams x 64 consecutive frames at the benchmark shape through the device-resident
+    batch path: every keypoint record, descriptor byte and match index against the oracle
+    (about half a million keypoints, i.e. a million double-precision sin/cos evaluations)"""
+    w, h, nf, B = 1241, 376, 2000, 64
+    gex = gpu_extractor(nf, w, h, B=B)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    total_kp = total_m = 0
+    for stream in range(4):
+        fr = frames_for(w, h, B, stream=30 + stream)
+        gex.reset_stream()
+        gex.extract_batch_device(*gex.upload_frames(fr, stride=1280))
+        gex.match_prev_batch_device(0.7, 50, True)
+        prev = None
+        for f in range(B):
+            k, d = gex.download(f)
+            ref = oex(fr[f])
+            assert ref["kps"].tobytes() == k.tobytes(), "stream %d frame %d keypoints" % (stream, f)
+            assert np.array_equal(ref["desc"], d), "stream %d frame %d descriptors" % (stream, f)
+            m, nm = gex.download_matches(f)
+            if prev is not None:
+                mr, nr = oracle.match_bruteforce(d, k["angle"], prev[1], prev[0]["angle"], 0.7, 50, True)
+                assert nm == nr and np.array_equal(m[:len(k)], mr), "stream %d frame %d matches" % (stream, f)
+                total_m += nr
+            prev = (k, d)
+            total_kp += len(k)
+    assert total_kp > 500000 and total_m > 200000
