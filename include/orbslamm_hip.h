@@ -258,6 +258,11 @@ int orbm_search_for_triangulation(orbm_t* h,
                                   const float F12[9], float ex, float ey, const float* sf2, const float* sigma2_2, int nlevels,
                                   int only_stereo, int check_ori, int32_t* matches12, int* nmatches);
 
+/* void Frame::UndistortKeyPoints()   src/Frame.cc:404-434  (cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK)).
+ * K = fx, fy, cx, cy; D = k1, k2, p1, p2, k3.  D[0] == 0: plain copy (:406-410).  Only pt changes. */
+int orbm_undistort_keypoints(orbm_t* h, const OrbxKeyPoint* keys, int n, const float K[4], const float D[5],
+                             OrbxKeyPoint* keys_un);
+
 /* void MapPoint::ComputeDistinctiveDescriptors()   src/MapPoint.cc:242-307, batched over map points.
  * desc = the observations' descriptors of all points back to back, start[npoints+1] = CSR.
  * best_idx[p] = index (inside point p's list) of the descriptor with the least median distance

@@ -382,3 +382,13 @@ def distinctive_descriptors(desc, start, L=None):
     out = np.full(max(len(start) - 1, 1), -1, np.int32)
     L.orc_distinctive_descriptors(_p(desc), _p(start), len(start) - 1, _p(out))
     return out[:len(start) - 1]
+
+
+def undistort_keypoints(keys, K, D, L=None):
+    L = L or lib()
+    keys = np.ascontiguousarray(keys, dtype=KP_DTYPE)
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    D = np.ascontiguousarray(D, dtype=np.float32)
+    out = np.zeros_like(keys)
+    L.orc_undistort_keypoints(_p(keys), keys.shape[0], _p(K), _p(D), _p(out))
+    return out

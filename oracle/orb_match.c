@@ -475,3 +475,34 @@ int orc_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int n
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ SURVEY 8(f).3
+ * Frame::UndistortKeyPoints (src/Frame.cc:404-434) = cv::undistortPoints(mat, mat, mK, mDistCoef,
+ * cv::Mat(), mK): OpenCV 3.0 cvUndistortPoints restated from its published algorithm (UNPINNED,
+ * like the other OpenCV primitives): normalise with 1/fx, 5 fixed-point iterations of the
+ * radial-tangential model in double, re-project with mK, store as float.  K = fx, fy, cx, cy;
+ * D = k1, k2, p1, p2, k3.  D[0] == 0 -> plain copy (:406-410). */
+void orc_undistort_keypoints(const OrcKeyPoint* in, int n, const float K[4], const float D[5], OrcKeyPoint* out)
+{
+    for (int i = 0; i < n; i++) out[i] = in[i];
+    if (D[0] == 0.0f) return;
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k[8] = {D[0], D[1], D[2], D[3], D[4], 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        double x = in[i].x, y = in[i].y, x0, y0;
+        x0 = x = (x - cx) * ifx;
+        y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+        out[i].x = (float)(xx * ww);
+        out[i].y = (float)(yy * ww);
+    }
+}

@@ -199,6 +199,9 @@ int  orc_search_for_triangulation(const OrcKeyPoint* k1, const uint8_t* d1, cons
                                   const float* sf2, const float* sigma2_2,
                                   int only_stereo, int check_ori, int32_t* matches12);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:404-434), OpenCV 3.0 undistortPoints (unpinned) */
+void orc_undistort_keypoints(const OrcKeyPoint* in, int n, const float K[4], const float D[5], OrcKeyPoint* out);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched */
 int  orc_distinctive_descriptors(const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx);
 

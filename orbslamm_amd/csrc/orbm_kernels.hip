@@ -788,4 +788,39 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ 
     if (lane == 0) bestIdx[p] = best;
 }
 
+// ------------------------------------------------------------------ SURVEY 8(f).3
+// Frame::UndistortKeyPoints (src/Frame.cc:404-434) = cv::undistortPoints(..., mK, mDistCoef, Mat(), mK):
+// 5 fixed-point iterations of the radial-tangential model in double, one thread per keypoint.
+// Every operation is a separately rounded IEEE binary64 op (no contraction), like the host code.
+struct UndistArgs { double fx, fy, cx, cy, k1, k2, p1, p2, k3; };
+__global__ void k_undistort(const KeyDev* __restrict__ in, int n, UndistArgs a, KeyDev* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    KeyDev kp = in[i];
+    const double ifx = __ddiv_rn(1.0, a.fx), ify = __ddiv_rn(1.0, a.fy);
+    double x = kp.x, y = kp.y;
+    const double x0 = x = __dmul_rn(__dsub_rn(x, a.cx), ifx);
+    const double y0 = y = __dmul_rn(__dsub_rn(y, a.cy), ify);
+    for (int j = 0; j < 5; j++) {
+        const double r2 = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+        // (1 + ((k7*r2 + k6)*r2 + k5)*r2) with k5..k7 = 0 evaluates to exactly 1
+        const double num = __dadd_rn(1.0, __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(0.0, r2), 0.0), r2), 0.0), r2));
+        const double den = __dadd_rn(1.0, __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(a.k3, r2), a.k2), r2), a.k1), r2));
+        const double icdist = __ddiv_rn(num, den);
+        const double deltaX = __dadd_rn(__dmul_rn(__dmul_rn(__dmul_rn(2.0, a.p1), x), y),
+                                        __dmul_rn(a.p2, __dadd_rn(r2, __dmul_rn(__dmul_rn(2.0, x), x))));
+        const double deltaY = __dadd_rn(__dmul_rn(a.p1, __dadd_rn(r2, __dmul_rn(__dmul_rn(2.0, y), y))),
+                                        __dmul_rn(__dmul_rn(__dmul_rn(2.0, a.p2), x), y));
+        x = __dmul_rn(__dsub_rn(x0, deltaX), icdist);
+        y = __dmul_rn(__dsub_rn(y0, deltaY), icdist);
+    }
+    const double xx = __dadd_rn(__dadd_rn(__dmul_rn(a.fx, x), __dmul_rn(0.0, y)), a.cx);
+    const double yy = __dadd_rn(__dadd_rn(__dmul_rn(0.0, x), __dmul_rn(a.fy, y)), a.cy);
+    const double ww = __ddiv_rn(1.0, __dadd_rn(__dadd_rn(__dmul_rn(0.0, x), __dmul_rn(0.0, y)), 1.0));
+    kp.x = (float)__dmul_rn(xx, ww);
+    kp.y = (float)__dmul_rn(yy, ww);
+    out[i] = kp;
+}
+
 }  // namespace orbm

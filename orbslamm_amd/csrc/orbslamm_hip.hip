@@ -1554,6 +1554,26 @@ extern "C" int orbm_search_for_triangulation(orbm_t* h,
 }
 #undef UP
 
+extern "C" int orbm_undistort_keypoints(orbm_t* h, const OrbxKeyPoint* keys, int n, const float K[4], const float D[5],
+                                        OrbxKeyPoint* keys_un)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (n < 0 || !K || !D || (n && (!keys || !keys_un))) return fail(ORBX_E_INVALID, "bad argument");
+    if (n == 0) return ORBX_OK;
+    if (D[0] == 0.0f) { memcpy(keys_un, keys, (size_t)n * sizeof(OrbxKeyPoint)); return ORBX_OK; }  // mvKeysUn = mvKeys (Frame.cc:406-410)
+    if ((rc = orbm_reserve(h, 0, (size_t)n * sizeof(OrbxKeyPoint))) || (rc = orbm_reserve(h, 1, (size_t)n * sizeof(OrbxKeyPoint)))) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->d_buf[0], keys, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyHostToDevice, s));
+    orbm::UndistArgs a = {K[0], K[1], K[2], K[3], D[0], D[1], D[2], D[3], D[4]};
+    hipLaunchKernelGGL(orbm::k_undistort, dim3((n + 255) / 256), dim3(256), 0, s, (const orbm::KeyDev*)h->d_buf[0], n, a,
+                       (orbm::KeyDev*)h->d_buf[1]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(keys_un, h->d_buf[1], (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
 extern "C" int orbm_distinctive_descriptors(orbm_t* h, const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx)
 {
     int rc = orbm_check(h);

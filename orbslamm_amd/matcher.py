@@ -174,6 +174,15 @@ class ORBmatcher:
                                                     int(bool(only_stereo)), int(self.mbCheckOrientation), ptr(m12), C.byref(n)))
         return m12[:n1], n.value
 
+    def UndistortKeyPoints(self, keys, K, D):
+        """Frame::UndistortKeyPoints (Frame.cc:404): K = (fx, fy, cx, cy), D = (k1, k2, p1, p2, k3)"""
+        keys = np.ascontiguousarray(keys, dtype=KP_DTYPE)
+        K = np.ascontiguousarray(K, dtype=np.float32)
+        D = np.ascontiguousarray(D, dtype=np.float32)
+        out = np.zeros_like(keys)
+        check(self._L.orbm_undistort_keypoints(self._h, ptr(keys), keys.shape[0], ptr(K), ptr(D), ptr(out)))
+        return out
+
     def ComputeDistinctiveDescriptors(self, desc, start):
         """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242), batched: desc = all observations'
         descriptors back to back, start = CSR offsets per map point; returns the winning index per point"""

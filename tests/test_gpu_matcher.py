@@ -216,3 +216,22 @@ def test_cpp_adapters_on_gpu(gpu, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "adapter_gpu ok" in out.stdout
+
+
+def test_undistort_keypoints_parity(gm, oracle):
+    """TUM1.yaml calibration (fx 517.3, fy 516.5, cx 318.6, cy 255.3, k1 0.2624 k2 -0.9531 p1 -0.0054 p2 0.0026 k3 1.1633)"""
+    rng = np.random.default_rng(501)
+    n = 5000
+    keys = np.zeros(n, dtype=oracle.KP_DTYPE)
+    keys["x"] = rng.uniform(0, 640, n).astype(np.float32)
+    keys["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    keys["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    keys["octave"] = rng.integers(0, 8, n)
+    K = [517.306408, 516.469215, 318.643040, 255.313989]
+    D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+    got = gm.UndistortKeyPoints(keys, K, D)
+    want = oracle.undistort_keypoints(keys, K, D)
+    assert got.tobytes() == want.tobytes()
+    assert np.abs(want["x"] - keys["x"]).max() > 1.0 and (want["angle"] == keys["angle"]).all()
+    # zero distortion (KITTI): mvKeysUn = mvKeys
+    assert gm.UndistortKeyPoints(keys, K, [0, 0, 0, 0, 0]).tobytes() == keys.tobytes()
