@@ -330,7 +330,8 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     g.candFrameRecs = candOff;
     g.keptFrameRecs = keptOff;
     g.maxKp = keptOff;
-    out.tileStrideDw = ((3 + maxRoiW + 3) / 4 + 1) | 1;  // odd dword stride
+    out.tileStrideDw = maxRoiW + 5 <= 48 ? 12 : 20;      // k_fast<48> or k_fast<80> (tile row stride in bytes)
+    if (maxRoiW + 5 > 80 || maxRoiW - 6 > 127 || maxRoiH - 6 > 127) return fail(ORBX_E_UNSUPPORTED, "cell larger than the FAST tile");
     out.tileRows = maxRoiH;
     out.fastListCap = ((maxRoiW - 6) * (maxRoiH - 6) + 63) / 64 * 64;  // compacted detection pixels
     out.nodeCap = align_up(nodeCap, 2);
@@ -733,10 +734,14 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         h->prof.end(s2);
         HIPCHK(hipEventRecord(h->evBlur[part], s2));
         if (g.totalCells > 0) {
-            const size_t lds = (size_t)2 * h->tileRows * h->tileStrideDw * 4 + (size_t)h->fastListCap * 2;
+            const size_t lds = (size_t)2 * (h->tileRows * h->tileStrideDw + 4) * 4 + (size_t)h->fastListCap * 2;
             h->prof.begin(P_FAST, s);
-            hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nb), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
-                               h->d_cellCount, h->d_err, h->tileStrideDw, h->tileRows, h->fastListCap);
+            if (h->tileStrideDw == 12)
+                hipLaunchKernelGGL(k_fast<48>, dim3(g.totalCells, nb), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
+                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap);
+            else
+                hipLaunchKernelGGL(k_fast<80>, dim3(g.totalCells, nb), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
+                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap);
             h->prof.end(s);
         }
         h->prof.begin(P_DISTRIBUTE, s);

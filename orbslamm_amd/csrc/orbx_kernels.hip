@@ -195,51 +195,92 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
 // threshold t iff S > t, and cv::FAST's cornerScore is then S - 1 (threshold
 // independent), so the minThFAST retry re-thresholds the same S map.
 //
-// Two-stage: a cheap compass test (every 9-arc holds one pixel of each opposite pair)
-// runs on all pixels and COMPACTS the survivors (about a quarter of a busy image) into
-// an LDS list; the exact 16-arc score, the 3x3 non-max suppression and the emission
-// then run on the dense list, so no lane idles through the heavy part.
-// Window-9 minima/maxima of the 16-ring with three-input min/max: m3[k] = min3(d[k..k+2]),
-// m9[k] = min3(m3[k], m3[k+3], m3[k+6]) -- 32 v_min3 + 32 v_max3 for all 16 arcs (full-rate
-// VOP3; packed i16 min/max issue at half rate on gfx950, tools/ubench/valu_rate.hip).
+// The kernel is VALU-issue bound (profiles/r01_pmc_sq_*.txt), so it is organised to shed
+// instructions, in three compactions:
+//   stage 1  compass test on every pixel, four pixels per lane from aligned LDS dwords: a
+//            9-arc holds two adjacent compass pixels, i.e. one of {N,S} and one of {E,W},
+//            all brighter than v+tq or all darker than v-tq.  Survivors are compacted into
+//            a list tagged with their side; the few that pass on both sides go to a second
+//            list growing down from the top of the same buffer.
+//   stage 2  exact score on the dense lists.  A bright and a dark 9-arc cannot coexist (two
+//            9-arcs of a 16-ring overlap), so one-sided survivors only evaluate their own
+//            side: d_k = +-(v - p_k), S = max(0, max_k min(d_k..d_k+8)).  Pixels with S > tq
+//            are compacted again, in place.
+//   stage 3  3x3 non-max suppression and emission run on that corner list only.
+// Window-9 minima of the 16-ring with three-input min: m3[k] = min3(d[k..k+2]),
+// m9[k] = min3(m3[k], m3[k+3], m3[k+6]) (full-rate VOP3; packed i16 min/max issue at half rate
+// on gfx950, tools/ubench/valu_rate.hip).
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-__device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p, const int* off)
+// ring offsets for a tile of row stride TSB bytes (compile-time: they become DS immediates)
+template <int TSB, int K> struct RingOff {
+    static constexpr int cx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    static constexpr int cy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    static constexpr int v = cx[K] + cy[K] * TSB;
+};
+
+__device__ __forceinline__ int arc_max_of_min(const int (&d)[16])
 {
-    const int v = p[0];
-    int d[16];
+    int m3[16], m9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - p[off[k]];
-    int mn3[16], mx3[16];
+    for (int k = 0; k < 16; k++) m3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        mx3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    }
-    int mn9[16], mx9[16];
+    for (int k = 0; k < 16; k++) m9[k] = min3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+    int a5[5];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn9[k] = min3i(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
-        mx9[k] = max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
-    }
-    // A = max_k mn9[k], Bn = min_k mx9[k] as three-input trees
-    int a5[6], b5[6];
-#pragma unroll
-    for (int k = 0; k < 5; k++) { a5[k] = max3i(mn9[3 * k], mn9[3 * k + 1], mn9[3 * k + 2]); b5[k] = min3i(mx9[3 * k], mx9[3 * k + 1], mx9[3 * k + 2]); }
-    a5[5] = mn9[15]; b5[5] = mx9[15];
-    const int A = max(max3i(a5[0], a5[1], a5[2]), max3i(a5[3], a5[4], a5[5]));
-    const int Bn = min(min3i(b5[0], b5[1], b5[2]), min3i(b5[3], b5[4], b5[5]));
-    const int S = max(A, -Bn);
-    return S < 0 ? 0 : S;
+    for (int k = 0; k < 5; k++) a5[k] = max3i(m9[3 * k], m9[3 * k + 1], m9[3 * k + 2]);
+    return max(max3i(a5[0], a5[1], a5[2]), max3i(a5[3], a5[4], m9[15]));
 }
 
+template <int TSB> __device__ __forceinline__ void ring_load(const uint8_t* __restrict__ p, int (&r)[16])
+{
+    r[0] = p[RingOff<TSB, 0>::v];   r[1] = p[RingOff<TSB, 1>::v];   r[2] = p[RingOff<TSB, 2>::v];   r[3] = p[RingOff<TSB, 3>::v];
+    r[4] = p[RingOff<TSB, 4>::v];   r[5] = p[RingOff<TSB, 5>::v];   r[6] = p[RingOff<TSB, 6>::v];   r[7] = p[RingOff<TSB, 7>::v];
+    r[8] = p[RingOff<TSB, 8>::v];   r[9] = p[RingOff<TSB, 9>::v];   r[10] = p[RingOff<TSB, 10>::v]; r[11] = p[RingOff<TSB, 11>::v];
+    r[12] = p[RingOff<TSB, 12>::v]; r[13] = p[RingOff<TSB, 13>::v]; r[14] = p[RingOff<TSB, 14>::v]; r[15] = p[RingOff<TSB, 15>::v];
+}
+
+// one side only: sgn = +1 dark arcs (d = v - p), -1 bright arcs (d = p - v)
+template <int TSB> __device__ __forceinline__ int fast_S_side(const uint8_t* __restrict__ p, int sgn)
+{
+    int r[16], d[16];
+    ring_load<TSB>(p, r);
+    const int sv = sgn * (int)p[0], ns = -sgn;
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = __mul24(r[k], ns) + sv;
+    return max(arc_max_of_min(d), 0);
+}
+
+// both sides (the rare pixel that passes the compass test on both)
+template <int TSB> __device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p)
+{
+    int r[16], d[16];
+    ring_load<TSB>(p, r);
+    const int v = p[0];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - r[k];
+    const int A = arc_max_of_min(d);
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = -d[k];
+    return max(max(A, arc_max_of_min(d)), 0);
+}
+
+__device__ __forceinline__ int lanes_below(uint64_t bal)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+}
+
+// Tile layout: ROI pixel (rx, ry) at byte ry*TSB + rx + 1, so detection pixel (x, y) = ROI (x+3, y+3)
+// sits at (y+3)*TSB + x + 4 and groups of four detection pixels are dword aligned.
+template <int TSB>
 __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const Cell* __restrict__ cells,
                                             FrameSrc src, uint64_t* __restrict__ cand,
                                             int32_t* __restrict__ cellCount, int32_t* __restrict__ errFlag,
-                                            int tileStrideDw, int tileRows, int listCap)
+                                            int tileRows, int listCap)
 {
     extern __shared__ uint32_t lds[];
+    constexpr int TSD = TSB / 4;
     const Cell c = cells[blockIdx.x];
     const int f = blockIdx.y + src.f0;
     const int lane = threadIdx.x;
@@ -248,117 +289,134 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     int stride;
     const uint8_t* base = level_ptr(g, src, f, level, stride);
 
-    uint32_t* tile = lds;                                   // [tileRows][tileStrideDw] dwords
-    const int tsb = tileStrideDw * 4;                       // tile stride in bytes
-    uint8_t* smap = (uint8_t*)(lds + tileRows * tileStrideDw);  // same geometry, bytes
-    uint16_t* list = (uint16_t*)(lds + 2 * tileRows * tileStrideDw);  // compacted (y<<8 | x)
+    uint32_t* tile = lds;                                           // [tileRows][TSD] dwords (+ slack)
+    uint8_t* smap = (uint8_t*)(lds + tileRows * TSD + 4);           // same geometry, bytes
+    uint16_t* list = (uint16_t*)(lds + 2 * (tileRows * TSD + 4));   // listCap entries
     const uint8_t* tb = (const uint8_t*)tile;
 
     const int cw = c.w, ch = c.h;
-    const int shift = c.x0 & 3;
-    const int ndw = (shift + cw + 3) >> 2;
-    // coalesced aligned dword loads of the ROI rows, 12 per lane in flight (clamped addresses,
-    // predicated LDS stores) so the wave pays one memory round trip; zero the S map
+    const int ndw = (cw + 4) >> 2;
+    // coalesced dword loads of the ROI rows starting one byte left of the ROI (unaligned global
+    // loads are fine on gfx950), 12 per lane in flight; clamped addresses so that out-of-range
+    // lanes re-store a valid dword and no store needs a predicate
     {
-        const uint8_t* rowbase = base + (int64_t)c.y0 * stride + (c.x0 & ~3);
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        const uint8_t* rowbase = base + (int64_t)c.y0 * stride + c.x0 - 1;
         for (int d0 = 0; d0 < ndw; d0 += 16) {
-            const int dd = d0 + (lane & 15);
-            const int ddc = min(dd, ndw - 1);
+            const int ddc = min(d0 + (lane & 15), ndw - 1);
             for (int rb = 0; rb < ch; rb += 48) {
                 uint32_t regs[12];
 #pragma unroll
                 for (int k = 0; k < 12; k++) {
                     const int r = min(rb + (lane >> 4) + 4 * k, ch - 1);
-                    regs[k] = *(const uint32_t*)(rowbase + (int64_t)r * stride + 4 * ddc);
+                    regs[k] = ((const U32*)(rowbase + (int64_t)r * stride + 4 * ddc))->v;
                 }
 #pragma unroll
                 for (int k = 0; k < 12; k++) {
-                    const int r = rb + (lane >> 4) + 4 * k;
-                    if (r < ch && dd < ndw) tile[r * tileStrideDw + dd] = regs[k];
+                    const int r = min(rb + (lane >> 4) + 4 * k, ch - 1);
+                    tile[r * TSD + ddc] = regs[k];
                 }
             }
         }
         uint32_t* sm32 = (uint32_t*)smap;
-        for (int i = lane; i < ch * tileStrideDw; i += 64) sm32[i] = 0;
+        for (int i = lane; i < ch * TSD; i += 64) sm32[i] = 0;
     }
     __syncthreads();
 
-    int off[16];
-    {
-        const int cx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-        const int cy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-#pragma unroll
-        for (int k = 0; k < 16; k++) off[k] = cx[k] + cy[k] * tsb;
-    }
     const int dw = cw - 6, dh = ch - 6;  // detection area
     int th = g->iniTh < 0 ? 0 : (g->iniTh > 255 ? 255 : g->iniTh);
     const int th2 = g->minTh < 0 ? 0 : (g->minTh > 255 ? 255 : g->minTh);
     const int tq = min(th, th2);
-    const uint64_t lt = lanemask_lt();
-    const int pos0 = 3 * tsb + shift + 3;  // tile byte offset of detection pixel (0,0)
+    constexpr int pos0 = 3 * TSB + 4;  // tile byte offset of detection pixel (0,0)
 
-    // stage 1: compass test on every pixel, survivors compacted (S <= tq otherwise: never a
-    // corner at either threshold and never a suppressing neighbour)
-    int cnt = 0;
+    // stage 1: list entries are (side << 14 | y << 7 | x), side 1 = bright
+    int nA = 0, nB = 0;
     for (int xb = 0; xb < dw; xb += 32) {
-        const int x = xb + (lane & 31);
-        for (int y0 = 0; y0 < dh; y0 += 2) {
-            const int y = y0 + (lane >> 5);
-            bool pass = false;
-            if (x < dw && y < dh) {
-                const uint8_t* p = tb + pos0 + y * tsb + x;
-                // max(|v-p0|,|v-p8|) = max(v - min(p0,p8), max(p0,p8) - v); both pairs must exceed tq
-                const int v = p[0];
-                const int p0 = p[off[0]], p8 = p[off[8]], p4 = p[off[4]], p12 = p[off[12]];
-                const int e0 = max(v - min(p0, p8), max(p0, p8) - v);
-                const int e4 = max(v - min(p4, p12), max(p4, p12) - v);
-                pass = min(e0, e4) > tq;
+        const int x4 = xb + 4 * (lane & 7);
+        for (int y0 = 0; y0 < dh; y0 += 8) {
+            const int y = y0 + (lane >> 3);
+            const bool rowOk = y < dh;
+            const uint32_t* q = tile + (rowOk ? y : 0) * TSD + (x4 >> 2);
+            const uint32_t N = q[1], C0 = q[3 * TSD], C1 = q[3 * TSD + 1], C2 = q[3 * TSD + 2], S = q[6 * TSD + 1];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int v = (C1 >> (8 * k)) & 0xFF;
+                const int pn = (N >> (8 * k)) & 0xFF, ps = (S >> (8 * k)) & 0xFF;
+                const int pw = k < 3 ? (C0 >> (8 * (k + 1))) & 0xFF : C1 & 0xFF;
+                const int pe = k == 0 ? C1 >> 24 : (C2 >> (8 * (k - 1))) & 0xFF;
+                const int hi = min(max(pn, ps), max(pw, pe));   // bright: hi - v > tq
+                const int lo = max(min(pn, ps), min(pw, pe));   // dark:   v - lo > tq
+                const bool in = rowOk && x4 + k < dw;
+                const bool br = in && hi - v > tq, dk = in && v - lo > tq;
+                const uint64_t balA = __ballot(br != dk);
+                const int e = (y << 7) | (x4 + k);
+                if (br != dk) list[nA + lanes_below(balA)] = (uint16_t)(e | (br ? 0x4000 : 0));
+                nA += __popcll(balA);
+                const uint64_t balB = __ballot(br && dk);
+                if (balB) {
+                    if (br && dk) list[listCap - 1 - nB - lanes_below(balB)] = (uint16_t)e;
+                    nB += __popcll(balB);
+                }
             }
-            const uint64_t bal = __ballot(pass);
-            if (pass) {
-                const int slot = cnt + __popcll(bal & lt);
-                if (slot < listCap) list[slot] = (uint16_t)((y << 8) | x);
-            }
-            cnt += __popcll(bal);
         }
     }
-    if (cnt > listCap) { if (lane == 0) atomicOr(errFlag, 8); cnt = listCap; }
     __syncthreads();
     // every cell owns a fixed segment of the candidate buffer (no atomics, deterministic layout)
     int32_t* myCount = cellCount + (int64_t)f * g->totalCells + blockIdx.x;
-    if (cnt == 0) { if (lane == 0) *myCount = 0; return; }
+    if (nA + nB == 0) { if (lane == 0) *myCount = 0; return; }
 
-    // stage 2: exact score on the dense list
-    for (int i = lane; i < cnt; i += 64) {
-        const int e = list[i];
-        const int pos = pos0 + (e >> 8) * tsb + (e & 0xFF);
-        smap[pos] = (uint8_t)fast_S(tb + pos, off);
+    // stage 2: exact score on the dense lists; pixels with S > tq (corners at the lower
+    // threshold) are compacted in place: writes land at or below entries already consumed
+    int nC = 0;
+    for (int i0 = 0; i0 < nA; i0 += 64) {
+        const int i = i0 + lane;
+        const bool act = i < nA;
+        const int e = act ? list[i] : 0;
+        const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+        const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
+        const bool corner = act && Sx > tq;
+        if (corner) smap[pos] = (uint8_t)Sx;
+        const uint64_t bal = __ballot(corner);
+        if (corner) list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF);
+        nC += __popcll(bal);
+    }
+    for (int i0 = 0; i0 < nB; i0 += 64) {  // ascending addresses, see above
+        const int i = i0 + lane;
+        const bool act = i < nB;
+        const int e = act ? list[listCap - nB + i] : 0;
+        const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+        const int Sx = fast_S<TSB>(tb + pos);
+        const bool corner = act && Sx > tq;
+        if (corner) smap[pos] = (uint8_t)Sx;
+        const uint64_t bal = __ballot(corner);
+        if (corner) list[nC + lanes_below(bal)] = (uint16_t)e;
+        nC += __popcll(bal);
     }
     __syncthreads();
+    if (nC == 0) { if (lane == 0) *myCount = 0; return; }
 
-    // 3x3 non-max suppression on M_t = (S > t ? S-1 : 0), strict >, zero outside the
-    // detection area; if nothing survives at iniThFAST, retry at minThFAST (:812-816)
+    // stage 3: 3x3 non-max suppression on M_t = (S > t ? S-1 : 0), strict >, zero outside the
+    // detection area (the S map is zero there); if nothing survives at iniThFAST, retry at
+    // minThFAST (:812-816).  The keep decision is remembered in bit 15 of the list entry.
     auto nms_keep = [&](int e, int& sc) {
-        const uint8_t* sp = smap + pos0 + (e >> 8) * tsb + (e & 0xFF);
+        const uint8_t* sp = smap + pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
         sc = sp[0];
         if (!(sc > th && sc >= 2)) return false;
         int m = 0;
 #define NB(o) { const int sn = sp[o]; if (sn > th) m = max(m, sn); }
-        NB(-1) NB(1) NB(-tsb - 1) NB(-tsb) NB(-tsb + 1) NB(tsb - 1) NB(tsb) NB(tsb + 1)
+        NB(-1) NB(1) NB(-TSB - 1) NB(-TSB) NB(-TSB + 1) NB(TSB - 1) NB(TSB) NB(TSB + 1)
 #undef NB
         return sc > m;
     };
-    // first pass at iniThFAST (retry at minThFAST only when the cell stays empty); the
-    // keep decision is remembered in bit 15 of the list entry, so emission needs no recompute
-    const int cntUp = (cnt + 63) & ~63;
     int total = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         total = 0;
-        for (int i = lane; i < cntUp; i += 64) {
+        for (int i0 = 0; i0 < nC; i0 += 64) {
+            const int i = i0 + lane;
             int sc;
             bool keep = false;
-            if (i < cnt) {
-                const int e = list[i] & 0x7FFF;
+            if (i < nC) {
+                const int e = list[i] & 0x3FFF;
                 keep = nms_keep(e, sc);
                 if (keep) list[i] = (uint16_t)(e | 0x8000);
             }
@@ -372,19 +430,19 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     __syncthreads();
 
     uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff + c.candOff;
-    const int basePos = 0;
     const int candCap = ((cw - 6 + 1) >> 1) * ((ch - 6 + 1) >> 1);  // NMS bound = segment size
     int run = 0;
-    for (int i = lane; i < cntUp; i += 64) {
+    for (int i0 = 0; i0 < nC; i0 += 64) {
+        const int i = i0 + lane;
         int e = 0;
         bool keep = false;
-        if (i < cnt) { e = list[i]; keep = (e & 0x8000) != 0; e &= 0x7FFF; }
+        if (i < nC) { e = list[i]; keep = (e & 0x8000) != 0; e &= 0x3FFF; }
         const uint64_t bal = __ballot(keep);
         if (keep) {
-            const int p = basePos + run + __popcll(bal & lt);
+            const int p = run + lanes_below(bal);
             if (p < candCap) {
-                const uint32_t xr = (e & 0xFF) + 3, yr = (e >> 8) + 3;  // ROI coordinates
-                const int sc = smap[pos0 + (e >> 8) * tsb + (e & 0xFF)];
+                const uint32_t xr = (e & 0x7F) + 3, yr = ((e >> 7) & 0x7F) + 3;  // ROI coordinates
+                const int sc = smap[pos0 + (yr - 3) * TSB + (xr - 3)];
                 out[p] = pack_cand(c.x0 - kMinBorder + xr, c.y0 - kMinBorder + yr, sc - 1, cand_order(c.seq, yr, xr));
             } else {
                 atomicOr(errFlag, 1);
