@@ -248,7 +248,8 @@ template <int TSB> __device__ __forceinline__ int fast_S_side(const uint8_t* __r
     ring_load<TSB>(p, r);
     const int sv = sgn * (int)p[0], ns = -sgn;
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = __mul24(r[k], ns) + sv;
+    for (int k = 0; k < 16; k++)  // d = sgn * (v - r): one full-rate VOP3 op (the compiler splits it into mul + sub)
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d[k]) : "v"(r[k]), "v"(ns), "v"(sv));
     return max(arc_max_of_min(d), 0);
 }
 
@@ -266,6 +267,8 @@ template <int TSB> __device__ __forceinline__ int fast_S(const uint8_t* __restri
     return max(max(A, arc_max_of_min(d)), 0);
 }
 
+__device__ __forceinline__ uint64_t ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ uint64_t tail_mask(int n) { return n >= 64 ? ~0ull : (1ull << n) - 1; }  // lanes < n (n > 0)
 __device__ __forceinline__ int lanes_below(uint64_t bal)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
@@ -329,13 +332,18 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     const int tq = min(th, th2);
     constexpr int pos0 = 3 * TSB + 4;  // tile byte offset of detection pixel (0,0)
 
-    // stage 1: list entries are (side << 14 | y << 7 | x), side 1 = bright
+    // stage 1: list entries are (side << 14 | y << 7 | x), side 1 = bright.  Ballots are taken of
+    // bare compares and combined on the scalar unit (a ballot of a derived bool costs two VALU ops).
     int nA = 0, nB = 0;
     for (int xb = 0; xb < dw; xb += 32) {
         const int x4 = xb + 4 * (lane & 7);
+        uint64_t mX[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) mX[k] = ballot64(x4 + k < dw);
         for (int y0 = 0; y0 < dh; y0 += 8) {
             const int y = y0 + (lane >> 3);
             const bool rowOk = y < dh;
+            const uint64_t mY = ballot64(y < dh);
             const uint32_t* q = tile + (rowOk ? y : 0) * TSD + (x4 >> 2);
             const uint32_t N = q[1], C0 = q[3 * TSD], C1 = q[3 * TSD + 1], C2 = q[3 * TSD + 2], S = q[6 * TSD + 1];
 #pragma unroll
@@ -346,15 +354,17 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const int pe = k == 0 ? C1 >> 24 : (C2 >> (8 * (k - 1))) & 0xFF;
                 const int hi = min(max(pn, ps), max(pw, pe));   // bright: hi - v > tq
                 const int lo = max(min(pn, ps), min(pw, pe));   // dark:   v - lo > tq
+                const bool br = hi - v > tq, dk = v - lo > tq;
+                const uint64_t mIn = mX[k] & mY, mBr = ballot64(br), mDk = ballot64(dk);
+                const uint64_t balA = (mBr ^ mDk) & mIn, balB = mBr & mDk & mIn;
                 const bool in = rowOk && x4 + k < dw;
-                const bool br = in && hi - v > tq, dk = in && v - lo > tq;
-                const uint64_t balA = __ballot(br != dk);
                 const int e = (y << 7) | (x4 + k);
-                if (br != dk) list[nA + lanes_below(balA)] = (uint16_t)(e | (br ? 0x4000 : 0));
-                nA += __popcll(balA);
-                const uint64_t balB = __ballot(br && dk);
+                if (balA) {
+                    if (in && br != dk) list[nA + lanes_below(balA)] = (uint16_t)(e | (br ? 0x4000 : 0));
+                    nA += __popcll(balA);
+                }
                 if (balB) {
-                    if (br && dk) list[listCap - 1 - nB - lanes_below(balB)] = (uint16_t)e;
+                    if (in && br && dk) list[listCap - 1 - nB - lanes_below(balB)] = (uint16_t)e;
                     nB += __popcll(balB);
                 }
             }
@@ -375,9 +385,8 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
         const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
         const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
         const bool corner = act && Sx > tq;
-        if (corner) smap[pos] = (uint8_t)Sx;
-        const uint64_t bal = __ballot(corner);
-        if (corner) list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF);
+        const uint64_t bal = ballot64(Sx > tq) & tail_mask(nA - i0);
+        if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
         nC += __popcll(bal);
     }
     for (int i0 = 0; i0 < nB; i0 += 64) {  // ascending addresses, see above
@@ -387,69 +396,46 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
         const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
         const int Sx = fast_S<TSB>(tb + pos);
         const bool corner = act && Sx > tq;
-        if (corner) smap[pos] = (uint8_t)Sx;
-        const uint64_t bal = __ballot(corner);
-        if (corner) list[nC + lanes_below(bal)] = (uint16_t)e;
+        const uint64_t bal = ballot64(Sx > tq) & tail_mask(nB - i0);
+        if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
         nC += __popcll(bal);
     }
     __syncthreads();
     if (nC == 0) { if (lane == 0) *myCount = 0; return; }
 
     // stage 3: 3x3 non-max suppression on M_t = (S > t ? S-1 : 0), strict >, zero outside the
-    // detection area (the S map is zero there); if nothing survives at iniThFAST, retry at
-    // minThFAST (:812-816).  The keep decision is remembered in bit 15 of the list entry.
-    auto nms_keep = [&](int e, int& sc) {
-        const uint8_t* sp = smap + pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
-        sc = sp[0];
-        if (!(sc > th && sc >= 2)) return false;
-        int m = 0;
-#define NB(o) { const int sn = sp[o]; if (sn > th) m = max(m, sn); }
-        NB(-1) NB(1) NB(-TSB - 1) NB(-TSB) NB(-TSB + 1) NB(TSB - 1) NB(TSB) NB(TSB + 1)
-#undef NB
-        return sc > m;
-    };
+    // detection area (the S map is zero there), fused with the emission; if nothing survives at
+    // iniThFAST, retry at minThFAST (:812-816).  A corner has S > t, so "S > every neighbour with
+    // S > t" is simply S > max of the eight neighbours.
+    uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff + c.candOff;
+    const int candCap = ((cw - 6 + 1) >> 1) * ((ch - 6 + 1) >> 1);  // NMS bound = segment size
     int total = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         total = 0;
         for (int i0 = 0; i0 < nC; i0 += 64) {
             const int i = i0 + lane;
-            int sc;
-            bool keep = false;
-            if (i < nC) {
-                const int e = list[i] & 0x3FFF;
-                keep = nms_keep(e, sc);
-                if (keep) list[i] = (uint16_t)(e | 0x8000);
+            const int e = i < nC ? list[i] : 0;
+            const uint8_t* sp = smap + pos0 + (e >> 7) * TSB + (e & 0x7F);
+            const int sc = sp[0];
+            const int n0 = sp[-TSB - 1], n1 = sp[-TSB], n2 = sp[-TSB + 1], n3 = sp[-1], n4 = sp[1], n5 = sp[TSB - 1], n6 = sp[TSB], n7 = sp[TSB + 1];
+            const int m = max3i(max3i(n0, n1, n2), max3i(n3, n4, n5), max(n6, n7));
+            const bool keep = i < nC && sc > th && sc >= 2 && sc > m;
+            const uint64_t bal = ballot64(sc > m) & ballot64(sc > max(th, 1)) & tail_mask(nC - i0);
+            if (keep) {
+                const int p = total + lanes_below(bal);
+                if (p < candCap) {
+                    const uint32_t xr = (e & 0x7F) + 3, yr = (e >> 7) + 3;  // ROI coordinates
+                    out[p] = pack_cand(c.x0 - kMinBorder + xr, c.y0 - kMinBorder + yr, sc - 1, cand_order(c.seq, yr, xr));
+                } else {
+                    atomicOr(errFlag, 1);
+                }
             }
-            total += __popcll(__ballot(keep));
+            total += __popcll(bal);
         }
         if (total > 0 || th == th2) break;
         th = th2;
     }
     if (lane == 0) *myCount = total;
-    if (total == 0) return;
-    __syncthreads();
-
-    uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff + c.candOff;
-    const int candCap = ((cw - 6 + 1) >> 1) * ((ch - 6 + 1) >> 1);  // NMS bound = segment size
-    int run = 0;
-    for (int i0 = 0; i0 < nC; i0 += 64) {
-        const int i = i0 + lane;
-        int e = 0;
-        bool keep = false;
-        if (i < nC) { e = list[i]; keep = (e & 0x8000) != 0; e &= 0x3FFF; }
-        const uint64_t bal = __ballot(keep);
-        if (keep) {
-            const int p = run + lanes_below(bal);
-            if (p < candCap) {
-                const uint32_t xr = (e & 0x7F) + 3, yr = ((e >> 7) & 0x7F) + 3;  // ROI coordinates
-                const int sc = smap[pos0 + (yr - 3) * TSB + (xr - 3)];
-                out[p] = pack_cand(c.x0 - kMinBorder + xr, c.y0 - kMinBorder + yr, sc - 1, cand_order(c.seq, yr, xr));
-            } else {
-                atomicOr(errFlag, 1);
-            }
-        }
-        run += __popcll(bal);
-    }
 }
 
 // ------------------------------------------------------------------ quadtree distribution
