@@ -40,7 +40,7 @@ def algorithmic_bytes(ex, w, h, nfeat):
         "k_blur": 2 * S,
         "k_orient_desc": 749 * nfeat + 512 * nfeat + (32 + 28) * nfeat,
         "k_distribute": 0,  # works on candidate records, not counted in the SURVEY figure
-        "k_match_best2": 2 * 32 * nfeat + 8 * nfeat,
+        "k_match_mfma": 2 * 32 * nfeat + 8 * nfeat,
         "k_match_accept": 0,
         "k_match_prune": 0,
     }

@@ -108,6 +108,160 @@ __global__ __launch_bounds__(256) void k_match_best2(MatchIO q, MatchIO t, int q
     partial[((int64_t)f * nchunks + chunk) * pitch + qi] = r;
 }
 
+// ------------------------------------------------------------------ brute-force scan on the matrix cores
+// The scan is a binary GEMM: with descriptors expanded to +-1 bytes, a . b = 256 - 2 * Hamming(a, b), exactly, in
+// int32.  The popcount formulation above is bound by the v_bcnt issue rate (tools/ubench/valu_rate.hip); the
+// v_mfma_i32_32x32x32_i8 formulation leaves three VALU ops per pair (key, min, med3).
+//
+// Expanded layout of one slot: block b (32 features) at b*8192 bytes; inside a block the 16-element chunk c of
+// feature r sits at (c*32 + r)*16, i.e. MFMA step s (32 elements) is the contiguous KiB [s*1024, (s+1)*1024)
+// with lane l = (c&1)*32 + r owning 16 bytes -- one coalesced 16-byte load per lane and step.  A (queries)
+// and B (trains) fragments are read the same way, so the element order inside a step cancels out.
+__global__ __launch_bounds__(256) void k_expand_desc(MatchIO io, int slot0, int xslot0, uint8_t* __restrict__ xdesc, int64_t xPitch)
+{
+    const int slot = slot0 + blockIdx.y;
+    const int n = io.count[slot];
+    const int t = blockIdx.x * 256 + threadIdx.x;  // (block, chunk, row)
+    const int blk = t >> 9, c = (t >> 5) & 15, r = t & 31;
+    if (blk * 32 >= n) return;
+    const int kp = blk * 32 + r;
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if (kp < n) {
+        const uint32_t bits = *(const uint16_t*)(io.desc + (int64_t)slot * io.descPitch + (int64_t)kp * 32 + 2 * c);
+        auto pm1 = [](uint32_t b4) {  // 4 bits -> 4 bytes, set = +1, clear = -1
+            const uint32_t x = (b4 * 0x00204081u) & 0x01010101u;
+            return x | ((x ^ 0x01010101u) * 0xFFu);
+        };
+        o.x = pm1(bits & 15); o.y = pm1((bits >> 4) & 15); o.z = pm1((bits >> 8) & 15); o.w = pm1(bits >> 12);
+    }
+    ((uint4*)(xdesc + (int64_t)(xslot0 + blockIdx.y) * xPitch))[t] = o;
+}
+
+__device__ __forceinline__ int med3i(int a, int b, int c)
+{
+    int o;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int kMfmaRowsPerBlock = 256;  // 4 waves x 2 query blocks of 32
+
+// One workgroup = 256 queries of one frame pair; the train side streams through LDS in tiles of 32 features
+// (8 KiB, double buffered, one barrier per tile); each wave holds two query blocks in registers (64 VGPRs) and
+// keeps, per lane and accumulator element, the running (best, second) keys of "its" train residue class.
+// key = Hamming << 16 | j - 2^23 (one v_lshl_add from the negated dot product), so signed min = best with the
+// lowest index on ties (the reference scans j ascending with strict <) and med3(best, key, second) = new second.
+__global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict__ xdesc, int64_t xPitch,
+                                                      const int32_t* __restrict__ count, int qslot0, int tslot0,
+                                                      uint2* __restrict__ partial, int64_t pitch, int nqb, int nframes)
+{
+    __shared__ uint4 tileB[3][512];
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, so the query blocks of one frame
+    // pair are given to one XCD and share that frame's train tiles in its L2
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int f = (k / nqb) * 8 + xcd;
+    if (f >= nframes) return;
+    const int nq = count[qslot0 + f], nt = count[tslot0 + f];
+    const int q0 = (k % nqb) * kMfmaRowsPerBlock;
+    if (q0 >= nq) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint8_t* qx = xdesc + (int64_t)(qslot0 + f) * xPitch;
+    const uint4* tsrc = (const uint4*)(xdesc + (int64_t)(tslot0 + f) * xPitch);
+    const int qblk0 = (q0 >> 5) + wave * 2;
+
+    v4i A[2][8];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int s = 0; s < 8; s++) A[qb][s] = *(const v4i*)(qx + (int64_t)(qblk0 + qb) * 8192 + s * 1024 + lane * 16);
+
+    int best[2][16], second[2][16];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) best[qb][r] = second[qb][r] = 0x7FFFFFFF;
+
+    const int ntiles = (nt + 31) >> 5;
+    // train tiles: prefetch distance 2 through registers (ga: even tiles, gb: odd tiles), LDS ring of 3
+    uint4 ga0, ga1, gb0, gb1;
+    if (ntiles > 0) { tileB[0][tid] = tsrc[tid]; tileB[0][tid + 256] = tsrc[tid + 256]; }
+    if (ntiles > 1) { gb0 = tsrc[512 + tid]; gb1 = tsrc[512 + tid + 256]; }
+    // queries negated (+-1 bytes: x ^ 0xFE), so the accumulator is -(a . b) = 2 * Hamming - 256 and the key is one
+    // v_lshl_add; using the fragments here also keeps their load waits out of the loop, where they would drain
+    // the prefetch
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int s = 0; s < 8; s++) A[qb][s] ^= (int)0xFEFEFEFE;
+    __syncthreads();
+
+    auto tile_step = [&](int t, int slot) {
+        const v4i* bt = (const v4i*)tileB[slot];
+        v4i Bf[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) Bf[s] = bt[s * 64 + lane];
+        v16i acc0 = {}, acc1 = {};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], Bf[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], Bf[s], acc1, 0, 0, 0);
+        }
+        const int j = t * 32 + (lane & 31);
+        const int jv = j < nt ? j : 0x3FFFFFFF;  // rows past the end decode to a distance >= 256: never taken
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            // compiler-visible VALU op on the accumulator: hipcc pads the MFMA -> VALU read hazard itself
+            // (an inline-asm consumer would read the accumulator too early)
+            const int k0 = (acc0[r] << 15) + jv, k1 = (acc1[r] << 15) + jv;
+            second[0][r] = med3i(best[0][r], k0, second[0][r]);
+            best[0][r] = min(best[0][r], k0);
+            second[1][r] = med3i(best[1][r], k1, second[1][r]);
+            best[1][r] = min(best[1][r], k1);
+        }
+    };
+    int slot = 0;  // ring slot of tile t
+    for (int t = 0; t < ntiles; t += 2) {
+        // even tile t: fetch t+2 into ga, compute t, park t+1 (gb) in the ring
+        if (t + 2 < ntiles) { ga0 = tsrc[(t + 2) * 512 + tid]; ga1 = tsrc[(t + 2) * 512 + tid + 256]; }
+        tile_step(t, slot);
+        const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        if (t + 1 < ntiles) { tileB[s1][tid] = gb0; tileB[s1][tid + 256] = gb1; }
+        __syncthreads();
+        if (t + 1 >= ntiles) break;
+        // odd tile t+1: fetch t+3 into gb, compute t+1, park t+2 (ga)
+        if (t + 3 < ntiles) { gb0 = tsrc[(t + 3) * 512 + tid]; gb1 = tsrc[(t + 3) * 512 + tid + 256]; }
+        tile_step(t + 1, s1);
+        if (t + 2 < ntiles) { tileB[s2][tid] = ga0; tileB[s2][tid + 256] = ga1; }
+        __syncthreads();
+        slot = s2;
+    }
+
+    // merge the 32 residue classes of every query row (lanes of one half-wave), then one lane per row writes
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int b = best[qb][r], s2 = second[qb][r];
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) {
+                const int ob = __shfl_xor(b, m), os = __shfl_xor(s2, m);
+                s2 = min(max(b, ob), min(s2, os));
+                b = min(b, ob);
+            }
+            if ((lane & 31) == r) {
+                const int qi = q0 + wave * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qi < nq) {
+                    const uint32_t h1 = (uint32_t)(b + (1 << 23)) >> 16, h2 = (uint32_t)(s2 + (1 << 23)) >> 16;
+                    uint2 o;
+                    o.x = h1 >= 256u ? 0xFFFFFFFFu : ((h1 << 20) | ((uint32_t)b & 0xFFFFu));
+                    o.y = ((h2 >= 256u ? 256u : h2) << 20) | 0xFFFFFu;
+                    partial[(int64_t)f * pitch + qi] = o;
+                }
+            }
+        }
+}
+
 // merge the chunk partials in index order, apply the acceptance rule (ORBmatcher.cc:230-232)
 // and histogram the rotation bin (:238-248)
 __global__ __launch_bounds__(256) void k_match_accept(MatchIO q, MatchIO t, int qslot0, int tslot0, int nchunks,

@@ -63,7 +63,7 @@ static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 // ------------------------------------------------------------------ profiling
 enum ProfId { P_H2D = 0, P_RESIZE, P_FAST, P_DISTRIBUTE, P_BLUR, P_ORIENT_DESC, P_MATCH_BEST2, P_MATCH_ACCEPT, P_MATCH_PRUNE, P_D2H, P_COUNT };
 static const char* kProfNames[P_COUNT] = {"h2d", "k_pyramid", "k_fast", "k_distribute", "k_blur",
-                                          "k_orient_desc", "k_match_best2", "k_match_accept", "k_match_prune", "d2h"};
+                                          "k_orient_desc", "k_match_mfma", "k_match_accept", "k_match_prune", "d2h"};
 struct ProfSpan { int id; hipEvent_t a, b; };
 
 struct Profiler {
@@ -169,6 +169,8 @@ struct orbx_handle {
     int32_t* d_hist = nullptr;           // [maxB][32]
     int32_t* d_nmatch = nullptr;         // [maxB]
     uint2* d_partial = nullptr;          // [maxB][kMatchChunks][maxKp] chunk partials of the brute-force scan
+    uint8_t* d_xdesc = nullptr;          // [maxB + 1] slots of +-1 byte descriptors in MFMA tile order (k_expand_desc)
+    int64_t xPitch = 0;
     uint8_t* h_pinned = nullptr; size_t pinnedBytes = 0;
     int lastB = 0;
     FrameSrc lastSrc{};
@@ -465,7 +467,7 @@ static void free_device(orbx_handle* h)
     h->prof.destroy();
     void* ptrs[] = {h->d_distScratch, h->d_pyrRanges, h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
                     h->d_candCount, h->d_cellCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
-                    h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial};
+                    h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial, h->d_xdesc};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
@@ -552,6 +554,9 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_hist, B * 32 * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_nmatch, B * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_partial, B * kMatchChunks * h->maxKp * sizeof(uint2)));
+    h->xPitch = (int64_t)align_up(h->maxKp, orbm::kMfmaRowsPerBlock) * 256;
+    CRT(hipMalloc(&h->d_xdesc, (B + 1) * (size_t)h->xPitch));
+    CRT(hipMemset(h->d_xdesc, 0, (B + 1) * (size_t)h->xPitch));
     CRT(hipMemset(h->d_err, 0, sizeof(int32_t)));
     CRT(hipMemset(h->d_count, 0, (B + 1) * sizeof(int32_t)));
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
@@ -968,11 +973,16 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     HIPCHK(hipStreamWaitEvent(s, h->evDesc, 0));
     orbm::MatchIO io = slots_io(h);
     h->prof.begin(P_MATCH_BEST2, s);
-    hipLaunchKernelGGL(orbm::k_match_best2, dim3((h->maxKp + 255) / 256, B, kMatchChunks), dim3(256), 0, s, io, io, 1, 0,
-                       kMatchChunks, h->d_partial, (int64_t)h->maxKp);
+    // slots 0..B expanded to +-1 bytes, then the Hamming scan as an int8 MFMA product (train slot f, query slot f+1)
+    hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(h->xPitch / 4096), B + 1), dim3(256), 0, s, io, 0, 0, h->d_xdesc, h->xPitch);
+    {
+        const int nqb = (h->maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
+        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, s, (const uint8_t*)h->d_xdesc, h->xPitch,
+                           (const int32_t*)h->d_count, 1, 0, h->d_partial, (int64_t)h->maxKp, nqb, B);
+    }
     h->prof.end(s);
     h->prof.begin(P_MATCH_ACCEPT, s);
-    hipLaunchKernelGGL(orbm::k_match_accept, dim3((h->maxKp + 255) / 256, B), dim3(256), 0, s, io, io, 1, 0, kMatchChunks,
+    hipLaunchKernelGGL(orbm::k_match_accept, dim3((h->maxKp + 255) / 256, B), dim3(256), 0, s, io, io, 1, 0, 1,
                        (const uint2*)h->d_partial, (int64_t)h->maxKp, nnratio, th_low, check_ori, h->d_match,
                        (int64_t)h->maxKp, h->d_binOf, h->d_hist);
     h->prof.end(s);
@@ -1159,9 +1169,20 @@ extern "C" int orbm_match_bruteforce(orbm_t* h, const uint8_t* qdesc, const floa
     orbm::MatchIO t{(const uint8_t*)h->d_buf[1], 0, (const float*)h->d_buf[3], 0, 1, (const int32_t*)h->d_buf[4] + 1};
     int32_t* d_hist = (int32_t*)h->d_buf[7];
     if ((rc = orbm_reserve(h, 8, (size_t)nq * kMatchChunks * sizeof(uint2)))) return rc;
-    hipLaunchKernelGGL(orbm::k_match_best2, dim3((nq + 255) / 256, 1, kMatchChunks), dim3(256), 0, s, q, t, 0, 0, kMatchChunks,
-                       (uint2*)h->d_buf[8], (int64_t)nq);
-    hipLaunchKernelGGL(orbm::k_match_accept, dim3((nq + 255) / 256, 1), dim3(256), 0, s, q, t, 0, 0, kMatchChunks,
+    const bool mfma = nt < 65536;  // the MFMA scan packs the train index into 16 bits of its key
+    if (mfma) {
+        const int64_t xPitch = (int64_t)align_up(std::max(nq, nt), orbm::kMfmaRowsPerBlock) * 256;
+        if ((rc = orbm_reserve(h, 9, (size_t)2 * xPitch))) return rc;
+        hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(xPitch / 4096), 1), dim3(256), 0, s, q, 0, 0, (uint8_t*)h->d_buf[9], xPitch);
+        hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(xPitch / 4096), 1), dim3(256), 0, s, t, 0, 1, (uint8_t*)h->d_buf[9], xPitch);
+        const int nqb = (nq + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
+        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * nqb), dim3(256), 0, s, (const uint8_t*)h->d_buf[9], xPitch,
+                           (const int32_t*)h->d_buf[4], 0, 1, (uint2*)h->d_buf[8], (int64_t)nq, nqb, 1);
+    } else {
+        hipLaunchKernelGGL(orbm::k_match_best2, dim3((nq + 255) / 256, 1, kMatchChunks), dim3(256), 0, s, q, t, 0, 0, kMatchChunks,
+                           (uint2*)h->d_buf[8], (int64_t)nq);
+    }
+    hipLaunchKernelGGL(orbm::k_match_accept, dim3((nq + 255) / 256, 1), dim3(256), 0, s, q, t, 0, 0, mfma ? 1 : kMatchChunks,
                        (const uint2*)h->d_buf[8], (int64_t)nq, nnratio, th_low, check_ori, (int32_t*)h->d_buf[5],
                        (int64_t)nq, (uint8_t*)h->d_buf[6], d_hist);
     hipLaunchKernelGGL(orbm::k_match_prune, dim3(1), dim3(256), 0, s, q, 0, check_ori, (int32_t*)h->d_buf[5], (int64_t)nq,
