@@ -183,17 +183,27 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
         for (int r = 0; r < 16; r++) best[qb][r] = second[qb][r] = 0x7FFFFFFF;
 
     const int ntiles = (nt + 31) >> 5;
-    // train tiles: prefetch distance 2 through registers (ga: even tiles, gb: odd tiles), LDS ring of 3
-    uint4 ga0, ga1, gb0, gb1;
+    // train tiles: prefetch distance 2 through registers (ga: even tiles, gb: odd tiles), LDS ring of 3.  The
+    // loads and their counted waits are inline asm: hipcc cannot count vmcnt across the loop back-edge and
+    // would drain the newest prefetch with vmcnt(0) at every LDS store.  Every step issues exactly two loads
+    // (past the end: the last tile again), so "vmcnt(2)" always means "everything but the newest pair".
+    v4i ga0, ga1, gb0, gb1;
+    auto fetch = [&](int tile, v4i& r0, v4i& r1) {
+        const uint4* p = tsrc + (int64_t)min(tile, max(ntiles - 1, 0)) * 512 + tid;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r0) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r1) : "v"(p + 256) : "memory");
+    };
+    // (tied to the last key of the tile so that the wait stays behind the tile's arithmetic)
+    auto landed = [&](v4i& r0, v4i& r1, int& after) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(r0), "+v"(r1), "+v"(after) :: "memory"); };
     if (ntiles > 0) { tileB[0][tid] = tsrc[tid]; tileB[0][tid + 256] = tsrc[tid + 256]; }
-    if (ntiles > 1) { gb0 = tsrc[512 + tid]; gb1 = tsrc[512 + tid + 256]; }
     // queries negated (+-1 bytes: x ^ 0xFE), so the accumulator is -(a . b) = 2 * Hamming - 256 and the key is one
-    // v_lshl_add; using the fragments here also keeps their load waits out of the loop, where they would drain
-    // the prefetch
+    // v_lshl_add; using the fragments here also retires their loads before the asm loads start counting
 #pragma unroll
     for (int qb = 0; qb < 2; qb++)
 #pragma unroll
         for (int s = 0; s < 8; s++) A[qb][s] ^= (int)0xFEFEFEFE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fetch(1, gb0, gb1);
     __syncthreads();
 
     auto tile_step = [&](int t, int slot) {
@@ -223,19 +233,22 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
     int slot = 0;  // ring slot of tile t
     for (int t = 0; t < ntiles; t += 2) {
         // even tile t: fetch t+2 into ga, compute t, park t+1 (gb) in the ring
-        if (t + 2 < ntiles) { ga0 = tsrc[(t + 2) * 512 + tid]; ga1 = tsrc[(t + 2) * 512 + tid + 256]; }
+        fetch(t + 2, ga0, ga1);
         tile_step(t, slot);
         const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-        if (t + 1 < ntiles) { tileB[s1][tid] = gb0; tileB[s1][tid + 256] = gb1; }
+        landed(gb0, gb1, second[1][15]);
+        ((v4i*)tileB[s1])[tid] = gb0; ((v4i*)tileB[s1])[tid + 256] = gb1;
         __syncthreads();
         if (t + 1 >= ntiles) break;
         // odd tile t+1: fetch t+3 into gb, compute t+1, park t+2 (ga)
-        if (t + 3 < ntiles) { gb0 = tsrc[(t + 3) * 512 + tid]; gb1 = tsrc[(t + 3) * 512 + tid + 256]; }
+        fetch(t + 3, gb0, gb1);
         tile_step(t + 1, s1);
-        if (t + 2 < ntiles) { tileB[s2][tid] = ga0; tileB[s2][tid + 256] = ga1; }
+        landed(ga0, ga1, second[1][15]);
+        ((v4i*)tileB[s2])[tid] = ga0; ((v4i*)tileB[s2])[tid + 256] = ga1;
         __syncthreads();
         slot = s2;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // merge the 32 residue classes of every query row (lanes of one half-wave), then one lane per row writes
 #pragma unroll
