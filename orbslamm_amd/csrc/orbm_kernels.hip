@@ -108,6 +108,38 @@ __global__ __launch_bounds__(256) void k_match_best2(MatchIO q, MatchIO t, int q
     partial[((int64_t)f * nchunks + chunk) * pitch + qi] = r;
 }
 
+// acceptance rule (ORBmatcher.cc:230-232) + rotation histogram (:238-248) for one query, given its merged
+// keys k1 = best << 20 | index (0xFFFFFFFF: none), k2 = second << 20 | ...
+struct AcceptArgs {
+    MatchIO q, t;
+    int qslot0, tslot0;
+    float nnratio;
+    int thLow, checkOri;
+    int32_t* match;
+    int64_t matchPitch;
+    uint8_t* binOf;
+    int32_t* hist;
+};
+__device__ __forceinline__ void accept_one(const AcceptArgs& a, int f, int qi, uint32_t k1, uint32_t k2)
+{
+    int m = -1;
+    if (k1 != 0xFFFFFFFFu) {
+        const int best1 = (int)(k1 >> 20), bestIdx = (int)(k1 & 0xFFFFFu);
+        const int best2 = k2 == 0xFFFFFFFFu ? 256 : min(256, (int)(k2 >> 20));
+        if (best1 <= a.thLow && (float)best1 < __fmul_rn(a.nnratio, (float)best2)) {
+            m = bestIdx;
+            if (a.checkOri) {
+                const float aq = a.q.ang[(int64_t)(a.qslot0 + f) * a.q.angPitch + (int64_t)qi * a.q.angStride];
+                const float at = a.t.ang[(int64_t)(a.tslot0 + f) * a.t.angPitch + (int64_t)bestIdx * a.t.angStride];
+                const int bin = rot_bin(aq, at);
+                a.binOf[(int64_t)f * a.matchPitch + qi] = (uint8_t)bin;
+                atomicAdd(&a.hist[f * 32 + bin], 1);
+            }
+        }
+    }
+    a.match[(int64_t)f * a.matchPitch + qi] = m;
+}
+
 // ------------------------------------------------------------------ brute-force scan on the matrix cores
 // The scan is a binary GEMM: with descriptors expanded to +-1 bytes, a . b = 256 - 2 * Hamming(a, b), exactly, in
 // int32.  The popcount formulation above is bound by the v_bcnt issue rate (tools/ubench/valu_rate.hip); the
@@ -153,9 +185,10 @@ constexpr int kMfmaRowsPerBlock = 256;  // 4 waves x 2 query blocks of 32
 // key = Hamming << 16 | j - 2^23 (one v_lshl_add from the negated dot product), so signed min = best with the
 // lowest index on ties (the reference scans j ascending with strict <) and med3(best, key, second) = new second.
 __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict__ xdesc, int64_t xPitch,
-                                                      const int32_t* __restrict__ count, int qslot0, int tslot0,
-                                                      uint2* __restrict__ partial, int64_t pitch, int nqb, int nframes)
+                                                      AcceptArgs acc, int nqb, int nframes)
 {
+    const int32_t* __restrict__ count = acc.q.count;  // q.count and t.count index the same slot table here
+    const int qslot0 = acc.qslot0, tslot0 = acc.tslot0;
     __shared__ uint4 tileB[3][512];
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, so the query blocks of one frame
     // pair are given to one XCD and share that frame's train tiles in its L2
@@ -250,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // merge the 32 residue classes of every query row (lanes of one half-wave), then one lane per row writes
+    // merge the 32 residue classes of every query row (lanes of one half-wave); lane l keeps the row of
+    // (query block (l >> 4) & 1, accumulator element l & 15), so the acceptance rule runs once, on all 64 lanes
+    int myB = 0x7FFFFFFF, myS = 0x7FFFFFFF;
 #pragma unroll
     for (int qb = 0; qb < 2; qb++)
 #pragma unroll
@@ -262,30 +297,27 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
                 s2 = min(max(b, ob), min(s2, os));
                 b = min(b, ob);
             }
-            if ((lane & 31) == r) {
-                const int qi = q0 + wave * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (qi < nq) {
-                    const uint32_t h1 = (uint32_t)(b + (1 << 23)) >> 16, h2 = (uint32_t)(s2 + (1 << 23)) >> 16;
-                    uint2 o;
-                    o.x = h1 >= 256u ? 0xFFFFFFFFu : ((h1 << 20) | ((uint32_t)b & 0xFFFFu));
-                    o.y = ((h2 >= 256u ? 256u : h2) << 20) | 0xFFFFFu;
-                    partial[(int64_t)f * pitch + qi] = o;
-                }
-            }
+            if ((lane & 31) == qb * 16 + r) { myB = b; myS = s2; }
         }
+    {
+        const int qb = (lane >> 4) & 1, r = lane & 15;
+        const int qi = q0 + wave * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (qi < nq) {
+            const uint32_t h1 = (uint32_t)(myB + (1 << 23)) >> 16, h2 = (uint32_t)(myS + (1 << 23)) >> 16;
+            const uint32_t k1 = h1 >= 256u ? 0xFFFFFFFFu : ((h1 << 20) | ((uint32_t)myB & 0xFFFFu));
+            const uint32_t k2 = ((h2 >= 256u ? 256u : h2) << 20) | 0xFFFFFu;
+            accept_one(acc, f, qi, k1, k2);
+        }
+    }
 }
 
 // merge the chunk partials in index order, apply the acceptance rule (ORBmatcher.cc:230-232)
 // and histogram the rotation bin (:238-248)
-__global__ __launch_bounds__(256) void k_match_accept(MatchIO q, MatchIO t, int qslot0, int tslot0, int nchunks,
-                                                     const uint2* __restrict__ partial, int64_t pitch,
-                                                     float nnratio, int thLow, int checkOri,
-                                                     int32_t* __restrict__ match, int64_t matchPitch,
-                                                     uint8_t* __restrict__ binOf, int32_t* __restrict__ hist)
+__global__ __launch_bounds__(256) void k_match_accept(AcceptArgs a, int nchunks, const uint2* __restrict__ partial, int64_t pitch)
 {
     const int f = blockIdx.y;
     const int qi = blockIdx.x * 256 + threadIdx.x;
-    const int nq = q.count[qslot0 + f];
+    const int nq = a.q.count[a.qslot0 + f];
     if (qi >= nq) return;
     uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
     for (int c = 0; c < nchunks; c++) {
@@ -294,22 +326,7 @@ __global__ __launch_bounds__(256) void k_match_accept(MatchIO q, MatchIO t, int 
         k2 = min(hi, min(k2, p.y));
         k1 = lo;
     }
-    int m = -1;
-    if (k1 != 0xFFFFFFFFu) {
-        const int best1 = (int)(k1 >> 20), bestIdx = (int)(k1 & 0xFFFFFu);
-        const int best2 = k2 == 0xFFFFFFFFu ? 256 : min(256, (int)(k2 >> 20));
-        if (best1 <= thLow && (float)best1 < __fmul_rn(nnratio, (float)best2)) {
-            m = bestIdx;
-            if (checkOri) {
-                const float aq = q.ang[(int64_t)(qslot0 + f) * q.angPitch + (int64_t)qi * q.angStride];
-                const float at = t.ang[(int64_t)(tslot0 + f) * t.angPitch + (int64_t)bestIdx * t.angStride];
-                const int bin = rot_bin(aq, at);
-                binOf[(int64_t)f * matchPitch + qi] = (uint8_t)bin;
-                atomicAdd(&hist[f * 32 + bin], 1);
-            }
-        }
-    }
-    match[(int64_t)f * matchPitch + qi] = m;
+    accept_one(a, f, qi, k1, k2);
 }
 
 // ComputeThreeMaxima + pruning, one workgroup per frame; leaves hist zeroed for the next call

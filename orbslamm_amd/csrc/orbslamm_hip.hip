@@ -974,17 +974,13 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     orbm::MatchIO io = slots_io(h);
     h->prof.begin(P_MATCH_BEST2, s);
     // slots 0..B expanded to +-1 bytes, then the Hamming scan as an int8 MFMA product (train slot f, query slot f+1)
+    // with the acceptance rule in its epilogue
     hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(h->xPitch / 4096), B + 1), dim3(256), 0, s, io, 0, 0, h->d_xdesc, h->xPitch);
     {
         const int nqb = (h->maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
-        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, s, (const uint8_t*)h->d_xdesc, h->xPitch,
-                           (const int32_t*)h->d_count, 1, 0, h->d_partial, (int64_t)h->maxKp, nqb, B);
+        const orbm::AcceptArgs aa = {io, io, 1, 0, nnratio, th_low, check_ori, h->d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist};
+        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, s, (const uint8_t*)h->d_xdesc, h->xPitch, aa, nqb, B);
     }
-    h->prof.end(s);
-    h->prof.begin(P_MATCH_ACCEPT, s);
-    hipLaunchKernelGGL(orbm::k_match_accept, dim3((h->maxKp + 255) / 256, B), dim3(256), 0, s, io, io, 1, 0, 1,
-                       (const uint2*)h->d_partial, (int64_t)h->maxKp, nnratio, th_low, check_ori, h->d_match,
-                       (int64_t)h->maxKp, h->d_binOf, h->d_hist);
     h->prof.end(s);
     h->prof.begin(P_MATCH_PRUNE, s);
     hipLaunchKernelGGL(orbm::k_match_prune, dim3(B), dim3(256), 0, s, io, 1, check_ori, h->d_match, (int64_t)h->maxKp,
@@ -1170,21 +1166,22 @@ extern "C" int orbm_match_bruteforce(orbm_t* h, const uint8_t* qdesc, const floa
     int32_t* d_hist = (int32_t*)h->d_buf[7];
     if ((rc = orbm_reserve(h, 8, (size_t)nq * kMatchChunks * sizeof(uint2)))) return rc;
     const bool mfma = nt < 65536;  // the MFMA scan packs the train index into 16 bits of its key
+    orbm::AcceptArgs aa = {q, t, 0, 0, nnratio, th_low, check_ori, (int32_t*)h->d_buf[5], (int64_t)nq, (uint8_t*)h->d_buf[6], d_hist};
     if (mfma) {
         const int64_t xPitch = (int64_t)align_up(std::max(nq, nt), orbm::kMfmaRowsPerBlock) * 256;
         if ((rc = orbm_reserve(h, 9, (size_t)2 * xPitch))) return rc;
         hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(xPitch / 4096), 1), dim3(256), 0, s, q, 0, 0, (uint8_t*)h->d_buf[9], xPitch);
         hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(xPitch / 4096), 1), dim3(256), 0, s, t, 0, 1, (uint8_t*)h->d_buf[9], xPitch);
+        // slot table {nq, nt}: query slot 0, train slot 1 (angles keep their own slot 0 via pitch 0)
+        orbm::AcceptArgs am = aa;
+        am.tslot0 = 1;
         const int nqb = (nq + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
-        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * nqb), dim3(256), 0, s, (const uint8_t*)h->d_buf[9], xPitch,
-                           (const int32_t*)h->d_buf[4], 0, 1, (uint2*)h->d_buf[8], (int64_t)nq, nqb, 1);
+        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * nqb), dim3(256), 0, s, (const uint8_t*)h->d_buf[9], xPitch, am, nqb, 1);
     } else {
         hipLaunchKernelGGL(orbm::k_match_best2, dim3((nq + 255) / 256, 1, kMatchChunks), dim3(256), 0, s, q, t, 0, 0, kMatchChunks,
                            (uint2*)h->d_buf[8], (int64_t)nq);
+        hipLaunchKernelGGL(orbm::k_match_accept, dim3((nq + 255) / 256, 1), dim3(256), 0, s, aa, kMatchChunks, (const uint2*)h->d_buf[8], (int64_t)nq);
     }
-    hipLaunchKernelGGL(orbm::k_match_accept, dim3((nq + 255) / 256, 1), dim3(256), 0, s, q, t, 0, 0, mfma ? 1 : kMatchChunks,
-                       (const uint2*)h->d_buf[8], (int64_t)nq, nnratio, th_low, check_ori, (int32_t*)h->d_buf[5],
-                       (int64_t)nq, (uint8_t*)h->d_buf[6], d_hist);
     hipLaunchKernelGGL(orbm::k_match_prune, dim3(1), dim3(256), 0, s, q, 0, check_ori, (int32_t*)h->d_buf[5], (int64_t)nq,
                        (const uint8_t*)h->d_buf[6], d_hist, d_hist + 32);
     HIPCHK(hipGetLastError());
