@@ -54,6 +54,42 @@ def test_bruteforce_ties_first_wins(gm, oracle):
     assert got[0] == -1 and got[1] == 10  # 0 < 0.7*0 fails for the duplicate
 
 
+@pytest.mark.parametrize("nq,nt", [(31, 31), (32, 32), (33, 33), (63, 65), (64, 64), (255, 97), (256, 256), (257, 96), (513, 31)])
+def test_bruteforce_tile_boundaries(gm, oracle, nq, nt):
+    """the matrix-core scan works on blocks of 32 trains / 64 queries per wave: sizes around those edges,
+    with duplicates planted in different tiles (lowest index wins, equal second blocks the ratio test)"""
+    rng = np.random.default_rng(1000 * nq + nt)
+    base = random_descriptors(rng, max(nq, nt))
+    t = base[:nt].copy()
+    q = noisy_copies(rng, base[rng.integers(0, nt, nq)], 9)
+    if nt > 40:
+        t[nt - 1] = t[2]          # duplicate in the last (partial) tile
+        t[37] = t[5]              # duplicate in the next tile
+        q[0] = t[2]; q[1] = t[5]; q[1, 3] ^= 4
+    q[-1] = ~t[0]                 # distance 256 to train 0
+    qa = rng.uniform(0, 360, nq).astype(np.float32)
+    ta = rng.uniform(0, 360, nt).astype(np.float32)
+    for ori in (True, False):
+        from orbslamm_amd import ORBmatcher
+        got, n = ORBmatcher(0.7, ori, device=0).match_bruteforce(q, qa, t, ta)
+        want, nw = oracle.match_bruteforce(q, qa, t, ta, 0.7, 50, ori)
+        assert n == nw and np.array_equal(got, want)
+
+
+def test_bruteforce_wide_train_fallback(gm, oracle):
+    """more than 65535 train features: the popcount scan (k_match_best2) takes over"""
+    rng = np.random.default_rng(77)
+    nt, nq = 66000, 24
+    t = random_descriptors(rng, nt)
+    q = noisy_copies(rng, t[rng.integers(0, nt, nq)], 10)
+    q[3] = t[65990]
+    qa = rng.uniform(0, 360, nq).astype(np.float32)
+    ta = rng.uniform(0, 360, nt).astype(np.float32)
+    got, n = gm.match_bruteforce(q, qa, t, ta)
+    want, nw = oracle.match_bruteforce(q, qa, t, ta, 0.7, 50, True)
+    assert n == nw and np.array_equal(got, want) and got[3] == 65990
+
+
 @pytest.mark.parametrize("by_train", [True, False])
 @pytest.mark.parametrize("nq,nt,nnodes,ratio", [(400, 450, 23, 0.75), (2000, 2000, 97, 0.7), (300, 300, 1, 0.9), (50, 700, 5, 0.6)])
 def test_search_by_bow_parity(gpu, oracle, by_train, nq, nt, nnodes, ratio):
