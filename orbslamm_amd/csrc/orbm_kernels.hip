@@ -169,12 +169,8 @@ __global__ __launch_bounds__(256) void k_expand_desc(MatchIO io, int slot0, int 
     ((uint4*)(xdesc + (int64_t)(xslot0 + blockIdx.y) * xPitch))[t] = o;
 }
 
-__device__ __forceinline__ int med3i(int a, int b, int c)
-{
-    int o;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
-    return o;
-}
+// median of three in the form the backend selects as v_med3_i32 (IntMed3Pat)
+__device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int kMfmaRowsPerBlock = 256;  // 4 waves x 2 query blocks of 32
