@@ -824,19 +824,24 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// 128x32 output tile per 256-thread block.  Global traffic is aligned dwords (byte
+// 120x32 output tile per 256-thread block.  Global traffic is aligned dwords (byte
 // path only where a dword straddles the image border); every thread owns 4 adjacent
 // pixels in both passes, so LDS is read as b32/b64 and the result leaves as one dword.
-constexpr int kBlurTW = 128, kBlurTH = 32;
+constexpr int kBlurTW = 120, kBlurTH = 32;
 
+// 7x7 Gaussian as two exact integer passes on the dot-product units.  The separable sum has no intermediate
+// rounding, so the pass order is free: the VERTICAL pass runs first, on bytes (v_dot4_u32_u8 over 4x4 byte
+// transposes of the input dwords; row sums <= 257*255 fit 16 bits), the horizontal pass then works on the
+// 16-bit sums, whose horizontally adjacent pairs are naturally packed for v_dot2_u32_u16.
+// Tile: 120 x 32 outputs; input 128 x 38 (4 px / 3 rows of halo, dword aligned).
 __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt)
 {
     constexpr int TW = kBlurTW, TH = kBlurTH;
-    constexpr int IN_DW = (TW + 8) / 4;       // 34 dwords per input row (4 px margin each side)
-    constexpr int IN_STRIDE = IN_DW + 1;      // 35
-    constexpr int RP_STRIDE = TW / 2 + 2;     // 66 dwords (u16 pairs), even for b64 reads
+    constexpr int IN_DW = (TW + 8) / 4;       // 32 dwords per input row (4 px margin each side)
+    constexpr int IN_STRIDE = IN_DW + 1;      // 33
+    constexpr int VS_STRIDE = IN_DW * 2 + 2;  // 66 dwords of u16 pairs per row, even for b64 access
     __shared__ uint32_t in[(TH + 6) * IN_STRIDE];
-    __shared__ uint32_t rp[(TH + 6) * RP_STRIDE];
+    __shared__ uint32_t vs[TH * VS_STRIDE];
     const int f = blockIdx.y + src.f0;
     int l = 0;
     while (l + 1 < g->nlevels && (int)blockIdx.x >= bt.base[l + 1]) l++;
@@ -848,7 +853,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     const uint8_t* S = level_ptr(g, src, f, l, stride);
     const int tid = threadIdx.x;
 
-    // (TH+6)*IN_DW = 1292 dwords: 6 per thread, all loads issued before the first LDS store
+    // (TH+6)*IN_DW = 1216 dwords: 5 per thread, all loads issued before the first LDS store
     {
         constexpr int N = (TH + 6) * IN_DW, PER = (N + 255) / 256;
         uint32_t regs[PER];
@@ -883,58 +888,69 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     }
     __syncthreads();
 
-    const int xq = tid & 31, yr = tid >> 5;
-    for (int r = yr; r < TH + 6; r += 8) {
-        const uint32_t d0 = in[r * IN_STRIDE + xq], d1 = in[r * IN_STRIDE + xq + 1], d2 = in[r * IN_STRIDE + xq + 2];
-        uint32_t b[12];
+    // vertical pass: thread = (dword column c, group of 4 output rows); rows 4rg .. 4rg+9 of the input tile
+    {
+        constexpr uint32_t KA = 18u | (34u << 8) | (49u << 16) | (55u << 24), KB = 49u | (34u << 8) | (18u << 16);
+        const int c = tid & 31, rg = tid >> 5;
+        uint32_t R[12];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            b[k] = (d0 >> (8 * k)) & 0xFF;
-            b[4 + k] = (d1 >> (8 * k)) & 0xFF;
-            b[8 + k] = (d2 >> (8 * k)) & 0xFF;
+        for (int k = 0; k < 10; k++) R[k] = in[(4 * rg + k) * IN_STRIDE + c];
+        R[10] = R[11] = 0;
+        uint32_t T[3][4];  // T[b][j] = column j of rows 4b .. 4b+3, one byte per row
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const uint32_t lo01 = __builtin_amdgcn_perm(R[4 * b + 1], R[4 * b], 0x05010400u);      // r0.b0 r1.b0 r0.b1 r1.b1
+            const uint32_t hi01 = __builtin_amdgcn_perm(R[4 * b + 1], R[4 * b], 0x07030602u);      // r0.b2 r1.b2 r0.b3 r1.b3
+            const uint32_t lo23 = __builtin_amdgcn_perm(R[4 * b + 3], R[4 * b + 2], 0x05010400u);
+            const uint32_t hi23 = __builtin_amdgcn_perm(R[4 * b + 3], R[4 * b + 2], 0x07030602u);
+            T[b][0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);  // low halves
+            T[b][1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);  // high halves
+            T[b][2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+            T[b][3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
         }
-        uint32_t o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++)  // <= 257*255 = 65535
-            o[i] = 18 * (b[1 + i] + b[7 + i]) + 34 * (b[2 + i] + b[6 + i]) + 49 * (b[3 + i] + b[5 + i]) + 55 * b[4 + i];
-        uint2 st;
-        st.x = o[0] | (o[1] << 16);
-        st.y = o[2] | (o[3] << 16);
-        *(uint2*)&rp[r * RP_STRIDE + 2 * xq] = st;
+        for (int y = 0; y < 4; y++) {
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t wa = y == 0 ? T[0][j] : __builtin_amdgcn_alignbyte(T[1][j], T[0][j], y);
+                const uint32_t wb = y == 0 ? T[1][j] : __builtin_amdgcn_alignbyte(T[2][j], T[1][j], y);
+                o[j] = __builtin_amdgcn_udot4(wb, KB, __builtin_amdgcn_udot4(wa, KA, 0u, false), false);  // <= 65535
+            }
+            uint2 st;
+            st.x = o[0] | (o[1] << 16);
+            st.y = o[2] | (o[3] << 16);
+            *(uint2*)&vs[(4 * rg + y) * VS_STRIDE + 2 * c] = st;
+        }
     }
     __syncthreads();
 
-    uint32_t acc[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc[j][i] = 1u << 15;
-    constexpr uint32_t K[7] = {18, 34, 49, 55, 49, 34, 18};
-#pragma unroll
-    for (int rr = 0; rr < 10; rr++) {
-        const uint2 v = *(const uint2*)&rp[(yr * 4 + rr) * RP_STRIDE + 2 * xq];
-        const uint32_t e[4] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int tap = rr - j;
-            if (tap >= 0 && tap < 7) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc[j][i] += K[tap] * e[i];
-            }
-        }
-    }
+    // horizontal pass on the 16-bit sums: item = (output dword column cq, row); outputs x = tx0 + 4cq + i are
+    // columns 4cq + 4 + i of vs and need a[i+1] .. a[i+7] of a[k] = vs column 4cq + k
+    typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
     uint8_t* D = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff;
-    const int x = tx0 + 4 * xq;
+    for (int item = tid; item < (TW / 4) * TH; item += 256) {
+        const int row = item / (TW / 4), cq = item - row * (TW / 4);
+        const uint2* pr = (const uint2*)&vs[row * VS_STRIDE + 2 * cq];
+        const uint2 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+        const uint32_t P[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};  // P[m] = (a[2m], a[2m+1])
+        uint32_t O[5];                                                // O[m] = (a[2m+1], a[2m+2])
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int y = ty0 + yr * 4 + j;
+        for (int m = 0; m < 5; m++) O[m] = __builtin_amdgcn_alignbyte(P[m + 1], P[m], 2);
+        auto dot = [](uint32_t p, uint32_t k, uint32_t c) {
+            return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p), __builtin_bit_cast(v2u16, k), c, false);
+        };
+        constexpr uint32_t K0 = 18u | (34u << 16), K1 = 49u | (55u << 16), K2 = 49u | (34u << 16), K3 = 18u;
+        uint32_t r4[4];
+        r4[0] = dot(O[3], K3, dot(O[2], K2, dot(O[1], K1, dot(O[0], K0, 1u << 15))));
+        r4[1] = dot(P[4], K3, dot(P[3], K2, dot(P[2], K1, dot(P[1], K0, 1u << 15))));
+        r4[2] = dot(O[4], K3, dot(O[3], K2, dot(O[2], K1, dot(O[1], K0, 1u << 15))));
+        r4[3] = dot(P[5], K3, dot(P[4], K2, dot(P[3], K1, dot(P[2], K0, 1u << 15))));
+        const int x = tx0 + 4 * cq, y = ty0 + row;
         if (x < w && y < h) {
             uint32_t pk = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t sv = acc[j][i] >> 16;
-                pk |= (sv > 255u ? 255u : sv) << (8 * i);
-            }
+            for (int i = 0; i < 4; i++) pk |= min(r4[i] >> 16, 255u) << (8 * i);
             *(uint32_t*)(D + (int64_t)y * L.blurStride + x) = pk;
         }
     }
