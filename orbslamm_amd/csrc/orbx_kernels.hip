@@ -853,38 +853,39 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     const uint8_t* S = level_ptr(g, src, f, l, stride);
     const int tid = threadIdx.x;
 
-    // (TH+6)*IN_DW = 1216 dwords: 5 per thread, all loads issued before the first LDS store
+    // (TH+6)*IN_DW = 1216 dwords, 5 per thread (rows tid/32 + 8k of dword column tid%32), all loads issued
+    // before the first LDS store.  Tiles that touch no image border (block-uniform test) skip the reflection.
     {
-        constexpr int N = (TH + 6) * IN_DW, PER = (N + 255) / 256;
+        constexpr int PER = (TH + 6 + 7) / 8;
+        const int c = tid & 31, r0 = tid >> 5;
+        const int x0 = tx0 - 4 + 4 * c;
         uint32_t regs[PER];
-        bool edge[PER];
+        if (tx0 >= 4 && tx0 + TW + 4 <= w && ty0 >= 3 && ty0 + TH + 3 <= h) {
+            const uint8_t* p = S + (int64_t)(ty0 - 3 + r0) * stride + x0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int i = min(tid + 256 * k, N - 1);
-            const int r = i / IN_DW, c = i - r * IN_DW;
-            const int sy = reflect101(ty0 + r - 3, h);
-            const int x0 = tx0 - 4 + 4 * c;
-            edge[k] = !(x0 >= 0 && x0 + 3 < w);
+            for (int k = 0; k < PER; k++) regs[k] = *(const uint32_t*)(p + (int64_t)min(8 * k, TH + 5 - r0) * stride);
+        } else {
+            const bool edge = !(x0 >= 0 && x0 + 3 < w);
             const int xs = min(max(x0, 0), (w - 1) & ~3);   // valid aligned address for every lane
-            regs[k] = *(const uint32_t*)(S + (int64_t)sy * stride + xs);
-        }
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int i = tid + 256 * k;
-            if (i < N) {
-                const int r = i / IN_DW, c = i - r * IN_DW;
-                uint32_t v = regs[k];
-                if (edge[k]) {  // dword straddles the image border: reflect byte by byte
-                    const int sy = reflect101(ty0 + r - 3, h);
-                    const int x0 = tx0 - 4 + 4 * c;
-                    const uint8_t* row = S + (int64_t)sy * stride;
-                    v = 0;
+            for (int k = 0; k < PER; k++) {
+                const int sy = reflect101(ty0 + min(r0 + 8 * k, TH + 5) - 3, h);
+                regs[k] = *(const uint32_t*)(S + (int64_t)sy * stride + xs);
+            }
+            if (edge) {  // dword straddles the image border: reflect byte by byte
+#pragma unroll
+                for (int k = 0; k < PER; k++) {
+                    const uint8_t* row = S + (int64_t)reflect101(ty0 + min(r0 + 8 * k, TH + 5) - 3, h) * stride;
+                    uint32_t v = 0;
 #pragma unroll
                     for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(x0 + b, w)] << (8 * b);
+                    regs[k] = v;
                 }
-                in[r * IN_STRIDE + c] = v;
             }
         }
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (r0 + 8 * k < TH + 6) in[(r0 + 8 * k) * IN_STRIDE + c] = regs[k];
     }
     __syncthreads();
 
@@ -925,20 +926,24 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     }
     __syncthreads();
 
-    // horizontal pass on the 16-bit sums: item = (output dword column cq, row); outputs x = tx0 + 4cq + i are
-    // columns 4cq + 4 + i of vs and need a[i+1] .. a[i+7] of a[k] = vs column 4cq + k
+    // horizontal pass on the 16-bit sums: thread = (output dword column cq < 30, rows rq + 8k); outputs
+    // x = tx0 + 4cq + i are columns 4cq + 4 + i of vs and need a[i+1] .. a[i+7] of a[k] = vs column 4cq + k
     typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
-    uint8_t* D = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff;
-    for (int item = tid; item < (TW / 4) * TH; item += 256) {
-        const int row = item / (TW / 4), cq = item - row * (TW / 4);
-        const uint2* pr = (const uint2*)&vs[row * VS_STRIDE + 2 * cq];
-        const uint2 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+    const int cq = tid & 31, rq = tid >> 5;
+    const int x = tx0 + 4 * cq;
+    if (cq >= TW / 4 || x >= w) return;
+    uint8_t* D = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)(ty0 + rq) * L.blurStride + x;
+    const uint2* pr = (const uint2*)&vs[rq * VS_STRIDE + 2 * cq];
+    const int nrows = min(TH, h - ty0);
+#pragma unroll
+    for (int k = 0; k < TH / 8; k++) {
+        const uint2 q0 = pr[k * 4 * VS_STRIDE], q1 = pr[k * 4 * VS_STRIDE + 1], q2 = pr[k * 4 * VS_STRIDE + 2];
         const uint32_t P[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};  // P[m] = (a[2m], a[2m+1])
         uint32_t O[5];                                                // O[m] = (a[2m+1], a[2m+2])
 #pragma unroll
         for (int m = 0; m < 5; m++) O[m] = __builtin_amdgcn_alignbyte(P[m + 1], P[m], 2);
-        auto dot = [](uint32_t p, uint32_t k, uint32_t c) {
-            return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p), __builtin_bit_cast(v2u16, k), c, false);
+        auto dot = [](uint32_t p, uint32_t kk, uint32_t c) {
+            return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p), __builtin_bit_cast(v2u16, kk), c, false);
         };
         constexpr uint32_t K0 = 18u | (34u << 16), K1 = 49u | (55u << 16), K2 = 49u | (34u << 16), K3 = 18u;
         uint32_t r4[4];
@@ -946,12 +951,11 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         r4[1] = dot(P[4], K3, dot(P[3], K2, dot(P[2], K1, dot(P[1], K0, 1u << 15))));
         r4[2] = dot(O[4], K3, dot(O[3], K2, dot(O[2], K1, dot(O[1], K0, 1u << 15))));
         r4[3] = dot(P[5], K3, dot(P[4], K2, dot(P[3], K1, dot(P[2], K0, 1u << 15))));
-        const int x = tx0 + 4 * cq, y = ty0 + row;
-        if (x < w && y < h) {
+        if (rq + 8 * k < nrows) {
             uint32_t pk = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) pk |= min(r4[i] >> 16, 255u) << (8 * i);
-            *(uint32_t*)(D + (int64_t)y * L.blurStride + x) = pk;
+            *(uint32_t*)(D + (int64_t)(8 * k) * L.blurStride) = pk;
         }
     }
 }
