@@ -451,7 +451,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
 
 static constexpr int kMatchChunks = 4;  // train chunks per query block (wave count x4)
 
-static size_t dist_lds_bytes(int cap, int maxCells) { return (size_t)(17 * cap + 8 + 2 * (maxCells + 1)) * 4; }
+static size_t dist_lds_bytes(int cap, int maxCells) { return (size_t)(19 * cap + 8 + 2 * (maxCells + 1)) * 4; }
 
 // ------------------------------------------------------------------ create / destroy
 static void free_device(orbx_handle* h)

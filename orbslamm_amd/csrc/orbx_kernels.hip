@@ -548,9 +548,9 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // candidates of this level = the per-cell segments FAST filled; prefix of the cell counts
     // in LDS turns a flat index into (cell, slot) by binary search
     const int nCells = L.nCells;
-    uint32_t* cellPref = smem + 17 * cap + 8;            // [maxCells + 1]
+    uint32_t* cellPref = smem + 19 * cap + 8;            // [maxCells + 1]
     uint32_t* cellOffs = cellPref + g->maxCellsPerLevel + 1;  // [maxCells]
-    uint32_t* wtmp0 = smem + 17 * cap;
+    uint32_t* wtmp0 = smem + 19 * cap;
     for (int i = tid; i < nCells; i += kDistThreads) {
         cellPref[i] = (uint32_t)cellCount[(int64_t)f * g->totalCells + L.cellBase + i];
         cellOffs[i] = cells[L.cellBase + i].candOff;
@@ -580,54 +580,77 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     uint32_t* tA = ord2 + cap;            // scan scratch
     uint32_t* tB = tA + cap;
     uint32_t* proc = tB + cap;            // processed flag per list index
-    uint32_t* wtmp = proc + cap;          // [8]
+    uint32_t* nk[2] = {proc + cap, proc + 2 * cap};  // depth << 24 | path code of the node
+    uint32_t* wtmp = proc + 3 * cap;      // [8]
     __shared__ int sJ;
 
-    // ---- roots (:543-585): nIni nodes, keys routed by (int)(x / hX)
+    // ---- roots (:543-585) and the first D levels below them in one counting sort.
+    // A key's way down the tree is a function of its coordinates alone: root (int)(x / hX), then at every
+    // level the quadrant against the node's midlines (:483-484).  So every key gets its path code to depth D
+    // (nIni * 4^D <= 1024 bins), one histogram + one scatter put the keys in path order, and the sums of
+    // the histogram over 4, 16, ... bins are the child counts of every node of depth < D: the first D
+    // rounds below replay the list logic on those counts and move no key at all.
+    __shared__ uint32_t hst[1368];   // levels 0..D of the histogram, level d at hoff(d) = nIni * (4^d - 1) / 3
+    __shared__ uint32_t hfill[1024]; // scatter cursors of the leaf bins
     const int nIni = L.nIni;
     const float hX = L.hX;
-    for (int i = tid; i < cap; i += kDistThreads) { tA[i] = 0; tB[i] = 0; }
+    if (nIni > 1024) { if (tid == 0) atomicOr(errFlag, 2); return; }
+    int D = 0;
+    while (D < 5 && (nIni << (2 * (D + 1))) <= 1024) D++;
+    auto hoff = [&](int d) { return nIni * (((1 << (2 * d)) - 1) / 3); };
+    const int nBins = nIni << (2 * D), hTotal = hoff(D) + nBins;
+    for (int i = tid; i < hTotal; i += kDistThreads) hst[i] = 0;
     __syncthreads();
-    {
-        // the raw FAST output stays untouched (debug dumps read it); rounds ping-pong A/B
-        const uint64_t* srcb = candRaw + (int64_t)f * g->candFrameRecs + L.candOff;
-        const uint64_t lt = lanemask_lt();
-        for (int pass = 0; pass < 2; pass++) {
-            for (int p0 = wave * 64; p0 < n; p0 += kDistThreads) {
-                const int p = p0 + lane;
-                int r = -1;
-                uint64_t key = 0;
-                if (p < n) {
-                    int lo = 0, hi = nCells;  // largest c with cellPref[c] <= p
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cellPref[mid] <= (uint32_t)p) lo = mid; else hi = mid; }
-                    key = srcb[cellOffs[lo] + (p - cellPref[lo])];
-                    r = (int)__fdiv_rn((float)cand_x(key), hX);
-                    if (r >= nIni) r = nIni - 1;
-                }
-                uint64_t todo = __ballot(r >= 0);
-                while (todo) {
-                    const int leader = __ffsll((unsigned long long)todo) - 1;
-                    const int rr = __shfl(r, leader);
-                    const uint64_t mask = __ballot(r == rr);
-                    if (pass == 0) {
-                        if (lane == leader) atomicAdd(&tA[rr], (uint32_t)__popcll(mask));
-                    } else {
-                        uint32_t bpos = 0;
-                        if (lane == leader) bpos = atomicAdd(&tB[rr], (uint32_t)__popcll(mask));
-                        bpos = __shfl(bpos, leader);
-                        if (r == rr) bufs[1][tA[rr] + bpos + __popcll(mask & lt)] = key;
-                    }
-                    todo &= ~mask;
-                }
-            }
-            __syncthreads();
-            if (pass == 0) {
-                for (int i = tid; i < nIni; i += kDistThreads) ord[i] = tA[i];  // counts
-                __syncthreads();
-                block_excl_scan(tA, nIni, wtmp);  // tA = starts
-            }
+    const uint64_t* srcb = candRaw + (int64_t)f * g->candFrameRecs + L.candOff;  // raw FAST output stays untouched
+    auto path_code = [&](uint64_t key) {
+        const int x = (int)cand_x(key), y = (int)cand_y(key);
+        int r = (int)__fdiv_rn((float)x, hX);
+        if (r >= nIni) r = nIni - 1;
+        int x0 = (short)(int)__fmul_rn(hX, (float)r), x1 = (short)(int)__fmul_rn(hX, (float)(r + 1)), y0 = 0, y1 = (short)L.winH;
+        int code = r;
+        for (int d = 0; d < D; d++) {
+            const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);
+            const int qx = x >= xm, qy = y >= ym;
+            code = code * 4 + qx + 2 * qy;
+            if (qx) x0 = xm; else x1 = xm;
+            if (qy) y0 = ym; else y1 = ym;
         }
+        return code;
+    };
+    // flat index -> (cell, slot) by binary search in the cell prefix; four keys in flight per thread
+    auto for_keys = [&](auto&& fn) {
+        constexpr int U = 4;
+        for (int p0 = tid; p0 < n; p0 += kDistThreads * U) {
+            uint64_t key[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int p = min(p0 + u * kDistThreads, n - 1);
+                int lo = 0, hi = nCells;  // largest c with cellPref[c] <= p
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cellPref[mid] <= (uint32_t)p) lo = mid; else hi = mid; }
+                key[u] = srcb[cellOffs[lo] + (p - cellPref[lo])];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (p0 + u * kDistThreads < n) fn(key[u]);
+        }
+    };
+    for_keys([&](uint64_t key) { atomicAdd(&hst[hoff(D) + path_code(key)], 1u); });
+    __syncthreads();
+    for (int d = D - 1; d >= 0; d--) {
+        const int cnt = nIni << (2 * d);
+        for (int i = tid; i < cnt; i += kDistThreads) {
+            const uint32_t* c4 = &hst[hoff(d + 1) + 4 * i];
+            hst[hoff(d) + i] = c4[0] + c4[1] + c4[2] + c4[3];
+        }
+        __syncthreads();
     }
+    for (int i = tid; i < nBins; i += kDistThreads) hfill[i] = hst[hoff(D) + i];
+    __syncthreads();
+    block_excl_scan(hfill, nBins, wtmp);
+    for_keys([&](uint64_t key) { bufs[1][atomicAdd(&hfill[path_code(key)], 1u)] = key; });
+    for (int i = tid; i < nIni; i += kDistThreads) { ord[i] = hst[i]; tA[i] = hst[i]; }  // root counts
+    __syncthreads();
+    block_excl_scan(tA, nIni, wtmp);  // tA = root starts
     // non-empty roots in order 0..nIni-1 (:572-585)
     for (int i = tid; i < nIni; i += kDistThreads) tB[i] = ord[i] > 0 ? 1u : 0u;
     __syncthreads();
@@ -642,6 +665,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
             nb[cur][pos] = make_short4((short)(int)__fmul_rn(hX, (float)i), (short)(int)__fmul_rn(hX, (float)(i + 1)), 0, (short)L.winH);
             ns[cur][pos] = tA[i];
             nc[cur][pos] = ord[i] | (1u << 31);  // keys are in buffer 1
+            nk[cur][pos] = (uint32_t)i;          // depth 0, path code = root index
         }
     }
     __syncthreads();
@@ -662,16 +686,24 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         if (careful) {
             // sort by (count desc, list position asc) == reference's (size, creation) ascending
             // sort walked from the back (:684-685, tie-break see DESIGN.md)
-            for (int e = tid; e < E; e += kDistThreads) {
-                const uint32_t i = ord[e];
-                const uint32_t ci = nc[cur][i] & 0x7FFFFFFFu;
+            // rank sort on compact (count, index) arrays; `parts` threads share one element's scan
+            for (int e = tid; e < E; e += kDistThreads) tA[e] = nc[cur][ord[e]] & 0x7FFFFFFFu;
+            __syncthreads();
+            int parts = 1;
+            while (parts < 8 && E * parts * 2 <= kDistThreads) parts *= 2;
+            for (int e0 = 0; e0 < E; e0 += kDistThreads / parts) {
+                const int e = e0 + tid / parts, sub = tid % parts;
                 int rank = 0;
-                for (int e2 = 0; e2 < E; e2++) {
-                    const uint32_t i2 = ord[e2];
-                    const uint32_t c2 = nc[cur][i2] & 0x7FFFFFFFu;
-                    rank += (c2 > ci || (c2 == ci && i2 < i)) ? 1 : 0;
+                if (e < E) {
+                    const uint32_t i = ord[e], ci = tA[e];
+                    const int per = (E + parts - 1) / parts;
+                    for (int e2 = sub * per; e2 < min(E, (sub + 1) * per); e2++) {
+                        const uint32_t c2 = tA[e2], i2 = ord[e2];
+                        rank += (c2 > ci || (c2 == ci && i2 < i)) ? 1 : 0;
+                    }
                 }
-                ord2[rank] = i;
+                for (int d = 1; d < parts; d <<= 1) rank += __shfl_xor(rank, d);
+                if (e < E && sub == 0) ord2[rank] = ord[e];
             }
             __syncthreads();
             for (int e = tid; e < E; e += kDistThreads) ord[e] = ord2[e];
@@ -699,7 +731,13 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                 const int xm = b.x + ((b.y - b.x + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  :483
                 const int ym = b.z + ((b.w - b.z + 1) >> 1);  // UL.y + ceil((BR.y-UL.y)/2)  :484
                 uint32_t c[4];
-                wave_divide(bufs[bid], bufs[bid ^ 1], ns[cur][i], cnt, xm, ym, c);
+                const uint32_t kd = nk[cur][i];
+                if ((int)(kd >> 24) < D) {  // child counts straight from the histogram, keys stay where they are
+                    const uint32_t* c4 = &hst[hoff((int)(kd >> 24) + 1) + 4 * (kd & 0xFFFFFFu)];
+                    c[0] = c4[0]; c[1] = c4[1]; c[2] = c4[2]; c[3] = c4[3];
+                } else {
+                    wave_divide(bufs[bid], bufs[bid ^ 1], ns[cur][i], cnt, xm, ym, c);
+                }
                 if (lane == 0) { cc[4 * t] = c[0]; cc[4 * t + 1] = c[1]; cc[4 * t + 2] = c[2]; cc[4 * t + 3] = c[3]; }
             }
             __syncthreads();
@@ -743,6 +781,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                 nb[nxt][pos] = nb[cur][i];
                 ns[nxt][pos] = ns[cur][i];
                 nc[nxt][pos] = nc[cur][i];
+                nk[nxt][pos] = nk[cur][i];
             }
         }
         // children: groups in reverse processing order, inside a group n4,n3,n2,n1 (push_front, :621-660)
@@ -751,16 +790,20 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
             const uint32_t i = ord[t];
             const short4 b = nb[cur][i];
             const uint32_t cb = nc[cur][i];
-            const uint32_t bid = (cb >> 31) ^ 1u;
+            const uint32_t kd = nk[cur][i];
+            const int dep = (int)(kd >> 24);
+            const bool virt = dep < D;                       // divided on the histogram: keys did not move
+            const uint32_t bid = (cb >> 31) ^ (virt ? 0u : 1u);
+            const uint32_t kc = ((uint32_t)(dep + 1) << 24) | (virt ? 4 * (kd & 0xFFFFFFu) : 0u);
             const int xm = b.x + ((b.y - b.x + 1) >> 1);
             const int ym = b.z + ((b.w - b.z + 1) >> 1);
             const uint32_t c0 = cc[4 * t], c1 = cc[4 * t + 1], c2 = cc[4 * t + 2], c3 = cc[4 * t + 3];
             const uint32_t st = ns[cur][i];
             int pos = (int)(K - (tB[t] + tA[t]));  // sum of k_u for u in (t, J]
-            if (c3) { nb[nxt][pos] = make_short4((short)xm, b.y, (short)ym, b.w); ns[nxt][pos] = st + c0 + c1 + c2; nc[nxt][pos] = c3 | (bid << 31); pos++; nToExpandLocal += c3 > 1; }
-            if (c2) { nb[nxt][pos] = make_short4(b.x, (short)xm, (short)ym, b.w); ns[nxt][pos] = st + c0 + c1; nc[nxt][pos] = c2 | (bid << 31); pos++; nToExpandLocal += c2 > 1; }
-            if (c1) { nb[nxt][pos] = make_short4((short)xm, b.y, b.z, (short)ym); ns[nxt][pos] = st + c0; nc[nxt][pos] = c1 | (bid << 31); pos++; nToExpandLocal += c1 > 1; }
-            if (c0) { nb[nxt][pos] = make_short4(b.x, (short)xm, b.z, (short)ym); ns[nxt][pos] = st; nc[nxt][pos] = c0 | (bid << 31); pos++; nToExpandLocal += c0 > 1; }
+            if (c3) { nb[nxt][pos] = make_short4((short)xm, b.y, (short)ym, b.w); ns[nxt][pos] = st + c0 + c1 + c2; nc[nxt][pos] = c3 | (bid << 31); nk[nxt][pos] = kc + 3; pos++; nToExpandLocal += c3 > 1; }
+            if (c2) { nb[nxt][pos] = make_short4(b.x, (short)xm, (short)ym, b.w); ns[nxt][pos] = st + c0 + c1; nc[nxt][pos] = c2 | (bid << 31); nk[nxt][pos] = kc + 2; pos++; nToExpandLocal += c2 > 1; }
+            if (c1) { nb[nxt][pos] = make_short4((short)xm, b.y, b.z, (short)ym); ns[nxt][pos] = st + c0; nc[nxt][pos] = c1 | (bid << 31); nk[nxt][pos] = kc + 1; pos++; nToExpandLocal += c1 > 1; }
+            if (c0) { nb[nxt][pos] = make_short4(b.x, (short)xm, b.z, (short)ym); ns[nxt][pos] = st; nc[nxt][pos] = c0 | (bid << 31); nk[nxt][pos] = kc; pos++; nToExpandLocal += c0 > 1; }
         }
         // block-wide sum of nToExpand (main mode only needs it)
         {
