@@ -336,7 +336,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     if (maxRoiW + 5 > 80 || maxRoiW - 6 > 127 || maxRoiH - 6 > 127) return fail(ORBX_E_UNSUPPORTED, "cell larger than the FAST tile");
     out.tileRows = maxRoiH;
     out.fastListCap = ((maxRoiW - 6) * (maxRoiH - 6) + 63) / 64 * 64;  // compacted detection pixels
-    out.nodeCap = align_up(nodeCap, 2);
+    out.nodeCap = align_up(nodeCap, 4);  // k_distribute reads its u32 arrays as uint4
 
     // cv::resize INTER_LINEAR coefficient tables, levels >= 1
     for (int l = 0; l < g.nlevels; l++) { out.xoff[l] = out.yoff[l] = 0; }

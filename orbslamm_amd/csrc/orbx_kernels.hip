@@ -538,6 +538,13 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                                                             int32_t* __restrict__ errFlag, int cap, int f0,
                                                             uint32_t* __restrict__ gscratch, int scratchWords)
 {
+#ifdef ORBX_DIST_TIMING  // phase timestamps of the level-0 block of frame 0, printed at the end (tools/dist_timing.py)
+    __shared__ uint64_t sStamp[96]; __shared__ int sStampId[96]; __shared__ int sNStamp;
+    if (threadIdx.x == 0) sNStamp = 0;
+#define STAMP(id) do { if (threadIdx.x == 0 && sNStamp < 96) { sStampId[sNStamp] = (id); sStamp[sNStamp++] = wall_clock64(); } } while (0)
+#else
+#define STAMP(id) do {} while (0)
+#endif
     extern __shared__ uint32_t smem_lds[];
     uint32_t* const smem = LDS ? smem_lds : gscratch + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * scratchWords;
     const int l = blockIdx.x, f = blockIdx.y + f0;
@@ -556,6 +563,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         cellOffs[i] = cells[L.cellBase + i].candOff;
     }
     __syncthreads();
+    STAMP(0);
     int n = (int)block_excl_scan(cellPref, nCells, wtmp0);
     if (tid == 0) { cellPref[nCells] = (uint32_t)n; candCount[f * g->nlevels + l] = n; }
     __syncthreads();
@@ -584,6 +592,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     uint32_t* wtmp = proc + 3 * cap;      // [8]
     __shared__ int sJ;
 
+    STAMP(1);
     // ---- roots (:543-585) and the first D levels below them in one counting sort.
     // A key's way down the tree is a function of its coordinates alone: root (int)(x / hX), then at every
     // level the quadrant against the node's midlines (:483-484).  So every key gets its path code to depth D
@@ -617,37 +626,67 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         }
         return code;
     };
-    // flat index -> (cell, slot) by binary search in the cell prefix; four keys in flight per thread
-    auto for_keys = [&](auto&& fn) {
-        constexpr int U = 4;
-        for (int p0 = tid; p0 < n; p0 += kDistThreads * U) {
-            uint64_t key[U];
+    // flat index -> (cell, slot) by binary search in the cell prefix.  A chunk is 16 keys per thread, all loads
+    // in flight together; a level that fits one chunk (<= 8192 candidates, every shipped shape) keeps its keys
+    // in registers between the count and the scatter, larger ones read them twice.
+    constexpr int KPT = 16;
+    int topStep = 1;
+    while (topStep * 2 < nCells) topStep *= 2;
+    auto load_chunk = [&](int base, uint64_t (&key)[KPT], uint32_t (&code)[KPT]) {
+        int lo[KPT], pp[KPT];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int p = min(p0 + u * kDistThreads, n - 1);
-                int lo = 0, hi = nCells;  // largest c with cellPref[c] <= p
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cellPref[mid] <= (uint32_t)p) lo = mid; else hi = mid; }
-                key[u] = srcb[cellOffs[lo] + (p - cellPref[lo])];
+        for (int u = 0; u < KPT; u++) { pp[u] = min(base + tid + u * kDistThreads, n - 1); lo[u] = 0; }
+        // largest c with cellPref[c] <= p: fixed-trip search, the 16 chains advance side by side
+        for (int step = topStep; step > 0; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < KPT; u++) {
+                const int c = lo[u] + step;
+                if (c < nCells && cellPref[c] <= (uint32_t)pp[u]) lo[u] = c;
             }
+        }
 #pragma unroll
-            for (int u = 0; u < U; u++)
-                if (p0 + u * kDistThreads < n) fn(key[u]);
-        }
+        for (int u = 0; u < KPT; u++) key[u] = srcb[cellOffs[lo[u]] + (pp[u] - cellPref[lo[u]])];
+#pragma unroll
+        for (int u = 0; u < KPT; u++) code[u] = (uint32_t)path_code(key[u]);
     };
-    for_keys([&](uint64_t key) { atomicAdd(&hst[hoff(D) + path_code(key)], 1u); });
-    __syncthreads();
-    for (int d = D - 1; d >= 0; d--) {
-        const int cnt = nIni << (2 * d);
-        for (int i = tid; i < cnt; i += kDistThreads) {
-            const uint32_t* c4 = &hst[hoff(d + 1) + 4 * i];
-            hst[hoff(d) + i] = c4[0] + c4[1] + c4[2] + c4[3];
-        }
+    auto count_chunk = [&](int base, const uint32_t (&code)[KPT]) {
+#pragma unroll
+        for (int u = 0; u < KPT; u++)
+            if (base + tid + u * kDistThreads < n) atomicAdd(&hst[hoff(D) + code[u]], 1u);
+    };
+    auto scatter_chunk = [&](int base, const uint64_t (&key)[KPT], const uint32_t (&code)[KPT]) {
+#pragma unroll
+        for (int u = 0; u < KPT; u++)
+            if (base + tid + u * kDistThreads < n) bufs[1][atomicAdd(&hfill[code[u]], 1u)] = key[u];
+    };
+    auto tree_sums_and_starts = [&]() {
         __syncthreads();
+        STAMP(3);
+        for (int d = D - 1; d >= 0; d--) {
+            const int cnt = nIni << (2 * d);
+            for (int i = tid; i < cnt; i += kDistThreads) {
+                const uint32_t* c4 = &hst[hoff(d + 1) + 4 * i];
+                hst[hoff(d) + i] = c4[0] + c4[1] + c4[2] + c4[3];
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < nBins; i += kDistThreads) hfill[i] = hst[hoff(D) + i];
+        __syncthreads();
+        block_excl_scan(hfill, nBins, wtmp);
+        STAMP(4);
+    };
+    constexpr int kChunk = KPT * kDistThreads;
+    if (n <= kChunk) {
+        uint64_t key[KPT];
+        uint32_t code[KPT];
+        if (n > 0) { load_chunk(0, key, code); count_chunk(0, code); }
+        tree_sums_and_starts();
+        if (n > 0) scatter_chunk(0, key, code);
+    } else {
+        for (int base = 0; base < n; base += kChunk) { uint64_t key[KPT]; uint32_t code[KPT]; load_chunk(base, key, code); count_chunk(base, code); }
+        tree_sums_and_starts();
+        for (int base = 0; base < n; base += kChunk) { uint64_t key[KPT]; uint32_t code[KPT]; load_chunk(base, key, code); scatter_chunk(base, key, code); }
     }
-    for (int i = tid; i < nBins; i += kDistThreads) hfill[i] = hst[hoff(D) + i];
-    __syncthreads();
-    block_excl_scan(hfill, nBins, wtmp);
-    for_keys([&](uint64_t key) { bufs[1][atomicAdd(&hfill[path_code(key)], 1u)] = key; });
     for (int i = tid; i < nIni; i += kDistThreads) { ord[i] = hst[i]; tA[i] = hst[i]; }  // root counts
     __syncthreads();
     block_excl_scan(tA, nIni, wtmp);  // tA = root starts
@@ -670,6 +709,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     }
     __syncthreads();
 
+    STAMP(2);
     // ---- rounds
     bool careful = false;
     for (int iter = 0; iter < 64; iter++) {
@@ -680,32 +720,58 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         for (int i = tid; i < m; i += kDistThreads) tB[i] = tA[i];
         __syncthreads();
         const int E = (int)block_excl_scan(tB, m, wtmp);
+        STAMP(10 + (careful ? 100 : 0));
         if (E == 0) break;  // size unchanged -> finish (:669 / :733)
         for (int i = tid; i < m; i += kDistThreads) if (tA[i]) ord[tB[i]] = i;
         __syncthreads();
         if (careful) {
             // sort by (count desc, list position asc) == reference's (size, creation) ascending
             // sort walked from the back (:684-685, tie-break see DESIGN.md)
-            // rank sort on compact (count, index) arrays; `parts` threads share one element's scan
-            for (int e = tid; e < E; e += kDistThreads) tA[e] = nc[cur][ord[e]] & 0x7FFFFFFFu;
+            // rank sort: rank(e) = number of keys above key(e), key = count << 13 | (8191 - list index), all
+            // distinct.  One subtract-with-borrow + add-with-carry per pair, four keys per LDS read, padded to
+            // a multiple of four with zeros (never above a real key); `parts` threads share one element's scan.
+            // (Boolean logic through SGPR pairs instead stalls this two-waves-per-SIMD kernel on every
+            // VALU -> SALU hand-over: measured 11 us against 1.)
+            if (cap > 8192 || n >= (1 << 19)) {  // key does not pack: plain two-field rank sort
+                for (int e = tid; e < E; e += kDistThreads) {
+                    const uint32_t i = ord[e];
+                    const uint32_t ci = nc[cur][i] & 0x7FFFFFFFu;
+                    int rank = 0;
+                    for (int e2 = 0; e2 < E; e2++) {
+                        const uint32_t i2 = ord[e2];
+                        const uint32_t c2 = nc[cur][i2] & 0x7FFFFFFFu;
+                        rank += (c2 > ci || (c2 == ci && i2 < i)) ? 1 : 0;
+                    }
+                    ord2[rank] = i;
+                }
+                __syncthreads();
+            } else {
+            const int E4 = (E + 3) & ~3;  // <= cap (a multiple of 4)
+            for (int e = tid; e < E4; e += kDistThreads) {
+                const uint32_t i = e < E ? ord[e] : 0;
+                tA[e] = e < E ? ((nc[cur][i] & 0x7FFFFFFFu) << 13) | (8191u - i) : 0u;
+            }
             __syncthreads();
             int parts = 1;
             while (parts < 8 && E * parts * 2 <= kDistThreads) parts *= 2;
+            const int per = ((E + parts - 1) / parts + 3) & ~3;
             for (int e0 = 0; e0 < E; e0 += kDistThreads / parts) {
                 const int e = e0 + tid / parts, sub = tid % parts;
-                int rank = 0;
+                uint32_t rank = 0;
                 if (e < E) {
-                    const uint32_t i = ord[e], ci = tA[e];
-                    const int per = (E + parts - 1) / parts;
-                    for (int e2 = sub * per; e2 < min(E, (sub + 1) * per); e2++) {
-                        const uint32_t c2 = tA[e2], i2 = ord[e2];
-                        rank += (c2 > ci || (c2 == ci && i2 < i)) ? 1 : 0;
+                    const uint32_t ke = tA[e];
+                    const int lim = min(E4, (sub + 1) * per);
+#pragma unroll 4
+                    for (int e2 = sub * per; e2 < lim; e2 += 4) {
+                        const uint4 k4 = *(const uint4*)&tA[e2];
+                        rank += (ke < k4.x) + (ke < k4.y) + (ke < k4.z) + (ke < k4.w);
                     }
                 }
                 for (int d = 1; d < parts; d <<= 1) rank += __shfl_xor(rank, d);
                 if (e < E && sub == 0) ord2[rank] = ord[e];
             }
             __syncthreads();
+            }
             for (int e = tid; e < E; e += kDistThreads) ord[e] = ord2[e];
             __syncthreads();
         }
@@ -713,6 +779,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         // phase stops at the first node after which the list holds N nodes (:727-728): a split
         // adds at most 3 nodes, so nodes are divided in sorted order in chunks of
         // ceil(deficit / 3) until the cut is found -- typically a quarter of E, not all of it.
+        STAMP(11);
         if (tid == 0) sJ = E - 1;
         int done = 0;
         while (done < E) {
@@ -759,6 +826,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
             if (sJ < E - 1 || (sJ == E - 1 && done == E)) break;  // cut found (or everything divided)
         }
         __syncthreads();
+        STAMP(12);
         const int J = sJ;
         const uint32_t K = tB[J] + tA[J];  // children of processed nodes
         // survivors: old nodes not processed keep their relative order behind the new ones
@@ -818,8 +886,12 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
 #pragma unroll
         for (int w = 0; w < NW; w++) nToExpand += (int)wtmp[w];
         __syncthreads();
+        STAMP(13);
         cur = nxt;
         m = newSize;
+#ifdef ORBX_DIST_TIMING
+        if (tid == 0 && sNStamp < 96) { sStampId[sNStamp] = 1000 + m; sStamp[sNStamp++] = (uint64_t)E; }
+#endif
         if (m >= N || m == prevSize) break;             // :669 / :733
         if (!careful && m + nToExpand * 3 > N) careful = true;  // :673
     }
@@ -851,6 +923,19 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         if (i < m && sub == 0) outk[i] = best;
     }
     if (tid == 0) keptCount[f * g->nlevels + l] = m;
+#ifdef ORBX_DIST_TIMING
+    __syncthreads();
+    STAMP(99);
+    if (tid == 0 && l == 0 && blockIdx.y == 0) {
+        printf("DIST n=%d N=%d D=%d\n", n, N, D);
+        uint64_t prev = sStamp[0];
+        for (int i = 0; i < sNStamp; i++) {
+            if (sStampId[i] >= 1000) printf("   -> m=%d E=%d\n", sStampId[i] - 1000, (int)sStamp[i]);
+            else { printf(" id %3d  +%6.2f us\n", sStampId[i], (double)(sStamp[i] - prev) / 100.0); prev = sStamp[i]; }
+        }
+    }
+#endif
+#undef STAMP
 }
 
 // ------------------------------------------------------------------ Gaussian 7x7 sigma 2

@@ -1,3 +1,5 @@
+# phase timing of k_distribute (level 0 of frame 0): build the library with -DORBX_DIST_TIMING first, e.g.
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DORBX_DIST_TIMING -o orbslamm_amd/liborbslamm_hip.so orbslamm_amd/csrc/orbslamm_hip.hip
 import sys, numpy as np
 sys.path.insert(0, '.')
 from orbslamm_amd import ORBextractor, synth
