@@ -141,6 +141,7 @@ struct orbx_handle {
     hipStream_t streamP[kMaxSplit] = {nullptr};  // pipeline stream of sub-batch p (p = 0 uses `stream`)
     hipStream_t streamB[kMaxSplit] = {nullptr};  // blur runs beside FAST + quadtree
     hipEvent_t evStart = nullptr, evPart[kMaxSplit] = {nullptr};
+    int lastParts = 0;                        // evPart[0..lastParts) belong to the last extraction
     hipStream_t stream3 = nullptr;            // matching runs beside the next batch's pyramid/FAST
     hipEvent_t evPyr[kMaxSplit] = {nullptr}, evBlur[kMaxSplit] = {nullptr}, evDesc = nullptr, evMatch = nullptr;
     bool matchPending = false;
@@ -507,16 +508,21 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     if (rc) { delete h; return rc; }
 #define CRT(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int r_ = fail(ORBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); free_device(h); delete h; return r_; } } while (0)
     CRT(hipSetDevice(device));
+    // HIP deals streams to the (four) hardware queues round-robin in creation order; two busy streams on one
+    // queue serialise.  The steady-state pipeline uses four: sub-batch 0, sub-batch 1, matching, blur (which
+    // shares its queue with the host-facing stream, idle while a device-resident stream runs).
     CRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CRT(hipStreamCreateWithFlags(&h->streamP[0], hipStreamNonBlocking));
+    CRT(hipStreamCreateWithFlags(&h->streamP[1], hipStreamNonBlocking));
+    CRT(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    CRT(hipStreamCreateWithFlags(&h->streamB[0], hipStreamNonBlocking));
     for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
-        if (i > 0) CRT(hipStreamCreateWithFlags(&h->streamP[i], hipStreamNonBlocking));
-        CRT(hipStreamCreateWithFlags(&h->streamB[i], hipStreamNonBlocking));
+        if (i > 1) CRT(hipStreamCreateWithFlags(&h->streamP[i], hipStreamNonBlocking));
         CRT(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
         CRT(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming));
         CRT(hipEventCreateWithFlags(&h->evPart[i], hipEventDisableTiming));
     }
     CRT(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
-    CRT(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
     CRT(hipEventCreateWithFlags(&h->evDesc, hipEventDisableTiming));
     CRT(hipEventCreateWithFlags(&h->evMatch, hipEventDisableTiming));
     const size_t B = (size_t)max_batch;
@@ -691,6 +697,13 @@ static int check_device(orbx_handle* h)
 }
 
 // ------------------------------------------------------------------ the pipeline
+// make `s` wait for every sub-batch of the last extraction
+static int join_parts(orbx_handle* h, hipStream_t s)
+{
+    for (int p = 0; p < h->lastParts; p++) HIPCHK(hipStreamWaitEvent(s, h->evPart[p], 0));
+    return ORBX_OK;
+}
+
 // The batch is cut into kSplit sub-batches that run on separate stream groups: the
 // latency-bound kernels of one sub-batch (quadtree, descriptors) overlap the
 // throughput-bound ones (FAST, matching) of the other.
@@ -708,14 +721,18 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     // the pyramid/blur buffers use the geometry's per-frame sizes as pitch
     hipStream_t s0 = h->stream;
     const int nsplit = h->serial ? 1 : std::min(h->nsplit, B);
-    if (nsplit > 1) HIPCHK(hipEventRecord(h->evStart, s0));
+    // Sub-batch p owns stream streamP[p] across calls: it follows its own previous work (its frames' scratch
+    // buffers) and the upload on the host-facing stream, nothing else -- the next batch's pyramid of sub-batch 0
+    // starts while this batch's sub-batch 1 is still in its quadtree.  Consumers join through evPart (join_parts).
+    if (!h->serial) HIPCHK(hipEventRecord(h->evStart, s0));
+    h->lastParts = 0;
     for (int part = 0; part < nsplit; part++) {
         const int f0 = (int)((int64_t)B * part / nsplit), f1 = (int)((int64_t)B * (part + 1) / nsplit);
         const int nb = f1 - f0;
         if (nb <= 0) continue;
-        hipStream_t s = part == 0 ? s0 : h->streamP[part];
-        hipStream_t s2 = h->serial ? s : h->streamB[part];
-        if (part > 0) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
+        hipStream_t s = h->serial ? s0 : h->streamP[part];
+        hipStream_t s2 = h->serial ? s : h->streamB[0];
+        if (!h->serial) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
         src.f0 = f0;
         if (g.nlevels > 1 && h->pyrFused) {
             const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
@@ -769,10 +786,7 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, nb), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
                            h->d_keptCount, h->d_kps + h->maxKp, h->d_desc + (size_t)h->maxKp * 32, h->d_count + 1);
         h->prof.end(s);
-        if (part > 0) {  // join back into the main stream
-            HIPCHK(hipEventRecord(h->evPart[part], s));
-            HIPCHK(hipStreamWaitEvent(s0, h->evPart[part], 0));
-        }
+        HIPCHK(hipEventRecord(h->evPart[h->lastParts++], s));
     }
     HIPCHK(hipGetLastError());
     h->lastB = B;
@@ -969,8 +983,7 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     if (B < 1) return fail(ORBX_E_INVALID, "no extracted batch to match");
     // matching runs on its own stream so that the next batch's pyramid/FAST can start beside it
     hipStream_t s = h->serial ? h->stream : h->stream3;
-    HIPCHK(hipEventRecord(h->evDesc, h->stream));
-    HIPCHK(hipStreamWaitEvent(s, h->evDesc, 0));
+    if ((rc = join_parts(h, s))) return rc;
     orbm::MatchIO io = slots_io(h);
     h->prof.begin(P_MATCH_BEST2, s);
     // slots 0..B expanded to +-1 bytes, then the Hamming scan as an int8 MFMA product (train slot f, query slot f+1)
