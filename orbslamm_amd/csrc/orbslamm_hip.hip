@@ -508,14 +508,14 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     if (rc) { delete h; return rc; }
 #define CRT(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int r_ = fail(ORBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); free_device(h); delete h; return r_; } } while (0)
     CRT(hipSetDevice(device));
-    // HIP deals streams to the (four) hardware queues round-robin in creation order; two busy streams on one
-    // queue serialise.  The steady-state pipeline uses four: sub-batch 0, sub-batch 1, matching, blur (which
-    // shares its queue with the host-facing stream, idle while a device-resident stream runs).
+    // The first four streams of a process get a hardware queue each, later ones share the last (observed with
+    // rocprofv3 --kernel-trace), and two busy streams on one queue serialise.  The steady-state pipeline therefore
+    // uses exactly four: the host-facing stream (uploads, downloads -- idle while a device-resident stream runs --
+    // and the blur kernels), sub-batch 0, sub-batch 1, matching.
     CRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CRT(hipStreamCreateWithFlags(&h->streamP[0], hipStreamNonBlocking));
     CRT(hipStreamCreateWithFlags(&h->streamP[1], hipStreamNonBlocking));
     CRT(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-    CRT(hipStreamCreateWithFlags(&h->streamB[0], hipStreamNonBlocking));
     for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
         if (i > 1) CRT(hipStreamCreateWithFlags(&h->streamP[i], hipStreamNonBlocking));
         CRT(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
@@ -731,7 +731,7 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         const int nb = f1 - f0;
         if (nb <= 0) continue;
         hipStream_t s = h->serial ? s0 : h->streamP[part];
-        hipStream_t s2 = h->serial ? s : h->streamB[0];
+        hipStream_t s2 = h->serial ? s : s0;  // blur: see orbx_create on the choice of streams
         if (!h->serial) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
         src.f0 = f0;
         if (g.nlevels > 1 && h->pyrFused) {
