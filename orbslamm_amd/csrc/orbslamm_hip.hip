@@ -143,8 +143,11 @@ struct orbx_handle {
     hipEvent_t evStart = nullptr, evPart[kMaxSplit] = {nullptr};
     int lastParts = 0;                        // evPart[0..lastParts) belong to the last extraction
     hipStream_t stream3 = nullptr;            // matching runs beside the next batch's pyramid/FAST
-    hipEvent_t evPyr[kMaxSplit] = {nullptr}, evBlur[kMaxSplit] = {nullptr}, evDesc = nullptr, evMatch = nullptr;
-    bool matchPending = false;
+    hipEvent_t evPyr[kMaxSplit] = {nullptr}, evBlur[kMaxSplit] = {nullptr}, evDesc = nullptr, evMatch[2] = {nullptr, nullptr};
+    bool matchPending[2] = {false, false};
+    // Results (keypoints, descriptors, counts, +-1 descriptors) live in two sets of maxB + 1 slots used by alternate
+    // extractions, so that the matching of batch n (set n & 1) never holds back the descriptors of batch n + 1
+    int curSet = 0;
     bool serial = false;                      // ORBX_SERIAL=1: everything on one stream (profiling aid)
     // device buffers (sized for maxW x maxH x maxB at create)
     Geom* d_geom = nullptr;
@@ -480,7 +483,7 @@ static void free_device(orbx_handle* h)
     }
     if (h->evStart) (void)hipEventDestroy(h->evStart);
     if (h->evDesc) (void)hipEventDestroy(h->evDesc);
-    if (h->evMatch) (void)hipEventDestroy(h->evMatch);
+    for (int i = 0; i < 2; i++) if (h->evMatch[i]) (void)hipEventDestroy(h->evMatch[i]);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
     if (h->stream) (void)hipStreamDestroy(h->stream);
 }
@@ -524,7 +527,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     }
     CRT(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
     CRT(hipEventCreateWithFlags(&h->evDesc, hipEventDisableTiming));
-    CRT(hipEventCreateWithFlags(&h->evMatch, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) CRT(hipEventCreateWithFlags(&h->evMatch[i], hipEventDisableTiming));
     const size_t B = (size_t)max_batch;
     // capacities with head-room so that smaller shapes (different cell layouts) also fit
     h->cellsCap = hg.cells.size() * 2 + 64;
@@ -552,19 +555,19 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_kept, h->keptCapFrame * B * sizeof(uint64_t)));
     CRT(hipMalloc(&h->d_keptCount, B * ORBX_MAXL * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_err, sizeof(int32_t)));
-    CRT(hipMalloc(&h->d_kps, (B + 1) * h->maxKp * sizeof(OrbxKeyPointDev)));
-    CRT(hipMalloc(&h->d_desc, (B + 1) * (size_t)h->maxKp * 32));
-    CRT(hipMalloc(&h->d_count, (B + 1) * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_kps, 2 * (B + 1) * h->maxKp * sizeof(OrbxKeyPointDev)));
+    CRT(hipMalloc(&h->d_desc, 2 * (B + 1) * (size_t)h->maxKp * 32));
+    CRT(hipMalloc(&h->d_count, 2 * (B + 1) * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_match, B * h->maxKp * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_binOf, B * (size_t)h->maxKp));
     CRT(hipMalloc(&h->d_hist, B * 32 * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_nmatch, B * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_partial, B * kMatchChunks * h->maxKp * sizeof(uint2)));
     h->xPitch = (int64_t)align_up(h->maxKp, orbm::kMfmaRowsPerBlock) * 256;
-    CRT(hipMalloc(&h->d_xdesc, (B + 1) * (size_t)h->xPitch));
-    CRT(hipMemset(h->d_xdesc, 0, (B + 1) * (size_t)h->xPitch));
+    CRT(hipMalloc(&h->d_xdesc, 2 * (B + 1) * (size_t)h->xPitch));
+    CRT(hipMemset(h->d_xdesc, 0, 2 * (B + 1) * (size_t)h->xPitch));
     CRT(hipMemset(h->d_err, 0, sizeof(int32_t)));
-    CRT(hipMemset(h->d_count, 0, (B + 1) * sizeof(int32_t)));
+    CRT(hipMemset(h->d_count, 0, 2 * (B + 1) * sizeof(int32_t)));
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
     CRT(hipMemset(h->d_nmatch, 0, B * sizeof(int32_t)));
     h->pinnedBytes = std::max(h->imgFrameBytes * B, B * (size_t)h->maxKp * (sizeof(OrbxKeyPointDev) + 32 + 4) + 4096);
@@ -615,6 +618,13 @@ extern "C" int orbx_max_keypoints(const orbx_t* h)
     return hg.g.maxKp + 64;
 }
 
+// ------------------------------------------------------------------ result sets
+static inline size_t set_slot0(const orbx_handle* h, int set) { return (size_t)set * ((size_t)h->maxB + 1); }
+static inline OrbxKeyPointDev* r_kps(orbx_handle* h, int set) { return h->d_kps + set_slot0(h, set) * h->maxKp; }
+static inline uint8_t* r_desc(orbx_handle* h, int set) { return h->d_desc + set_slot0(h, set) * h->maxKp * 32; }
+static inline int32_t* r_count(orbx_handle* h, int set) { return h->d_count + set_slot0(h, set); }
+static inline uint8_t* r_xdesc(orbx_handle* h, int set) { return h->d_xdesc + set_slot0(h, set) * (size_t)h->xPitch; }
+
 // ------------------------------------------------------------------ shape configuration
 static int sync_all(orbx_handle* h)
 {
@@ -624,7 +634,7 @@ static int sync_all(orbx_handle* h)
         if (h->streamB[i]) HIPCHK(hipStreamSynchronize(h->streamB[i]));
     }
     HIPCHK(hipStreamSynchronize(h->stream3));
-    h->matchPending = false;
+    h->matchPending[0] = h->matchPending[1] = false;
     return ORBX_OK;
 }
 
@@ -684,7 +694,7 @@ static int configure_shape(orbx_handle* h, int w, int hh)
     h->curW = w; h->curH = hh;
     // a new shape starts a new stream
     h->havePrev = false;
-    HIPCHK(hipMemset(h->d_count, 0, sizeof(int32_t)));
+    for (int set = 0; set < 2; set++) HIPCHK(hipMemset(r_count(h, set), 0, sizeof(int32_t)));
     return ORBX_OK;
 }
 
@@ -726,6 +736,8 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     // starts while this batch's sub-batch 1 is still in its quadtree.  Consumers join through evPart (join_parts).
     if (!h->serial) HIPCHK(hipEventRecord(h->evStart, s0));
     h->lastParts = 0;
+    h->curSet ^= 1;
+    const int set = h->curSet;
     for (int part = 0; part < nsplit; part++) {
         const int f0 = (int)((int64_t)B * part / nsplit), f1 = (int)((int64_t)B * (part + 1) / nsplit);
         const int nb = f1 - f0;
@@ -781,10 +793,10 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         h->prof.end(s);
         HIPCHK(hipStreamWaitEvent(s, h->evBlur[part], 0));
         // the output slots are still being read by the previous batch's matching on stream3
-        if (h->matchPending) HIPCHK(hipStreamWaitEvent(s, h->evMatch, 0));
+        if (h->matchPending[set]) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set], 0));  // the matching two batches back read this set
         h->prof.begin(P_ORIENT_DESC, s);
         hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, nb), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
-                           h->d_keptCount, h->d_kps + h->maxKp, h->d_desc + (size_t)h->maxKp * 32, h->d_count + 1);
+                           h->d_keptCount, r_kps(h, set) + h->maxKp, r_desc(h, set) + (size_t)h->maxKp * 32, r_count(h, set) + 1);
         h->prof.end(s);
         HIPCHK(hipEventRecord(h->evPart[h->lastParts++], s));
     }
@@ -807,9 +819,9 @@ extern "C" int orbx_device_results(orbx_t* h, OrbxKeyPoint** d_kps, uint8_t** d_
 {
     int rc = check_device(h);
     if (rc) return rc;
-    if (d_kps) *d_kps = (OrbxKeyPoint*)(h->d_kps + h->maxKp);
-    if (d_desc) *d_desc = h->d_desc + (size_t)h->maxKp * 32;
-    if (d_counts) *d_counts = h->d_count + 1;
+    if (d_kps) *d_kps = (OrbxKeyPoint*)(r_kps(h, h->curSet) + h->maxKp);
+    if (d_desc) *d_desc = r_desc(h, h->curSet) + (size_t)h->maxKp * 32;
+    if (d_counts) *d_counts = r_count(h, h->curSet) + 1;
     if (cap) *cap = h->maxKp;
     return ORBX_OK;
 }
@@ -861,12 +873,12 @@ extern "C" int orbx_download(orbx_t* h, int frame, OrbxKeyPoint* kps, uint8_t* d
     if (rc) return rc;
     if (frame < 0 || frame >= h->lastB) return fail(ORBX_E_INVALID, "frame %d not in the last batch", frame);
     int32_t n = 0;
-    HIPCHK(hipMemcpy(&n, h->d_count + 1 + frame, sizeof n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&n, r_count(h, h->curSet) + 1 + frame, sizeof n, hipMemcpyDeviceToHost));
     if (n_out) *n_out = n;
     if (n > cap) return fail(ORBX_E_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
     if (n > 0) {
-        if (kps) HIPCHK(hipMemcpy(kps, h->d_kps + (size_t)(frame + 1) * h->maxKp, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost));
-        if (desc) HIPCHK(hipMemcpy(desc, h->d_desc + (size_t)(frame + 1) * h->maxKp * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+        if (kps) HIPCHK(hipMemcpy(kps, r_kps(h, h->curSet) + (size_t)(frame + 1) * h->maxKp, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy(desc, r_desc(h, h->curSet) + (size_t)(frame + 1) * h->maxKp * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
     }
     return ORBX_OK;
 }
@@ -899,7 +911,7 @@ extern "C" int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, 
     // one D2H of counts, then per-frame payloads
     std::vector<int32_t> counts(B);
     h->prof.begin(P_D2H, h->stream);
-    HIPCHK(hipMemcpyAsync(counts.data(), h->d_count + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(counts.data(), r_count(h, h->curSet) + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     int over = 0;
     for (int f = 0; f < B; f++) {
@@ -907,8 +919,8 @@ extern "C" int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, 
         if (n_out) n_out[f] = n;
         if (n > cap) { over = 1; continue; }
         if (n > 0) {
-            if (kps) HIPCHK(hipMemcpyAsync(kps + (size_t)f * cap, h->d_kps + (size_t)(f + 1) * h->maxKp, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost, h->stream));
-            if (desc) HIPCHK(hipMemcpyAsync(desc + (size_t)f * cap * 32, h->d_desc + (size_t)(f + 1) * h->maxKp * 32, (size_t)n * 32, hipMemcpyDeviceToHost, h->stream));
+            if (kps) HIPCHK(hipMemcpyAsync(kps + (size_t)f * cap, r_kps(h, h->curSet) + (size_t)(f + 1) * h->maxKp, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost, h->stream));
+            if (desc) HIPCHK(hipMemcpyAsync(desc + (size_t)f * cap * 32, r_desc(h, h->curSet) + (size_t)(f + 1) * h->maxKp * 32, (size_t)n * 32, hipMemcpyDeviceToHost, h->stream));
         }
     }
     h->prof.end(h->stream);
@@ -966,12 +978,12 @@ extern "C" int orbx_level_candidates(orbx_t* h, int frame, int level, uint64_t* 
 }
 
 // ------------------------------------------------------------------ stream matching
-static orbm::MatchIO slots_io(orbx_handle* h)
+static orbm::MatchIO slots_io(orbx_handle* h, int set)
 {
     orbm::MatchIO io;
-    io.desc = h->d_desc; io.descPitch = (int64_t)h->maxKp * 32;
-    io.ang = &((const float*)h->d_kps)[3]; io.angStride = 7; io.angPitch = (int64_t)h->maxKp * 7;
-    io.count = h->d_count;
+    io.desc = r_desc(h, set); io.descPitch = (int64_t)h->maxKp * 32;
+    io.ang = &((const float*)r_kps(h, set))[3]; io.angStride = 7; io.angPitch = (int64_t)h->maxKp * 7;
+    io.count = r_count(h, set);
     return io;
 }
 
@@ -984,28 +996,29 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     // matching runs on its own stream so that the next batch's pyramid/FAST can start beside it
     hipStream_t s = h->serial ? h->stream : h->stream3;
     if ((rc = join_parts(h, s))) return rc;
-    orbm::MatchIO io = slots_io(h);
+    const int set = h->curSet;
+    orbm::MatchIO io = slots_io(h, set);
     h->prof.begin(P_MATCH_BEST2, s);
     // slots 0..B expanded to +-1 bytes, then the Hamming scan as an int8 MFMA product (train slot f, query slot f+1)
     // with the acceptance rule in its epilogue
-    hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(h->xPitch / 4096), B + 1), dim3(256), 0, s, io, 0, 0, h->d_xdesc, h->xPitch);
+    hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(h->xPitch / 4096), B + 1), dim3(256), 0, s, io, 0, 0, r_xdesc(h, set), h->xPitch);
     {
         const int nqb = (h->maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
         const orbm::AcceptArgs aa = {io, io, 1, 0, nnratio, th_low, check_ori, h->d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist};
-        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, s, (const uint8_t*)h->d_xdesc, h->xPitch, aa, nqb, B);
+        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, s, (const uint8_t*)r_xdesc(h, set), h->xPitch, aa, nqb, B);
     }
     h->prof.end(s);
     h->prof.begin(P_MATCH_PRUNE, s);
     hipLaunchKernelGGL(orbm::k_match_prune, dim3(B), dim3(256), 0, s, io, 1, check_ori, h->d_match, (int64_t)h->maxKp,
                        h->d_binOf, h->d_hist, h->d_nmatch);
     h->prof.end(s);
-    // last frame of this batch becomes the stream's previous frame (slot 0)
-    HIPCHK(hipMemcpyAsync(h->d_kps, h->d_kps + (size_t)B * h->maxKp, (size_t)h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->d_desc, h->d_desc + (size_t)B * h->maxKp * 32, (size_t)h->maxKp * 32, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->d_count, h->d_count + B, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipEventRecord(h->evMatch, s));
+    // last frame of this batch becomes the stream's previous frame: slot 0 of the set the next extraction fills
+    HIPCHK(hipMemcpyAsync(r_kps(h, set ^ 1), r_kps(h, set) + (size_t)B * h->maxKp, (size_t)h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(r_desc(h, set ^ 1), r_desc(h, set) + (size_t)B * h->maxKp * 32, (size_t)h->maxKp * 32, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(r_count(h, set ^ 1), r_count(h, set) + B, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipEventRecord(h->evMatch[set], s));
     HIPCHK(hipGetLastError());
-    h->matchPending = true;
+    h->matchPending[set] = true;
     h->havePrev = true;
     return ORBX_OK;
 }
@@ -1025,7 +1038,7 @@ extern "C" int orbx_download_matches(orbx_t* h, int frame, int32_t* match, int c
     if (rc) return rc;
     if (frame < 0 || frame >= h->lastB) return fail(ORBX_E_INVALID, "frame %d not in the last batch", frame);
     int32_t n = 0, nm = 0;
-    HIPCHK(hipMemcpy(&n, h->d_count + 1 + frame, sizeof n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&n, r_count(h, h->curSet) + 1 + frame, sizeof n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&nm, h->d_nmatch + frame, sizeof nm, hipMemcpyDeviceToHost));
     if (nmatch) *nmatch = nm;
     if (n > cap) return fail(ORBX_E_CAPACITY, "%d queries, caller capacity %d", n, cap);
@@ -1038,7 +1051,7 @@ extern "C" int orbx_reset_stream(orbx_t* h)
     int rc = check_device(h);
     if (rc) return rc;
     if ((rc = sync_all(h))) return rc;
-    HIPCHK(hipMemsetAsync(h->d_count, 0, sizeof(int32_t), h->stream));
+    for (int set = 0; set < 2; set++) HIPCHK(hipMemsetAsync(r_count(h, set), 0, sizeof(int32_t), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->havePrev = false;
     return ORBX_OK;
