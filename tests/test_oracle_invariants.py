@@ -216,3 +216,14 @@ def test_brief_pattern_equals_scikit_image_copy():
     theirs = np.loadtxt(path).astype(np.int64).reshape(-1)
     ours = np.array(_read_pattern(os.path.join(ROOT, "oracle", "brief_pattern.inc")))
     assert np.array_equal(theirs, ours)
+
+
+def test_device_sincos_sequence_matches_libm(tmp_path):
+    """the kernel's binary64 sin/cos sequence, run on the host over a 1-in-61 sample of all binary32 angles in
+    [0, 2pi], rounds to the same floats as libm (the exhaustive run, step 1, is 15 s: also bad=0)"""
+    import subprocess
+    exe = str(tmp_path / "sincos_check")
+    src = os.path.join(ROOT, "oracle", "sincos_check.c")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"])
+    out = subprocess.check_output([exe, "61"]).decode()
+    assert "bad=0" in out and "n=17818339" in out
