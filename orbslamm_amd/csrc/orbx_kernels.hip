@@ -1120,7 +1120,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 // sin and cos of x in [0, 2pi] in binary64: Cody-Waite reduction by pi/2 (two constants, k <= 4) and the
 // fdlibm kernel polynomials on |r| <= pi/4, every operation a separately rounded IEEE op.  The reference
-// rounds cos((double)angle) / sin((double)angle) to float (ORBextractor.cc:112-113); oracle/sincos_check.c
+// rounds cos((double)angle) / sin((double)angle) to float (ORBextractor.cc:112-113); tests/cpp/sincos_check.c
 // runs this very sequence against the host libm over EVERY binary32 argument in [0, 2pi] (1.09e9 values) and
 // finds the float results identical, so the third of the generic library routine's work is enough here.
 __device__ __forceinline__ double ksin_d(double x)

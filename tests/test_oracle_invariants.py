@@ -223,7 +223,7 @@ def test_device_sincos_sequence_matches_libm(tmp_path):
     [0, 2pi], rounds to the same floats as libm (the exhaustive run, step 1, is 15 s: also bad=0)"""
     import subprocess
     exe = str(tmp_path / "sincos_check")
-    src = os.path.join(ROOT, "oracle", "sincos_check.c")
+    src = os.path.join(ROOT, "tests", "cpp", "sincos_check.c")
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"])
     out = subprocess.check_output([exe, "61"]).decode()
     assert "bad=0" in out and "n=17818339" in out
