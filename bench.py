@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
+    ap.add_argument("--no-replay", action="store_true", help="skip the untimed serialized replay (roofline.isolated); used under rocprofv3 so that its per-kernel averages are those of the timed launches")
     args = ap.parse_args()
 
     from orbslamm_amd import ORBextractor, streams, synth
@@ -113,7 +114,7 @@ def main():
         ex.match_prev_batch_device(0.7, 50, True)
 
     def sync():
-        ex.sync()  # hipStreamSynchronize of the handle's stream (all work of this process is on it)
+        ex.sync()  # orbx_sync: every stream of the handle (all GPU work of this process hangs off it)
         if torch is not None:
             torch.cuda.synchronize()
 
@@ -135,7 +136,7 @@ def main():
     # serialized replay (untimed): the same steps with every kernel alone on the GPU, to tell
     # kernel cost from overlap.  `value` above is NOT affected by it.
     prof_serial = {}
-    if rank == 0 and not args.no_profile:
+    if rank == 0 and not args.no_profile and not args.no_replay:
         ex.set_serial(True)
         step()
         ex.sync()
@@ -190,6 +191,9 @@ def main():
             out["roofline"]["pipeline_bytes_per_frame"] = bytes_frame
             out["roofline"]["pipeline_achieved_GBs"] = fps / world * bytes_frame / 1e9
             out["roofline"]["pipeline_frac"] = fps / world * bytes_frame / 1e9 / HBM_PEAK_GBS
+        elif prof:
+            out["roofline"] = roofline_of(prof, "k_fast")  # --no-replay: the kernel named by the isolated runs so far
+            out["roofline"]["overlapped_streams"] = True
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)
         print(json.dumps(out))

@@ -12,7 +12,7 @@ def per_kernel(db, counter):
     c = sqlite3.connect(db)
     out = {}
     for name, v in c.execute("select kernel_name, avg(value) from counters_collection where counter_name=? group by kernel_name", (counter,)):
-        out[name.split("(")[0].split("::")[-1]] = v
+        out[name.split("(")[0].split("::")[-1].split("<")[0]] = v  # "void orbx::k_fast<48>(...)" -> "k_fast"
     return out
 
 

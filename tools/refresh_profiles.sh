@@ -1,0 +1,26 @@
+#!/bin/bash
+# On the GPU box (via gpurun): regenerate everything kept under profiles/ for round TAG (default r01) into
+# gpurun_out/.  rocprofv3 passes are separate runs: --kernel-trace --stats, then one --pmc pass per counter set
+# (never combined with tracing), PMC passes in ORBX_SERIAL=1 so that every kernel is alone on the GPU.
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+ORBX_SERIAL=1 python $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_serial.json 2>> $O/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats -d /tmp/prof_o -o t -- python $R/bench.py --no-cpu-baseline --no-replay > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
+python $R/tools/rocprof_summary.py stats /tmp/prof_o/t_results.db > $O/${TAG}_kernel_stats.txt
+python $R/tools/timeline.py /tmp/prof_o/t_results.db 40 > $O/${TAG}_timeline.txt
+ORBX_SERIAL=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o t -- python $R/bench.py --no-cpu-baseline --no-replay > /dev/null 2>&1
+python $R/tools/rocprof_summary.py stats /tmp/prof_s/t_results.db > $O/${TAG}_kernel_stats_serial.txt
+export ORBX_SERIAL=1
+pmc() { # tag, counters
+  rocprofv3 --pmc $2 -d /tmp/pmc_$1 -o p -- python $R/bench.py --no-cpu-baseline --no-profile --steps 3 --warmup 1 > /dev/null 2>&1
+}
+pmc fetch "FETCH_SIZE"; python $R/tools/rocprof_summary.py pmc /tmp/pmc_fetch/p_results.db > $O/${TAG}_pmc_fetch.txt
+pmc write "WRITE_SIZE"; python $R/tools/rocprof_summary.py pmc /tmp/pmc_write/p_results.db > $O/${TAG}_pmc_write.txt
+python $R/tools/pmc_traffic.py /tmp/pmc_fetch/p_results.db /tmp/pmc_write/p_results.db $O/${TAG}_pmc_traffic.json > /dev/null
+pmc sqa "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; python $R/tools/pmc_table.py /tmp/pmc_sqa/p_results.db > $O/${TAG}_pmc_sq_a.txt
+pmc sqb "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"; python $R/tools/pmc_table.py /tmp/pmc_sqb/p_results.db > $O/${TAG}_pmc_sq_b.txt
+pmc sqc "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8 GRBM_GUI_ACTIVE"; python $R/tools/pmc_table.py /tmp/pmc_sqc/p_results.db > $O/${TAG}_pmc_sq_c.txt
+ls -la $O | tail -15
