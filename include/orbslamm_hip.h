@@ -96,10 +96,11 @@ int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int 
 
 /* Device-resident form: frames already in HBM (d_imgs + f*frame_pitch, rows `stride`
  * bytes apart; base, stride and frame_pitch must be multiples of 4).  Results stay
- * in handle-owned HBM (see orbx_device_results); asynchronous on the handle's stream. */
+ * in handle-owned HBM (see orbx_device_results); asynchronous on the handle's streams (orbx_sync waits). */
 int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int B, int w, int h_,
                               int stride, size_t frame_pitch);
-/* device pointers of the last batch: kps[B][cap], desc[B][cap][32], counts[B] */
+/* device pointers of the last batch: kps[B][cap], desc[B][cap][32], counts[B].  Results alternate between two
+ * sets: the pointers are those of the batch just extracted and stay untouched until the next-but-one extraction. */
 int orbx_device_results(orbx_t* h, OrbxKeyPoint** d_kps, uint8_t** d_desc, int32_t** d_counts, int* cap);
 /* blocking D2H copy of one frame of the last batch */
 int orbx_download(orbx_t* h, int frame, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
@@ -128,7 +129,9 @@ int orbx_upload(orbx_t* h, void* d_dst, const void* h_src, size_t bytes);
  * Brute-force best/second Hamming over ALL previous-frame descriptors in index order,
  * accept best<=th_low && (float)best < nnratio*(float)second, rotation histogram and
  * three-maxima pruning exactly as ORBmatcher::SearchByBoW does (src/ORBmatcher.cc:230-287).
- * Results stay in HBM: match[B][cap] (int32, -1 = none), nmatch[B]. */
+ * Results stay in HBM: match[B][cap] (int32, -1 = none), nmatch[B].
+ * Call it once after every orbx_extract_batch_device of the stream: it also rolls the batch's last frame into
+ * the previous-frame slot the next batch is matched against. */
 int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low, int check_ori);
 int orbx_device_matches(orbx_t* h, int32_t** d_match, int32_t** d_nmatch);
 int orbx_download_matches(orbx_t* h, int frame, int32_t* match, int cap, int* nmatch);
