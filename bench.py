@@ -173,7 +173,7 @@ def main():
             traffic = None
             try:  # PMC pass (separate rocprofv3 --pmc runs), KB per 64-frame launch as reported
                 t = json.load(open(os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")))[dom]
-                traffic = (t["fetch_kb"] + t["write_kb"]) * 1024.0 * frames_per_launch / t["frames_per_launch"]
+                traffic = (t["fetch_kb"] * t.get("fetch_scale", 1.0) + t["write_kb"]) * 1024.0 * frames_per_launch / t["frames_per_launch"]
             except Exception:
                 pass
             return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -707,6 +707,9 @@ static int check_device(orbx_handle* h)
 }
 
 // ------------------------------------------------------------------ the pipeline
+// grid.y of the launches that map (block, frame) through xcd_block_frame
+static inline unsigned xcd_grid_y(int nb) { return nb < 8 ? (unsigned)nb : 8u * (unsigned)((nb + 7) / 8); }
+
 // make `s` wait for every sub-batch of the last extraction
 static int join_parts(orbx_handle* h, hipStream_t s)
 {
@@ -764,18 +767,18 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         HIPCHK(hipEventRecord(h->evPyr[part], s));
         HIPCHK(hipStreamWaitEvent(s2, h->evPyr[part], 0));
         h->prof.begin(P_BLUR, s2);
-        hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], nb), dim3(256), 0, s2, h->d_geom, src, h->blurTiles);
+        hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], xcd_grid_y(nb)), dim3(256), 0, s2, h->d_geom, src, h->blurTiles, nb);
         h->prof.end(s2);
         HIPCHK(hipEventRecord(h->evBlur[part], s2));
         if (g.totalCells > 0) {
             const size_t lds = (size_t)2 * (h->tileRows * h->tileStrideDw + 4) * 4 + (size_t)h->fastListCap * 2;
             h->prof.begin(P_FAST, s);
             if (h->tileStrideDw == 12)
-                hipLaunchKernelGGL(k_fast<48>, dim3(g.totalCells, nb), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
-                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap);
+                hipLaunchKernelGGL(k_fast<48>, dim3(g.totalCells, xcd_grid_y(nb)), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
+                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap, nb);
             else
-                hipLaunchKernelGGL(k_fast<80>, dim3(g.totalCells, nb), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
-                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap);
+                hipLaunchKernelGGL(k_fast<80>, dim3(g.totalCells, xcd_grid_y(nb)), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
+                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap, nb);
             h->prof.end(s);
         }
         h->prof.begin(P_DISTRIBUTE, s);
@@ -795,8 +798,8 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         // the output slots are still being read by the previous batch's matching on stream3
         if (h->matchPending[set]) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set], 0));  // the matching two batches back read this set
         h->prof.begin(P_ORIENT_DESC, s);
-        hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, nb), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
-                           h->d_keptCount, r_kps(h, set) + h->maxKp, r_desc(h, set) + (size_t)h->maxKp * 32, r_count(h, set) + 1);
+        hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, xcd_grid_y(nb)), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
+                           h->d_keptCount, r_kps(h, set) + h->maxKp, r_desc(h, set) + (size_t)h->maxKp * 32, r_count(h, set) + 1, nb);
         h->prof.end(s);
         HIPCHK(hipEventRecord(h->evPart[h->lastParts++], s));
     }

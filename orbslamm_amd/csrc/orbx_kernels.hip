@@ -32,6 +32,21 @@ __device__ __forceinline__ const uint8_t* level_ptr(const Geom* g, const FrameSr
     return s.pyr + (int64_t)f * g->pyrFrameBytes + g->lv[l].pyrOff;
 }
 
+// XCD-aware (block, frame) mapping for launches of grid (blocksPerFrame, xcd_grid_y(frames)): workgroups are dealt
+// round-robin to the 8 XCDs in linear order, so without this the neighbours of one frame (which share cache
+// lines: cell aprons, blur halos, overlapping keypoint patches) land on 8 different L2s and every line is fetched
+// up to 8 times.  Here XCD x works through frames x, x+8, ... one after the other.
+__device__ __forceinline__ bool xcd_block_frame(int nframes, int& blk, int& fr)
+{
+    if (nframes < 8) { blk = blockIdx.x; fr = blockIdx.y; return true; }  // too few frames to give every XCD one: grid (blocksPerFrame, frames)
+    const int total = gridDim.x;
+    const int lin = blockIdx.y * total + blockIdx.x;
+    const int k = lin >> 3;
+    fr = (k / total) * 8 + (lin & 7);
+    blk = k - (k / total) * total;
+    return fr < nframes;
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt()
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -280,12 +295,14 @@ template <int TSB>
 __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const Cell* __restrict__ cells,
                                             FrameSrc src, uint64_t* __restrict__ cand,
                                             int32_t* __restrict__ cellCount, int32_t* __restrict__ errFlag,
-                                            int tileRows, int listCap)
+                                            int tileRows, int listCap, int nframes)
 {
     extern __shared__ uint32_t lds[];
     constexpr int TSD = TSB / 4;
-    const Cell c = cells[blockIdx.x];
-    const int f = blockIdx.y + src.f0;
+    int bx, fr;
+    if (!xcd_block_frame(nframes, bx, fr)) return;
+    const Cell c = cells[bx];
+    const int f = fr + src.f0;
     const int lane = threadIdx.x;
     const int level = c.level;
     const LevelGeom& L = g->lv[level];
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     }
     __syncthreads();
     // every cell owns a fixed segment of the candidate buffer (no atomics, deterministic layout)
-    int32_t* myCount = cellCount + (int64_t)f * g->totalCells + blockIdx.x;
+    int32_t* myCount = cellCount + (int64_t)f * g->totalCells + bx;
     if (nA + nB == 0) { if (lane == 0) *myCount = 0; return; }
 
     // stage 2: exact score on the dense lists; pixels with S > tq (corners at the lower
@@ -962,7 +979,7 @@ constexpr int kBlurTW = 120, kBlurTH = 32;
 // transposes of the input dwords; row sums <= 257*255 fit 16 bits), the horizontal pass then works on the
 // 16-bit sums, whose horizontally adjacent pairs are naturally packed for v_dot2_u32_u16.
 // Tile: 120 x 32 outputs; input 128 x 38 (4 px / 3 rows of halo, dword aligned).
-__global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt)
+__global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt, int nframes)
 {
     constexpr int TW = kBlurTW, TH = kBlurTH;
     constexpr int IN_DW = (TW + 8) / 4;       // 32 dwords per input row (4 px margin each side)
@@ -970,10 +987,12 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     constexpr int VS_STRIDE = IN_DW * 2 + 2;  // 66 dwords of u16 pairs per row, even for b64 access
     __shared__ uint32_t in[(TH + 6) * IN_STRIDE];
     __shared__ uint32_t vs[TH * VS_STRIDE];
-    const int f = blockIdx.y + src.f0;
+    int bx, fr;
+    if (!xcd_block_frame(nframes, bx, fr)) return;
+    const int f = fr + src.f0;
     int l = 0;
-    while (l + 1 < g->nlevels && (int)blockIdx.x >= bt.base[l + 1]) l++;
-    const int tIdx = blockIdx.x - bt.base[l];
+    while (l + 1 < g->nlevels && bx >= bt.base[l + 1]) l++;
+    const int tIdx = bx - bt.base[l];
     const int tx0 = (tIdx % bt.tilesX[l]) * TW, ty0 = (tIdx / bt.tilesX[l]) * TH;
     const LevelGeom& L = g->lv[l];
     const int w = L.w, h = L.h;
@@ -1156,18 +1175,20 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
                                                     const uint64_t* __restrict__ kept,
                                                     const int32_t* __restrict__ keptCount,
                                                     OrbxKeyPointDev* __restrict__ outKps,
-                                                    uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount)
+                                                    uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount, int nframes)
 {
     __shared__ int32_t spat[256];  // 256 tests x (x0,y0,x1,y1) int8
     __shared__ int32_t sumax[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f = blockIdx.y + src.f0;
+    int bx, fr;
+    if (!xcd_block_frame(nframes, bx, fr)) return;
+    const int f = fr + src.f0;
     spat[tid] = ((const int32_t*)d_pattern)[tid];
     if (tid < 16) sumax[tid] = g->umax[tid];
     __syncthreads();
     int l = 0;
-    while (l + 1 < g->nlevels && (int)blockIdx.x >= kb.base[l + 1]) l++;
-    const int idx = ((int)blockIdx.x - kb.base[l]) * 4 + wave;
+    while (l + 1 < g->nlevels && bx >= kb.base[l + 1]) l++;
+    const int idx = (bx - kb.base[l]) * 4 + wave;
     const int nl = g->nlevels;
     int before = 0, totalAll = 0;
     for (int i = 0; i < nl; i++) {
@@ -1175,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
         if (i < l) before += c;
         totalAll += c;
     }
-    if (blockIdx.x == 0 && tid == 0) outCount[f] = totalAll < g->maxKp ? totalAll : g->maxKp;
+    if (bx == 0 && tid == 0) outCount[f] = totalAll < g->maxKp ? totalAll : g->maxKp;
     if (idx >= keptCount[f * nl + l]) return;
     const int o = before + idx;
     if (o >= g->maxKp) return;

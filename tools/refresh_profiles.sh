@@ -23,4 +23,8 @@ python $R/tools/pmc_traffic.py /tmp/pmc_fetch/p_results.db /tmp/pmc_write/p_resu
 pmc sqa "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; python $R/tools/pmc_table.py /tmp/pmc_sqa/p_results.db > $O/${TAG}_pmc_sq_a.txt
 pmc sqb "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"; python $R/tools/pmc_table.py /tmp/pmc_sqb/p_results.db > $O/${TAG}_pmc_sq_b.txt
 pmc sqc "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8 GRBM_GUI_ACTIVE"; python $R/tools/pmc_table.py /tmp/pmc_sqc/p_results.db > $O/${TAG}_pmc_sq_c.txt
+if [ -x $R/build_ub/fetch_calib ]; then
+  rocprofv3 --pmc FETCH_SIZE -d /tmp/c1 -o p -- $R/build_ub/fetch_calib > /dev/null 2>&1; rocprofv3 --pmc WRITE_SIZE -d /tmp/c2 -o p -- $R/build_ub/fetch_calib > /dev/null 2>&1
+  { echo "# tools/ubench/fetch_calib.hip: read_b1 = 64 MiB at 1 B/lane, read_b4 / read_b16 = 512 MiB at 4 / 16 B/lane, write_b4 = 512 MiB (values in KB)"; python $R/tools/rocprof_summary.py pmc /tmp/c1/p_results.db; python $R/tools/rocprof_summary.py pmc /tmp/c2/p_results.db; } > $O/${TAG}_fetch_calibration.txt
+fi
 ls -la $O | tail -15
