@@ -149,6 +149,7 @@ struct orbx_handle {
     // extractions, so that the matching of batch n (set n & 1) never holds back the descriptors of batch n + 1
     int curSet = 0;
     bool serial = false;                      // ORBX_SERIAL=1: everything on one stream (profiling aid)
+    bool matchPopcount = false;               // ORBX_MATCH_POPCOUNT=1: xor/popcount scan instead of the int8 MFMA scan
     // device buffers (sized for maxW x maxH x maxB at create)
     Geom* d_geom = nullptr;
     Cell* d_cells = nullptr; size_t cellsCap = 0;
@@ -498,6 +499,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     if (rc) { delete h; return rc; }
     h->device = device;
     { const char* e = getenv("ORBX_SERIAL"); h->serial = e && e[0] == '1'; }
+    { const char* e = getenv("ORBX_MATCH_POPCOUNT"); h->matchPopcount = e && e[0] == '1'; }
     { const char* e = getenv("ORBX_SPLIT"); if (e && e[0] >= '1' && e[0] <= '4') h->nsplit = e[0] - '0'; }
     h->maxW = max_w; h->maxH = max_h; h->maxB = max_batch;
     if (device < 0) { *out = h; return ORBX_OK; }  // host-only handle: tables and geometry queries
@@ -1004,10 +1006,15 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     h->prof.begin(P_MATCH_BEST2, s);
     // slots 0..B expanded to +-1 bytes, then the Hamming scan as an int8 MFMA product (train slot f, query slot f+1)
     // with the acceptance rule in its epilogue
-    hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(h->xPitch / 4096), B + 1), dim3(256), 0, s, io, 0, 0, r_xdesc(h, set), h->xPitch);
-    {
+    const orbm::AcceptArgs aa = {io, io, 1, 0, nnratio, th_low, check_ori, h->d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist};
+    if (h->matchPopcount) {  // the literal xor + popcount scan (lane = query, train descriptor wave-uniform), kept for A/B runs
+        hipLaunchKernelGGL(orbm::k_match_best2, dim3((h->maxKp + 255) / 256, B, kMatchChunks), dim3(256), 0, s, io, io, 1, 0,
+                           kMatchChunks, h->d_partial, (int64_t)h->maxKp);
+        hipLaunchKernelGGL(orbm::k_match_accept, dim3((h->maxKp + 255) / 256, B), dim3(256), 0, s, aa, kMatchChunks,
+                           (const uint2*)h->d_partial, (int64_t)h->maxKp);
+    } else {
+        hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(h->xPitch / 4096), B + 1), dim3(256), 0, s, io, 0, 0, r_xdesc(h, set), h->xPitch);
         const int nqb = (h->maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
-        const orbm::AcceptArgs aa = {io, io, 1, 0, nnratio, th_low, check_ori, h->d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist};
         hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, s, (const uint8_t*)r_xdesc(h, set), h->xPitch, aa, nqb, B);
     }
     h->prof.end(s);

@@ -187,6 +187,26 @@ def test_batch_and_device_path_agree_with_single(gpu, oracle):
     assert nm == nr and np.array_equal(m[:len(k0)], mr)
 
 
+def test_matrix_core_scan_equals_popcount_scan(gpu, monkeypatch):
+    """the stream matcher's two scans -- +-1 int8 product on the matrix cores (default) and the literal
+    xor + popcount scan (ORBX_MATCH_POPCOUNT=1) -- give identical match tables over consecutive batches"""
+    w, h, nf, B = 1241, 376, 2000, 8
+    fr = frames_for(w, h, 2 * B, stream=9)
+    out = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("ORBX_MATCH_POPCOUNT", env)
+        gex = gpu_extractor(nf, w, h, B=B)
+        got = []
+        for b in range(2):
+            gex.extract_batch_device(*gex.upload_frames(fr[b * B:(b + 1) * B], stride=1280))
+            gex.match_prev_batch_device(0.7, 50, True)
+            got += [gex.download_matches(f) for f in range(B)]
+        out.append(got)
+    for (m0, n0), (m1, n1) in zip(*out):
+        assert n0 == n1 and np.array_equal(m0, m1)
+    assert sum(n for _, n in out[0]) > 5000
+
+
 def test_properties_full_size(gpu):
     """size-independent properties at BASELINE's full size with 64 frames in flight"""
     w, h, nf, B = 1241, 376, 2000, 64
