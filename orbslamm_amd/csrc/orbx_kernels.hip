@@ -164,39 +164,53 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
         __syncthreads();  // also orders the previous level's tile writes before the reads below
         const int offP = offBuf[(l - 1) & 1], offC = offBuf[l & 1];
         if (gpr > 0) {
-            int yy = tid / gpr, gx = tid - yy * gpr;
-            const int dr = 256 / gpr, dc = 256 - dr * gpr;
-            while (yy < chh) {
-                const uint2 yt = syt[yy];
-                const int sy0 = (int16_t)(yt.x & 0xFFFF), sy1 = (int16_t)(yt.x >> 16);
-                const int b0 = (int16_t)(yt.y & 0xFFFF), b1 = (int16_t)(yt.y >> 16);
-                const int o0 = offP + (sy0 - pny0) * pstride - pnx0;
-                const int o1 = offP + (sy1 - pny0) * pstride - pnx0;
-                uint32_t packed = 0;
+            // thread = (dword group gx, row lane): the four x-coefficient entries of the group are unpacked once
+            // and reused down the rows the thread owns (rows yy0, yy0 + dr, ...)
+          for (int gxb = 0; gxb < gpr; gxb += 256) {  // one pass unless the tile is wider than 1024 px
+            const int cols = min(256, gpr - gxb);
+            const int dr = 256 / cols;           // row lanes
+            const int yy0 = tid / cols, gx = gxb + tid - yy0 * cols;
+            if (yy0 < dr) {
+                int sx[4], a0[4], a1[4];
+                bool interp[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint2 xt = sxt[4 * gx + i];
-                    const int sx = (int)(xt.x & 0xFFFF);
-                    const int a0 = (int16_t)(xt.x >> 16), a1 = (int16_t)(xt.y & 0xFFFF);
-                    const int s00 = ldsb[o0 + sx], s10 = ldsb[o1 + sx];
-                    int r0, r1;
-                    if (xt.y >> 16) {
-                        r0 = s00 * a0 + ldsb[o0 + sx + 1] * a1;
-                        r1 = s10 * a0 + ldsb[o1 + sx + 1] * a1;
-                    } else {
-                        r0 = s00 * 2048;
-                        r1 = s10 * 2048;
-                    }
-                    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                    packed |= (uint32_t)(v & 0xFF) << (8 * i);
+                    sx[i] = (int)(xt.x & 0xFFFF) - pnx0;
+                    a0[i] = (int16_t)(xt.x >> 16);
+                    a1[i] = (int16_t)(xt.y & 0xFFFF);
+                    interp[i] = (xt.y >> 16) != 0;
                 }
-                plds[(offC >> 2) + yy * gpr + gx] = packed;
-                const int dx = c.nx0 + 4 * gx, dy = c.ny0 + yy;
-                if (dy >= c.oy0 && dy < c.oy1 && dx >= c.ox0 && dx < c.ox1)
-                    *(uint32_t*)(D + (int64_t)dy * dstStride + dx) = packed;  // own ranges are 4-aligned in x
-                yy += dr; gx += dc;
-                if (gx >= gpr) { gx -= gpr; yy++; }
+                const int dx = c.nx0 + 4 * gx;
+                const bool ownX = dx >= c.ox0 && dx < c.ox1;
+                for (int yy = yy0; yy < chh; yy += dr) {
+                    const uint2 yt = syt[yy];
+                    const int sy0 = (int16_t)(yt.x & 0xFFFF), sy1 = (int16_t)(yt.x >> 16);
+                    const int b0 = (int16_t)(yt.y & 0xFFFF), b1 = (int16_t)(yt.y >> 16);
+                    const int o0 = offP + (sy0 - pny0) * pstride;
+                    const int o1 = offP + (sy1 - pny0) * pstride;
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int s00 = ldsb[o0 + sx[i]], s10 = ldsb[o1 + sx[i]];
+                        int r0, r1;
+                        if (interp[i]) {
+                            r0 = s00 * a0[i] + ldsb[o0 + sx[i] + 1] * a1[i];
+                            r1 = s10 * a0[i] + ldsb[o1 + sx[i] + 1] * a1[i];
+                        } else {
+                            r0 = s00 * 2048;
+                            r1 = s10 * 2048;
+                        }
+                        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                        packed |= (uint32_t)(v & 0xFF) << (8 * i);
+                    }
+                    plds[(offC >> 2) + yy * gpr + gx] = packed;
+                    const int dy = c.ny0 + yy;
+                    if (ownX && dy >= c.oy0 && dy < c.oy1)
+                        *(uint32_t*)(D + (int64_t)dy * dstStride + dx) = packed;  // own ranges are 4-aligned in x
+                }
             }
+          }
         }
         p = c;
         pstride = cstride;
