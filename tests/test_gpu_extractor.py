@@ -298,6 +298,37 @@ def test_errors_do_not_poison_the_handle(gpu, oracle):
     assert_same(oracle.Extractor(500, 1.2, 8, 20, 7)(img), *gex(img))  # still works, still exact
 
 
+@pytest.mark.parametrize("B", [16, 8, 3])
+def test_pipelined_batches_without_sync(gpu, oracle, B):
+    """batches enqueued back to back (no host sync in between, as bench.py does): sub-batch streams persist
+    across calls, results alternate between two sets, matching runs beside the next extraction.  The last
+    batch of every run -- keypoints, descriptors, matches incl. frame 0 against the previous batch's last
+    frame -- must equal the oracle's."""
+    w, h, nf, nbatch = 640, 480, 1000, 6
+    fr = frames_for(w, h, nbatch * B, stream=41)
+    gex = gpu_extractor(nf, w, h, B=B)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    dargs = [gex.upload_frames(fr[b * B:(b + 1) * B], stride=640) for b in range(nbatch)]
+    ref = {}
+    for K in (2, 3, 6, 5):
+        gex.reset_stream()
+        for b in range(K):
+            gex.extract_batch_device(*dargs[b])
+            gex.match_prev_batch_device(0.7, 50, True)
+        first = (K - 1) * B
+        for f in range(first - 1, first + B):
+            if f not in ref:
+                ref[f] = oex(fr[f])
+        for f in range(B):
+            k, d = gex.download(f)
+            r = ref[first + f]
+            assert r["kps"].tobytes() == k.tobytes() and np.array_equal(r["desc"], d), "K=%d frame %d" % (K, f)
+            p = ref[first + f - 1]
+            m, nm = gex.download_matches(f)
+            mr, nr = oracle.match_bruteforce(d, k["angle"], p["desc"], p["kps"]["angle"], 0.7, 50, True)
+            assert nm == nr and np.array_equal(m[:len(k)], mr), "K=%d frame %d matches" % (K, f)
+
+
 def test_soak_256_frames_bit_exact(gpu, oracle):
     """4 streams x 64 consecutive frames at the benchmark shape through the device-resident
     batch path: every keypoint record, descriptor byte and match index against the oracle
