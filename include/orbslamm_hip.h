@@ -261,6 +261,24 @@ int orbm_search_for_triangulation(orbm_t* h,
                                   const float F12[9], float ex, float ey, const float* sf2, const float* sigma2_2, int nlevels,
                                   int only_stereo, int check_ori, int32_t* matches12, int* nmatches);
 
+/* ---- a Frame's matcher-side state held in HBM ------------------------------------------------
+ * The tail of Frame::Frame (src/Frame.cc:196-210: UndistortKeyPoints + AssignFeaturesToGrid) run on DEVICE-resident
+ * extractor output -- e.g. d_keys = kps + f*cap, d_desc = desc + f*cap*32 from orbx_device_results -- so that the
+ * projection searches consume it without a round trip through the host.  The frame copies what it needs (the
+ * extractor's result sets are reused two batches later) and belongs to the matcher handle that created it. */
+typedef struct orbm_frame orbm_frame_t;
+int orbm_frame_create(orbm_t* h, const OrbxKeyPoint* d_keys, const uint8_t* d_desc, int n,
+                      const float K[4], const float D[5], const OrbmGrid* grid, orbm_frame_t** out);
+int orbm_frame_destroy(orbm_frame_t* f);
+int orbm_frame_size(const orbm_frame_t* f);
+/* mvKeysUn for the host side of Tracking (pose optimisation reads it) */
+int orbm_frame_download_keys_un(orbm_frame_t* f, OrbxKeyPoint* keys_un);
+/* orbm_search_by_projection with the frame as train side (CurrentFrame of modes 3-5, the KeyFrame of mode 6) */
+int orbm_search_by_projection_frame(orbm_t* h, const OrbmProjParams* pp,
+                                    const float* q_uvr, const int8_t* q_lvl, const uint8_t* qdesc, const float* qangle,
+                                    const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                                    orbm_frame_t* train, uint8_t* t_occ, int32_t* assign, int* nmatches);
+
 /* void Frame::UndistortKeyPoints()   src/Frame.cc:404-434  (cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK)).
  * K = fx, fy, cx, cy; D = k1, k2, p1, p2, k3.  D[0] == 0: plain copy (:406-410).  Only pt changes. */
 int orbm_undistort_keypoints(orbm_t* h, const OrbxKeyPoint* keys, int n, const float K[4], const float D[5],

@@ -1308,6 +1308,24 @@ extern "C" int orbm_search_by_bow(orbm_t* h,
 // ------------------------------------------------------------------ grid + SearchByProjection
 enum { G_KEYS = 16, G_CNT, G_START, G_FILL, G_IDX };
 
+// grid of n device-resident keys into (d_cnt, d_start, d_fill: ncell(+1) ints, d_idx: n ints), on stream s
+static int grid_build_device(const OrbmGrid* grid, const orbm::KeyDev* dk, int n, int32_t* d_cnt, int32_t* d_start,
+                             int32_t* d_fill, int32_t* d_idx, hipStream_t s, orbm::GridDev& gd)
+{
+    const int ncell = grid->cols * grid->rows;
+    gd.minX = grid->minX; gd.minY = grid->minY; gd.invW = grid->invW; gd.invH = grid->invH; gd.cols = grid->cols; gd.rows = grid->rows;
+    HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)ncell * 4, s));
+    HIPCHK(hipMemsetAsync(d_fill, 0, (size_t)ncell * 4, s));
+    if (n) hipLaunchKernelGGL(orbm::k_grid_count, dim3((n + 255) / 256), dim3(256), 0, s, gd, dk, n, d_cnt);
+    hipLaunchKernelGGL(orbm::k_scan_small, dim3(1), dim3(1024), 0, s, (const int32_t*)d_cnt, ncell, d_start);
+    if (n) {
+        hipLaunchKernelGGL(orbm::k_grid_fill, dim3((n + 255) / 256), dim3(256), 0, s, gd, dk, n, (const int32_t*)d_start, d_fill, d_idx);
+        hipLaunchKernelGGL(orbm::k_grid_sort, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, (const int32_t*)d_start, d_idx);
+    }
+    HIPCHK(hipGetLastError());
+    return ORBX_OK;
+}
+
 static int orbm_build_grid(orbm_handle* h, const OrbmGrid* grid, const OrbxKeyPoint* keys, int n, orbm::GridDev& gd)
 {
     if (!grid || grid->cols < 1 || grid->rows < 1 || grid->cols * grid->rows > (1 << 20)) return fail(ORBX_E_INVALID, "bad grid");
@@ -1317,21 +1335,9 @@ static int orbm_build_grid(orbm_handle* h, const OrbmGrid* grid, const OrbxKeyPo
         (rc = orbm_reserve(h, G_START, (size_t)(ncell + 1) * 4)) || (rc = orbm_reserve(h, G_FILL, (size_t)ncell * 4)) ||
         (rc = orbm_reserve(h, G_IDX, (size_t)std::max(n, 1) * 4))) return rc;
     hipStream_t s = h->stream;
-    gd.minX = grid->minX; gd.minY = grid->minY; gd.invW = grid->invW; gd.invH = grid->invH; gd.cols = grid->cols; gd.rows = grid->rows;
     if (n) HIPCHK(hipMemcpyAsync(h->d_buf[G_KEYS], keys, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(h->d_buf[G_CNT], 0, (size_t)ncell * 4, s));
-    HIPCHK(hipMemsetAsync(h->d_buf[G_FILL], 0, (size_t)ncell * 4, s));
-    const orbm::KeyDev* dk = (const orbm::KeyDev*)h->d_buf[G_KEYS];
-    if (n) hipLaunchKernelGGL(orbm::k_grid_count, dim3((n + 255) / 256), dim3(256), 0, s, gd, dk, n, (int32_t*)h->d_buf[G_CNT]);
-    hipLaunchKernelGGL(orbm::k_scan_small, dim3(1), dim3(1024), 0, s, (const int32_t*)h->d_buf[G_CNT], ncell, (int32_t*)h->d_buf[G_START]);
-    if (n) {
-        hipLaunchKernelGGL(orbm::k_grid_fill, dim3((n + 255) / 256), dim3(256), 0, s, gd, dk, n, (const int32_t*)h->d_buf[G_START],
-                           (int32_t*)h->d_buf[G_FILL], (int32_t*)h->d_buf[G_IDX]);
-        hipLaunchKernelGGL(orbm::k_grid_sort, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, (const int32_t*)h->d_buf[G_START],
-                           (int32_t*)h->d_buf[G_IDX]);
-    }
-    HIPCHK(hipGetLastError());
-    return ORBX_OK;
+    return grid_build_device(grid, (const orbm::KeyDev*)h->d_buf[G_KEYS], n, (int32_t*)h->d_buf[G_CNT], (int32_t*)h->d_buf[G_START],
+                             (int32_t*)h->d_buf[G_FILL], (int32_t*)h->d_buf[G_IDX], s, gd);
 }
 
 extern "C" int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const OrbxKeyPoint* keys_un, int n,
@@ -1358,45 +1364,41 @@ extern "C" int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const Orbx
     return ORBX_OK;
 }
 
-extern "C" int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
-                                         const float* q_uvr, const int8_t* q_lvl,
-                                         const uint8_t* qdesc, const float* qangle,
-                                         const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
-                                         const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un,
-                                         const uint8_t* tdesc, int nt,
-                                         uint8_t* t_occ, int32_t* assign, int* nmatches)
-{
-    int rc = orbm_check(h);
-    if (rc) return rc;
-    if (!pp || pp->mode < 3 || pp->mode > 6) return fail(ORBX_E_INVALID, "mode must be 3..6");
-    if (nq < 0 || nt < 0 || (nq && (!q_uvr || !q_lvl || !qdesc)) || (nt && (!t_keys_un || !tdesc || !t_occ || !assign)))
-        return fail(ORBX_E_INVALID, "bad argument");
-    const bool useRot = pp->check_ori && (pp->mode == 4 || pp->mode == 5);
-    if (useRot && nq && !qangle) return fail(ORBX_E_INVALID, "angles required for the rotation check");
-    if (nmatches) *nmatches = 0;
-    if (nq == 0 || nt == 0) return ORBX_OK;
+// train side of a projection search, resident in HBM
+struct ProjTrain {
     orbm::GridDev gd;
-    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, gd))) return rc;
+    const orbm::KeyDev* keys;
+    const int32_t *cellStart, *cellIdx;
+    const uint8_t* desc;
+    int nt;
+};
+
+static int proj_core(orbm_handle* h, const OrbmProjParams* pp, const float* q_uvr, const int8_t* q_lvl, const uint8_t* qdesc,
+                     const float* qangle, const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq, const ProjTrain& tr,
+                     uint8_t* t_occ, int32_t* assign, int* nmatches)
+{
+    int rc;
+    const int nt = tr.nt;
     enum { S_UVR, S_LVL, S_QD, S_QA, S_QV, S_QO, S_TD, S_CNT, S_OFF, S_KEY, S_CIDX, S_OCC, S_ASSIGN, S_NM, S_PUSHT, S_PUSHB };
     const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 2, (size_t)nq * 32, (size_t)nq * 4, (size_t)nq, (size_t)nq,
-                            (size_t)nt * 32, (size_t)nq * 4, (size_t)(nq + 1) * 4, 16, 16, (size_t)nt, (size_t)nt * 4, 16,
+                            16, (size_t)nq * 4, (size_t)(nq + 1) * 4, 16, 16, (size_t)nt, (size_t)nt * 4, 16,
                             (size_t)nq * 4, (size_t)nq};
-    for (int i = 0; i < 16; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    for (int i = 0; i < 16; i++) if (i != S_TD && (rc = orbm_reserve(h, i, sizes[i]))) return rc;
     hipStream_t s = h->stream;
     UP(S_UVR, q_uvr, (size_t)nq * 12); UP(S_LVL, q_lvl, (size_t)nq * 2); UP(S_QD, qdesc, (size_t)nq * 32);
     if (qangle) UP(S_QA, qangle, (size_t)nq * 4);
     if (qvalid) UP(S_QV, qvalid, (size_t)nq);
     if (q_obs_pos) UP(S_QO, q_obs_pos, (size_t)nq);
-    UP(S_TD, tdesc, (size_t)nt * 32); UP(S_OCC, t_occ, (size_t)nt); UP(S_ASSIGN, assign, (size_t)nt * 4);
+    UP(S_OCC, t_occ, (size_t)nt); UP(S_ASSIGN, assign, (size_t)nt * 4);
     orbm::ProjArgs a;
-    a.grid = gd;
-    a.tkeys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
-    a.cellStart = (const int32_t*)h->d_buf[G_START]; a.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    a.grid = tr.gd;
+    a.tkeys = tr.keys;
+    a.cellStart = tr.cellStart; a.cellIdx = tr.cellIdx;
     a.quvr = (const float*)h->d_buf[S_UVR]; a.qlvl = (const int8_t*)h->d_buf[S_LVL];
     a.qdesc = (const uint8_t*)h->d_buf[S_QD]; a.qang = (const float*)h->d_buf[S_QA];
     a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
     a.qobs = q_obs_pos ? (const uint8_t*)h->d_buf[S_QO] : nullptr;
-    a.tdesc = (const uint8_t*)h->d_buf[S_TD];
+    a.tdesc = tr.desc;
     a.nq = nq; a.nt = nt;
     a.candCnt = (int32_t*)h->d_buf[S_CNT]; a.candOff = (int32_t*)h->d_buf[S_OFF];
     a.candKey = nullptr; a.candIdx = nullptr;
@@ -1425,6 +1427,128 @@ extern "C" int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
     HIPCHK(hipStreamSynchronize(s));
     if (nmatches) *nmatches = nm;
     return ORBX_OK;
+}
+
+static int proj_check(orbm_handle* h, const OrbmProjParams* pp, const float* q_uvr, const int8_t* q_lvl, const uint8_t* qdesc,
+                      const float* qangle, int nq, int nt, const uint8_t* t_occ, const int32_t* assign, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (!pp || pp->mode < 3 || pp->mode > 6) return fail(ORBX_E_INVALID, "mode must be 3..6");
+    if (nq < 0 || nt < 0 || (nq && (!q_uvr || !q_lvl || !qdesc)) || (nt && (!t_occ || !assign))) return fail(ORBX_E_INVALID, "bad argument");
+    const bool useRot = pp->check_ori && (pp->mode == 4 || pp->mode == 5);
+    if (useRot && nq && !qangle) return fail(ORBX_E_INVALID, "angles required for the rotation check");
+    if (nmatches) *nmatches = 0;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
+                                         const float* q_uvr, const int8_t* q_lvl,
+                                         const uint8_t* qdesc, const float* qangle,
+                                         const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                                         const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un,
+                                         const uint8_t* tdesc, int nt,
+                                         uint8_t* t_occ, int32_t* assign, int* nmatches)
+{
+    int rc = proj_check(h, pp, q_uvr, q_lvl, qdesc, qangle, nq, nt, t_occ, assign, nmatches);
+    if (rc) return rc;
+    if (nt && (!t_keys_un || !tdesc)) return fail(ORBX_E_INVALID, "bad argument");
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    ProjTrain tr;
+    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, tr.gd))) return rc;
+    if ((rc = orbm_reserve(h, 6, (size_t)nt * 32))) return rc;
+    hipStream_t s = h->stream;
+    UP(6, tdesc, (size_t)nt * 32);
+    tr.keys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
+    tr.cellStart = (const int32_t*)h->d_buf[G_START]; tr.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    tr.desc = (const uint8_t*)h->d_buf[6];
+    tr.nt = nt;
+    return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, tr, t_occ, assign, nmatches);
+}
+
+// ------------------------------------------------------------------ the Frame's matcher-side state in HBM
+struct orbm_frame {
+    orbm_handle* owner = nullptr;
+    int n = 0;
+    orbm::GridDev gd{};
+    orbm::KeyDev* d_keysUn = nullptr;
+    uint8_t* d_desc = nullptr;
+    int32_t *d_cnt = nullptr, *d_start = nullptr, *d_fill = nullptr, *d_idx = nullptr;
+};
+
+extern "C" int orbm_frame_destroy(orbm_frame_t* f)
+{
+    if (!f) return ORBX_OK;
+    if (f->owner && f->owner->device >= 0) {
+        (void)hipSetDevice(f->owner->device);
+        (void)hipStreamSynchronize(f->owner->stream);
+        void* ptrs[] = {f->d_keysUn, f->d_desc, f->d_cnt, f->d_start, f->d_fill, f->d_idx};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+    }
+    delete f;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_frame_create(orbm_t* h, const OrbxKeyPoint* d_keys, const uint8_t* d_desc, int n,
+                                 const float K[4], const float D[5], const OrbmGrid* grid, orbm_frame_t** out)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (!out || n < 0 || (n && (!d_keys || !d_desc)) || !K || !D) return fail(ORBX_E_INVALID, "bad argument");
+    if (!grid || grid->cols < 1 || grid->rows < 1 || grid->cols * grid->rows > (1 << 20)) return fail(ORBX_E_INVALID, "bad grid");
+    *out = nullptr;
+    orbm_frame* f = new orbm_frame;
+    f->owner = h; f->n = n;
+    const int ncell = grid->cols * grid->rows, nn = std::max(n, 1);
+#define FCR(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int r_ = fail(ORBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); orbm_frame_destroy(f); return r_; } } while (0)
+    FCR(hipMalloc(&f->d_keysUn, (size_t)nn * sizeof(OrbxKeyPoint)));
+    FCR(hipMalloc(&f->d_desc, (size_t)nn * 32));
+    FCR(hipMalloc(&f->d_cnt, (size_t)ncell * 4));
+    FCR(hipMalloc(&f->d_start, (size_t)(ncell + 1) * 4));
+    FCR(hipMalloc(&f->d_fill, (size_t)ncell * 4));
+    FCR(hipMalloc(&f->d_idx, (size_t)nn * 4));
+    hipStream_t s = h->stream;
+    if (n) {
+        FCR(hipMemcpyAsync(f->d_desc, d_desc, (size_t)n * 32, hipMemcpyDeviceToDevice, s));
+        if (D[0] == 0.0f) {  // mvKeysUn = mvKeys (Frame.cc:406-410)
+            FCR(hipMemcpyAsync(f->d_keysUn, d_keys, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToDevice, s));
+        } else {
+            orbm::UndistArgs a = {K[0], K[1], K[2], K[3], D[0], D[1], D[2], D[3], D[4]};
+            hipLaunchKernelGGL(orbm::k_undistort, dim3((n + 255) / 256), dim3(256), 0, s, (const orbm::KeyDev*)d_keys, n, a, f->d_keysUn);
+        }
+    }
+#undef FCR
+    if ((rc = grid_build_device(grid, f->d_keysUn, n, f->d_cnt, f->d_start, f->d_fill, f->d_idx, s, f->gd))) { orbm_frame_destroy(f); return rc; }
+    if (hipStreamSynchronize(s) != hipSuccess) { orbm_frame_destroy(f); return fail(ORBX_E_HIP, "frame construction failed"); }
+    *out = f;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_frame_size(const orbm_frame_t* f) { return f ? f->n : 0; }
+
+extern "C" int orbm_frame_download_keys_un(orbm_frame_t* f, OrbxKeyPoint* keys_un)
+{
+    if (!f || !f->owner) return fail(ORBX_E_INVALID, "null frame");
+    int rc = orbm_check(f->owner);
+    if (rc) return rc;
+    if (f->n && !keys_un) return fail(ORBX_E_INVALID, "bad argument");
+    if (f->n) HIPCHK(hipMemcpy(keys_un, f->d_keysUn, (size_t)f->n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_by_projection_frame(orbm_t* h, const OrbmProjParams* pp,
+                                               const float* q_uvr, const int8_t* q_lvl,
+                                               const uint8_t* qdesc, const float* qangle,
+                                               const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                                               orbm_frame_t* train, uint8_t* t_occ, int32_t* assign, int* nmatches)
+{
+    if (!train || train->owner != h) return fail(ORBX_E_INVALID, "frame does not belong to this matcher handle");
+    const int nt = train->n;
+    int rc = proj_check(h, pp, q_uvr, q_lvl, qdesc, qangle, nq, nt, t_occ, assign, nmatches);
+    if (rc) return rc;
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    ProjTrain tr = {train->gd, train->d_keysUn, train->d_start, train->d_idx, train->d_desc, nt};
+    return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, tr, t_occ, assign, nmatches);
 }
 
 // ------------------------------------------------------------------ SURVEY 8(f).1 entry points

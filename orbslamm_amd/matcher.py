@@ -113,6 +113,42 @@ class ORBmatcher:
                                                 ptr(tdesc), t_keys_un.shape[0], ptr(t_occ), ptr(assign), C.byref(n)))
         return assign, t_occ, n.value
 
+    # ---- the Frame's matcher-side state in HBM
+    def frame_from_device(self, d_keys, d_desc, n, K, D, grid):
+        """Frame::Frame tail (UndistortKeyPoints + AssignFeaturesToGrid) on device-resident extractor output;
+        d_keys / d_desc are device addresses (orbx_device_results + frame offsets).  Returns an opaque frame."""
+        K = np.ascontiguousarray(K, dtype=np.float32)
+        D = np.ascontiguousarray(D, dtype=np.float32)
+        f = C.c_void_p()
+        check(self._L.orbm_frame_create(self._h, C.c_void_p(int(d_keys)), C.c_void_p(int(d_desc)), int(n), ptr(K), ptr(D),
+                                        C.byref(grid), C.byref(f)))
+        return f
+
+    def frame_keys_un(self, frame):
+        n = self._L.orbm_frame_size(frame)
+        out = np.zeros(n, dtype=KP_DTYPE)
+        check(self._L.orbm_frame_download_keys_un(frame, ptr(out)))
+        return out
+
+    def frame_destroy(self, frame):
+        check(self._L.orbm_frame_destroy(frame))
+
+    def SearchByProjectionFrame(self, mode, th_dist, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, frame, t_occ, assign):
+        """SearchByProjection with a device-resident frame as train side."""
+        pp = OrbmProjParams(int(mode), self.mfNNratio, int(self.mbCheckOrientation), int(th_dist))
+        q_uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
+        q_lvl = np.ascontiguousarray(q_lvl, dtype=np.int8)
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+        qangle = np.ascontiguousarray(qangle, dtype=np.float32)
+        qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+        qo = None if q_obs_pos is None else np.ascontiguousarray(q_obs_pos, dtype=np.uint8)
+        t_occ = np.ascontiguousarray(t_occ, dtype=np.uint8).copy()
+        assign = np.ascontiguousarray(assign, dtype=np.int32).copy()
+        n = C.c_int(0)
+        check(self._L.orbm_search_by_projection_frame(self._h, C.byref(pp), ptr(q_uvr), ptr(q_lvl), ptr(qdesc), ptr(qangle),
+                                                      ptr(qv), ptr(qo), q_uvr.shape[0], frame, ptr(t_occ), ptr(assign), C.byref(n)))
+        return assign, t_occ, n.value
+
     # ---- SURVEY.md 8(f) rank 1
     def window_best(self, q_uvr, q_pred, qdesc, qvalid, grid, t_keys_un, tdesc, inv_sigma2=None, chi2=False,
                     q_ur=None, t_uright=None):

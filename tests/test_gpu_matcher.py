@@ -271,3 +271,58 @@ def test_undistort_keypoints_parity(gm, oracle):
     assert np.abs(want["x"] - keys["x"]).max() > 1.0 and (want["angle"] == keys["angle"]).all()
     # zero distortion (KITTI): mvKeysUn = mvKeys
     assert gm.UndistortKeyPoints(keys, K, [0, 0, 0, 0, 0]).tobytes() == keys.tobytes()
+
+
+def test_device_frame_feeds_projection_search(gpu, oracle):
+    """extractor output stays in HBM -- the matcher builds the Frame's undistorted keys + grid from the
+    device pointers and the projection searches use it as train side; same results as the oracle fed with the
+    downloaded arrays and as the host-array entry point"""
+    from orbslamm_amd import ORBextractor, ORBmatcher, make_grid, synth
+    w, h, nf = 640, 480, 1000
+    K = [517.306408, 516.469215, 318.643040, 255.313989]
+    D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+    fr = synth.make_frames(w, h, 2, stream=3)
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2, device=0)
+    gex.extract_batch_device(*gex.upload_frames(fr))
+    gex.sync()
+    dk, dd, _, cap = gex.device_results()
+    keys, desc = gex.download(1)
+    nt = len(keys)
+    rng = np.random.default_rng(8)
+    for dist in (D, [0, 0, 0, 0, 0]):
+        want_un = oracle.undistort_keypoints(keys, K, dist)
+        # image bounds of the undistorted frame (Frame::ComputeImageBounds is the caller's; any box works for the test)
+        x0, x1 = float(np.floor(want_un["x"].min())) - 1, float(np.ceil(want_un["x"].max())) + 1
+        y0, y1 = float(np.floor(want_un["y"].min())) - 1, float(np.ceil(want_un["y"].max())) + 1
+        g = make_grid(x0, y0, x1, y1)
+        gp = oracle.make_grid_params(x0, y0, x1, y1)
+        for ratio, ori, mode, th in ((0.9, True, 4, 100), (0.8, False, 3, 100), (0.75, True, 6, 50)):
+            m = ORBmatcher(ratio, ori, device=0)
+            frame = m.frame_from_device(dk + 1 * cap * 28, dd + 1 * cap * 32, nt, K, dist, g)
+            got_un = m.frame_keys_un(frame)
+            assert got_un.tobytes() == want_un.tobytes()
+            start, idx = oracle.grid_build(gp, want_un)
+            nq = 700
+            src = rng.integers(0, nt, nq)
+            qd = desc[src].copy()
+            flip = rng.integers(0, 256, size=(nq, 10))
+            for i in range(nq):
+                for b in flip[i]:
+                    qd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+            uvr = np.zeros((nq, 3), np.float32)
+            uvr[:, 0] = want_un["x"][src] + rng.normal(0, 3, nq)
+            uvr[:, 1] = want_un["y"][src] + rng.normal(0, 3, nq)
+            uvr[:, 2] = (15.0 * np.float32(1.2) ** want_un["octave"][src]).astype(np.float32)
+            lvl = np.stack([want_un["octave"][src] - 1, want_un["octave"][src] + 1], axis=1).astype(np.int8)
+            qa = (want_un["angle"][src] + rng.normal(0, 5, nq)).astype(np.float32) % np.float32(360)
+            qv = (rng.uniform(size=nq) < 0.9).astype(np.uint8)
+            qo = (rng.uniform(size=nq) < 0.7).astype(np.uint8)
+            occ = (rng.uniform(size=nt) < 0.1).astype(np.uint8)
+            a0 = np.full(nt, -1, np.int32)
+            ga, gocc, gn = m.SearchByProjectionFrame(mode, th, uvr, lvl, qd, qa, qv, qo, frame, occ, a0)
+            wa, wocc, wn = oracle.search_by_projection(mode, ratio, ori, th, uvr, lvl, qd, qa, qv, qo, gp, want_un, start, idx,
+                                                       desc, occ, a0)
+            ha, hocc, hn = m.SearchByProjection(mode, th, uvr, lvl, qd, qa, qv, qo, g, want_un, desc, occ, a0)
+            assert gn == wn == hn and wn > 100
+            assert np.array_equal(ga, wa) and np.array_equal(gocc, wocc) and np.array_equal(ga, ha)
+            m.frame_destroy(frame)
