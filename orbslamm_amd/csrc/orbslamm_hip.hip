@@ -572,7 +572,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMemset(h->d_count, 0, 2 * (B + 1) * sizeof(int32_t)));
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
     CRT(hipMemset(h->d_nmatch, 0, B * sizeof(int32_t)));
-    h->pinnedBytes = std::max(h->imgFrameBytes * B, B * (size_t)h->maxKp * (sizeof(OrbxKeyPointDev) + 32 + 4) + 4096);
+    h->pinnedBytes = std::max(h->imgFrameBytes * B, B * (size_t)h->maxKp * (sizeof(OrbxKeyPointDev) + 32) + B * 4 + 4096);
     CRT(hipHostMalloc(&h->h_pinned, h->pinnedBytes));
 #undef CRT
     *out = h;
@@ -911,25 +911,33 @@ extern "C" int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, 
     h->prof.end(h->stream);
     rc = run_extract(h, h->d_img, B, w, hh, dstride, dpitch);
     if (rc) return rc;
+    // One device->host pass behind the kernels, no intermediate host sync: the counts and the full-capacity
+    // keypoint / descriptor slots of the batch go to the pinned staging buffer (the frames it held were consumed
+    // by the upload above), one synchronisation, then the exact n entries are copied out to the caller's arrays.
+    hipStream_t s0 = h->stream;
+    if ((rc = join_parts(h, s0))) return rc;
+    const size_t kpBytes = (size_t)B * h->maxKp * sizeof(OrbxKeyPointDev), dBytes = (size_t)B * h->maxKp * 32;
+    uint8_t* st = h->h_pinned;
+    int32_t* st_cnt = (int32_t*)st;
+    uint8_t* st_kp = st + align_up(B * 4, 64);
+    uint8_t* st_d = st_kp + kpBytes;
+    h->prof.begin(P_D2H, s0);
+    HIPCHK(hipMemcpyAsync(st_cnt, r_count(h, h->curSet) + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+    if (kps) HIPCHK(hipMemcpyAsync(st_kp, r_kps(h, h->curSet) + h->maxKp, kpBytes, hipMemcpyDeviceToHost, s0));
+    if (desc) HIPCHK(hipMemcpyAsync(st_d, r_desc(h, h->curSet) + (size_t)h->maxKp * 32, dBytes, hipMemcpyDeviceToHost, s0));
+    h->prof.end(s0);
     rc = orbx_sync(h);
     if (rc) return rc;
-    // one D2H of counts, then per-frame payloads
-    std::vector<int32_t> counts(B);
-    h->prof.begin(P_D2H, h->stream);
-    HIPCHK(hipMemcpyAsync(counts.data(), r_count(h, h->curSet) + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
     int over = 0;
     for (int f = 0; f < B; f++) {
-        const int n = counts[f];
+        const int n = st_cnt[f];
         if (n_out) n_out[f] = n;
         if (n > cap) { over = 1; continue; }
         if (n > 0) {
-            if (kps) HIPCHK(hipMemcpyAsync(kps + (size_t)f * cap, r_kps(h, h->curSet) + (size_t)(f + 1) * h->maxKp, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToHost, h->stream));
-            if (desc) HIPCHK(hipMemcpyAsync(desc + (size_t)f * cap * 32, r_desc(h, h->curSet) + (size_t)(f + 1) * h->maxKp * 32, (size_t)n * 32, hipMemcpyDeviceToHost, h->stream));
+            if (kps) memcpy(kps + (size_t)f * cap, st_kp + (size_t)f * h->maxKp * sizeof(OrbxKeyPointDev), (size_t)n * sizeof(OrbxKeyPoint));
+            if (desc) memcpy(desc + (size_t)f * cap * 32, st_d + (size_t)f * h->maxKp * 32, (size_t)n * 32);
         }
     }
-    h->prof.end(h->stream);
-    HIPCHK(hipStreamSynchronize(h->stream));
     if (over) return fail(ORBX_E_CAPACITY, "a frame produced more keypoints than cap=%d", cap);
     return ORBX_OK;
 }
