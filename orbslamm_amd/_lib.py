@@ -107,7 +107,8 @@ def lib():
             raise RuntimeError("liborbslamm_hip.so is missing (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                "there is no CPU fallback for the ORB front-end")
         _preload_hip_runtime()
-        L = C.CDLL(SO_PATH)
+        # ORBSLAMM_HIP_LIB: load another build of the same library (A/B timing of kernel variants, tools/ab_bench.sh)
+        L = C.CDLL(os.environ.get("ORBSLAMM_HIP_LIB") or SO_PATH)
         L.orbx_last_error.restype = C.c_char_p
         L.orbx_scale_factor.restype = C.c_float
         for name in EXPORTS:
