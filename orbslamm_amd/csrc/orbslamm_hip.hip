@@ -378,14 +378,14 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
             out.tabs.push_back(make_short4((short)clip(sy), (short)clip(sy + 1), sat((1.f - fy) * 2048), sat(fy * 2048)));
         }
     }
-    // blur tiles (kBlurTW x kBlurTH) and orient/desc blocks (4 keypoints) per level
+    // blur tiles (kBlurTW x kBlurTH) and orient/desc blocks (kKpPerBlock keypoints) per level
     int tb = 0, kb = 0;
     for (int l = 0; l < g.nlevels; l++) {
         out.bt.base[l] = tb;
         out.bt.tilesX[l] = (g.lv[l].w + kBlurTW - 1) / kBlurTW;
         tb += out.bt.tilesX[l] * ((g.lv[l].h + kBlurTH - 1) / kBlurTH);
         out.kb.base[l] = kb;
-        kb += (g.lv[l].keptCap + 3) / 4;
+        kb += (g.lv[l].keptCap + kKpPerBlock - 1) / kKpPerBlock;
     }
     for (int l = g.nlevels; l <= ORBX_MAXL; l++) { out.bt.base[l] = tb; out.kb.base[l] = kb; }
     out.blurTilesTotal = tb;

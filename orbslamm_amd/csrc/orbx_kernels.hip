@@ -1183,26 +1183,48 @@ __device__ __forceinline__ void sincos_0_2pi(double x, double& s, double& c)
     if ((k + 1) & 2) c = -c;
 }
 
-struct KpBlocks { int32_t base[ORBX_MAXL + 1]; };  // block index -> level (4 keypoints per block)
+constexpr int kKpPerBlock = 16;
+struct KpBlocks { int32_t base[ORBX_MAXL + 1]; };  // block index -> level (kKpPerBlock keypoints per block)
 
+// Four keypoints per wave, one per quarter-wave (16 lanes): about half of a keypoint's instructions are
+// quarter-uniform (level and slot bookkeeping, fastAtan2, the binary64 sin/cos, the keypoint record) and cost a
+// full wave instruction however many lanes need them, so one wave now pays them for four keypoints.
+//  * IC_Angle: the 31 x 32 patch as 248 (row, dword) items, 16 per lane, unaligned dword loads all in flight;
+//    the masked moments are v_dot4_u32_u8 sums against per-item byte weights kept in LDS:
+//    m10 = sum dot4(px, u + 16) - 16 * sum dot4(px, 1), m01 = sum v * dot4(px, 1); butterfly over 16 lanes.
+//  * steered BRIEF: lane j of the quarter owns tests j, j + 16, ...; one ballot serves the four keypoints, its
+//    16-bit field of the quarter is descriptor word t, parked in lane t and stored as 16 x 2 bytes.
 __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g, FrameSrc src, KpBlocks kb,
                                                     const uint64_t* __restrict__ kept,
                                                     const int32_t* __restrict__ keptCount,
                                                     OrbxKeyPointDev* __restrict__ outKps,
                                                     uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount, int nframes)
 {
-    __shared__ int32_t spat[256];  // 256 tests x (x0,y0,x1,y1) int8
-    __shared__ int32_t sumax[16];
+    __shared__ float4 spat[256];           // 256 tests x (x0, y0, x1, y1)
+    __shared__ uint32_t swu[256], sw1[256];  // per item: byte weights u + 16 (0 outside the disc), disc flags
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, ql = lane & 15;
     int bx, fr;
     if (!xcd_block_frame(nframes, bx, fr)) return;
     const int f = fr + src.f0;
-    spat[tid] = ((const int32_t*)d_pattern)[tid];
-    if (tid < 16) sumax[tid] = g->umax[tid];
+    {
+        const int32_t pk = ((const int32_t*)d_pattern)[tid];
+        spat[tid] = make_float4((float)(int8_t)(pk & 0xFF), (float)(int8_t)((pk >> 8) & 0xFF),
+                                (float)(int8_t)((pk >> 16) & 0xFF), (float)(int8_t)((pk >> 24) & 0xFF));
+        const int v = (tid >> 3) - kHalfPatch, u0 = 4 * (tid & 7) - 16;
+        const int d = tid < 248 ? g->umax[(v < 0 ? -v : v) & 15] : -1;
+        uint32_t wu = 0, w1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int u = u0 + j;
+            if (u >= -d && u <= d) { wu |= (uint32_t)(u + 16) << (8 * j); w1 |= 1u << (8 * j); }
+        }
+        swu[tid] = wu; sw1[tid] = w1;
+    }
     __syncthreads();
     int l = 0;
     while (l + 1 < g->nlevels && bx >= kb.base[l + 1]) l++;
-    const int idx = (bx - kb.base[l]) * 4 + wave;
+    const int idx = (bx - kb.base[l]) * kKpPerBlock + wave * 4 + q;
     const int nl = g->nlevels;
     int before = 0, totalAll = 0;
     for (int i = 0; i < nl; i++) {
@@ -1211,48 +1233,43 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
         totalAll += c;
     }
     if (bx == 0 && tid == 0) outCount[f] = totalAll < g->maxKp ? totalAll : g->maxKp;
-    if (idx >= keptCount[f * nl + l]) return;
     const int o = before + idx;
-    if (o >= g->maxKp) return;
+    const bool active = idx < keptCount[f * nl + l] && o < g->maxKp;   // uniform over the quarter
+    if (!__builtin_amdgcn_ballot_w64(active)) return;
     const LevelGeom& L = g->lv[l];
-    const uint64_t rec = kept[(int64_t)f * g->keptFrameRecs + L.keptOff + idx];
+    const uint64_t rec = active ? kept[(int64_t)f * g->keptFrameRecs + L.keptOff + idx] : 0;
     const int cx = (int)cand_x(rec) + kMinBorder, cy = (int)cand_y(rec) + kMinBorder;  // :843-844
     int stride;
     const uint8_t* img = level_ptr(g, src, f, l, stride);
     const uint8_t* center = img + (int64_t)cy * stride + cx;
 
-    // IC_Angle: integer moments over the radius-15 disc of the raw level.  The 31 x 32 patch is
-    // read as 248 (row, dword) items, 4 per lane, all loads in flight at once; the dwords are
-    // unaligned (gfx950 global loads allow it), each covers u0..u0+3 of one row.
-    int m10 = 0, m01 = 0;
+    // IC_Angle
+    int m10, m01 = 0;
     {
         struct __attribute__((packed)) U32 { uint32_t v; };
-        uint32_t dw[4];
+        uint32_t dw[16];
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int item = lane + 64 * it;
+        for (int it = 0; it < 16; it++) {
+            const int item = ql + 16 * it;
             const int r = item < 248 ? (item >> 3) : 15, c = item & 7;
             dw[it] = ((const U32*)(center + (r - kHalfPatch) * stride + (4 * c - 16)))->v;
         }
+        uint32_t su = 0, s1 = 0;
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int item = lane + 64 * it;
-            const int v = (item >> 3) - kHalfPatch, u0 = 4 * (item & 7) - 16;
-            const int d = item < 248 ? sumax[(v < 0 ? -v : v) & 15] : -1;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int u = u0 + j;
-                const int val = (u >= -d && u <= d) ? (int)((dw[it] >> (8 * j)) & 0xFF) : 0;
-                m10 += u * val;
-                m01 += v * val;
-            }
+        for (int it = 0; it < 16; it++) {
+            const int item = ql + 16 * it;  // items 248..255 carry zero weights
+            const uint32_t rs = __builtin_amdgcn_udot4(dw[it], sw1[item], 0u, false);
+            su = __builtin_amdgcn_udot4(dw[it], swu[item], su, false);
+            s1 += rs;
+            m01 += ((item >> 3) - kHalfPatch) * (int)rs;
         }
+        m10 = (int)su - 16 * (int)s1;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+        for (int d = 8; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // steered BRIEF on the blurred level: lane j owns tests j, j+64, j+128, j+192
+    // steered BRIEF on the blurred level
     constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
     double sn, cs;
@@ -1260,34 +1277,40 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     const float a = (float)cs, b = (float)sn;
     const int bs = L.blurStride;
     const uint8_t* bc = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)cy * bs + cx;
-    int t0[4], t1[4];
+    uint32_t myWord = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int32_t pk = spat[lane + 64 * r];
-        const float x0 = (float)(int8_t)(pk & 0xFF), y0 = (float)(int8_t)((pk >> 8) & 0xFF);
-        const float x1 = (float)(int8_t)((pk >> 16) & 0xFF), y1 = (float)(int8_t)((pk >> 24) & 0xFF);
-        const int ry0 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int rx0 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int ry1 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int rx1 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        t0[r] = bc[ry0 * bs + rx0];
-        t1[r] = bc[ry1 * bs + rx1];
+    for (int h0 = 0; h0 < 16; h0 += 8) {  // 8 tests = 16 byte loads in flight per lane
+        int t0[8], t1[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const float4 pt = spat[ql + 16 * (h0 + t)];
+            const int ry0 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+            const int rx0 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+            const int ry1 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+            const int rx1 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+            t0[t] = active ? bc[ry0 * bs + rx0] : 0;
+            t1[t] = active ? bc[ry1 * bs + rx1] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(t0[t] < t1[t]);
+            const uint32_t w16 = (uint32_t)(bal >> (16 * q)) & 0xFFFFu;  // tests 16(h0+t) .. +15 of this quarter's keypoint
+            if (ql == h0 + t) myWord = w16;
+        }
     }
-    uint64_t bits[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) bits[r] = __ballot(t0[r] < t1[r]);
-    if (lane < 4) ((uint64_t*)(outDesc + ((int64_t)f * g->maxKp + o) * 32))[lane] =
-        lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
-    if (lane == 0) {
-        OrbxKeyPointDev kp;
-        kp.x = __fmul_rn((float)cx, L.scale);  // level 0: scale == 1.0f, identity (:1095-1101)
-        kp.y = __fmul_rn((float)cy, L.scale);
-        kp.size = L.kpSize;
-        kp.angle = angle;
-        kp.response = (float)cand_resp(rec);
-        kp.octave = l;
-        kp.class_id = -1;
-        outKps[(int64_t)f * g->maxKp + o] = kp;
+    if (active) {
+        ((uint16_t*)(outDesc + ((int64_t)f * g->maxKp + o) * 32))[ql] = (uint16_t)myWord;
+        if (ql == 0) {
+            OrbxKeyPointDev kp;
+            kp.x = __fmul_rn((float)cx, L.scale);  // level 0: scale == 1.0f, identity (:1095-1101)
+            kp.y = __fmul_rn((float)cy, L.scale);
+            kp.size = L.kpSize;
+            kp.angle = angle;
+            kp.response = (float)cand_resp(rec);
+            kp.octave = l;
+            kp.class_id = -1;
+            outKps[(int64_t)f * g->maxKp + o] = kp;
+        }
     }
 }
 
