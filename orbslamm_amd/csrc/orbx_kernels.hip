@@ -1200,8 +1200,17 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
                                                     OrbxKeyPointDev* __restrict__ outKps,
                                                     uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount, int nframes)
 {
+#ifdef ORBX_ORIENT_TIMING
+    uint64_t ts[10]; int nts = 0;
+#define OSTAMP() ts[nts++] = wall_clock64()
+#else
+#define OSTAMP() do {} while (0)
+#endif
+    OSTAMP();
     __shared__ float4 spat[256];           // 256 tests x (x0, y0, x1, y1)
     __shared__ uint32_t swu[256], sw1[256];  // per item: byte weights u + 16 (0 outside the disc), disc flags
+    constexpr int PR = 19, PDW = 10, PROWS = 2 * PR + 1;  // blurred patch: rows cy-19 .. cy+19, bytes cx-19 .. cx+20
+    __shared__ uint32_t spatch[kKpPerBlock][PROWS * PDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, ql = lane & 15;
     int bx, fr;
@@ -1222,6 +1231,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
         swu[tid] = wu; sw1[tid] = w1;
     }
     __syncthreads();
+    OSTAMP();
     int l = 0;
     while (l + 1 < g->nlevels && bx >= kb.base[l + 1]) l++;
     const int idx = (bx - kb.base[l]) * kKpPerBlock + wave * 4 + q;
@@ -1236,6 +1246,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     const int o = before + idx;
     const bool active = idx < keptCount[f * nl + l] && o < g->maxKp;   // uniform over the quarter
     if (!__builtin_amdgcn_ballot_w64(active)) return;
+    OSTAMP();
     const LevelGeom& L = g->lv[l];
     const uint64_t rec = active ? kept[(int64_t)f * g->keptFrameRecs + L.keptOff + idx] : 0;
     const int cx = (int)cand_x(rec) + kMinBorder, cy = (int)cand_y(rec) + kMinBorder;  // :843-844
@@ -1243,6 +1254,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     const uint8_t* img = level_ptr(g, src, f, l, stride);
     const uint8_t* center = img + (int64_t)cy * stride + cx;
 
+    OSTAMP();
     // IC_Angle
     int m10, m01 = 0;
     {
@@ -1267,6 +1279,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
     }
+    OSTAMP();
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // steered BRIEF on the blurred level
@@ -1277,27 +1290,47 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     const float a = (float)cs, b = (float)sn;
     const int bs = L.blurStride;
     const uint8_t* bc = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)cy * bs + cx;
-    uint32_t myWord = 0;
+    OSTAMP();
+    // The 512 sample points of a keypoint lie within radius 18.4 of it: the quarter first copies that patch of the
+    // blurred level into LDS with row-coalesced (unaligned) dword loads -- 25 per lane, ~100 cache lines per wave --
+    // and gathers from there.  Gathering the bytes straight from memory costs one cache-line access per lane and
+    // test (2048 per wave): the kernel then runs at the address rate of the vector-memory pipe (14 of its 19 us).
+    uint32_t* const mypatch = spatch[wave * 4 + q];
+    {
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        constexpr int NIT = (PROWS * PDW + 15) / 16;
+        uint32_t pd[NIT];
 #pragma unroll
-    for (int h0 = 0; h0 < 16; h0 += 8) {  // 8 tests = 16 byte loads in flight per lane
-        int t0[8], t1[8];
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const float4 pt = spat[ql + 16 * (h0 + t)];
-            const int ry0 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-            const int rx0 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-            const int ry1 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-            const int rx1 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-            t0[t] = active ? bc[ry0 * bs + rx0] : 0;
-            t1[t] = active ? bc[ry1 * bs + rx1] : 0;
+        for (int it = 0; it < NIT; it++) {
+            const int item = min(ql + 16 * it, PROWS * PDW - 1);
+            const int r = item / PDW, c = item - r * PDW;
+            pd[it] = active ? ((const U32*)(bc + (r - PR) * bs + (4 * c - PR)))->v : 0u;
         }
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(t0[t] < t1[t]);
-            const uint32_t w16 = (uint32_t)(bal >> (16 * q)) & 0xFFFFu;  // tests 16(h0+t) .. +15 of this quarter's keypoint
-            if (ql == h0 + t) myWord = w16;
+        for (int it = 0; it < NIT; it++) {
+            const int item = ql + 16 * it;
+            if (item < PROWS * PDW) mypatch[item] = pd[it];
         }
     }
+    const uint8_t* const pb = (const uint8_t*)mypatch + PR * (PDW * 4) + PR;  // the keypoint's own pixel
+    uint32_t myWord = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const float4 pt = spat[ql + 16 * t];
+        const int ry0 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+        const int rx0 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+        const int ry1 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+        const int rx1 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+        const int t0 = pb[ry0 * (PDW * 4) + rx0], t1 = pb[ry1 * (PDW * 4) + rx1];
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(t0 < t1);
+        const uint32_t w16 = (uint32_t)(bal >> (16 * q)) & 0xFFFFu;  // tests 16t .. 16t+15 of this quarter's keypoint
+        if (ql == t) myWord = w16;
+    }
+    OSTAMP();
+#ifdef ORBX_ORIENT_TIMING
+    if (lane == 0 && wave == 0 && fr == 0 && (bx % 29) == 0)
+        printf("ORIENT bx %d l %d: barrier %.2f counts %.2f rec %.2f moments %.2f trig %.2f brief %.2f us\n", bx, l, (ts[1]-ts[0])/100.0, (ts[2]-ts[1])/100.0, (ts[3]-ts[2])/100.0, (ts[4]-ts[3])/100.0, (ts[5]-ts[4])/100.0, (ts[6]-ts[5])/100.0);
+#endif
     if (active) {
         ((uint16_t*)(outDesc + ((int64_t)f * g->maxKp + o) * 32))[ql] = (uint16_t)myWord;
         if (ql == 0) {
