@@ -140,7 +140,8 @@ struct orbx_handle {
     int nsplit = 2;                           // sub-batches per call (ORBX_SPLIT)
     hipStream_t streamP[kMaxSplit] = {nullptr};  // pipeline stream of sub-batch p (p = 0 uses `stream`)
     hipStream_t streamB[kMaxSplit] = {nullptr};  // blur runs beside FAST + quadtree
-    hipEvent_t evStart = nullptr, evPart[kMaxSplit] = {nullptr};
+    hipEvent_t evStart = nullptr, evPart[kMaxSplit] = {nullptr}, evFast0[kMaxSplit] = {nullptr};
+    bool partEverRan[kMaxSplit] = {false};
     int lastParts = 0;                        // evPart[0..lastParts) belong to the last extraction
     hipStream_t stream3 = nullptr;            // matching runs beside the next batch's pyramid/FAST
     hipEvent_t evPyr[kMaxSplit] = {nullptr}, evBlur[kMaxSplit] = {nullptr}, evDesc = nullptr, evMatch[2] = {nullptr, nullptr};
@@ -479,6 +480,7 @@ static void free_device(orbx_handle* h)
         if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]);
         if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]);
         if (h->evPart[i]) (void)hipEventDestroy(h->evPart[i]);
+        if (h->evFast0[i]) (void)hipEventDestroy(h->evFast0[i]);
         if (h->streamP[i]) (void)hipStreamDestroy(h->streamP[i]);
         if (h->streamB[i]) (void)hipStreamDestroy(h->streamB[i]);
     }
@@ -526,6 +528,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
         CRT(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
         CRT(hipEventCreateWithFlags(&h->evBlur[i], hipEventDisableTiming));
         CRT(hipEventCreateWithFlags(&h->evPart[i], hipEventDisableTiming));
+        CRT(hipEventCreateWithFlags(&h->evFast0[i], hipEventDisableTiming));
     }
     CRT(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
     CRT(hipEventCreateWithFlags(&h->evDesc, hipEventDisableTiming));
@@ -751,6 +754,29 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         hipStream_t s2 = h->serial ? s : s0;  // blur: see orbx_create on the choice of streams
         if (!h->serial) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
         src.f0 = f0;
+        auto launch_fast = [&](hipStream_t fs, int cell0, int ncells) {
+            if (ncells <= 0) return;
+            const size_t lds = (size_t)2 * (h->tileRows * h->tileStrideDw + 4) * 4 + (size_t)h->fastListCap * 2;
+            h->prof.begin(P_FAST, fs);
+            if (h->tileStrideDw == 12)
+                hipLaunchKernelGGL(k_fast<48>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
+                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap, nb, cell0);
+            else
+                hipLaunchKernelGGL(k_fast<80>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
+                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap, nb, cell0);
+            h->prof.end(fs);
+        };
+        // FAST of level 0 needs no pyramid: on the blur stream it runs beside the (latency-bound) pyramid kernel.
+        // It overwrites this sub-batch's candidate segments, which the previous batch's quadtree read.
+        const int cellsL0 = g.lv[0].nCells;
+        const bool splitFast = !h->serial && g.nlevels > 1;
+        if (splitFast) {
+            if (h->partEverRan[part]) HIPCHK(hipStreamWaitEvent(s2, h->evPart[part], 0));
+            launch_fast(s2, 0, cellsL0);
+            HIPCHK(hipEventRecord(h->evFast0[part], s2));
+        } else {
+            launch_fast(s, 0, cellsL0);
+        }
         if (g.nlevels > 1 && h->pyrFused) {
             const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
             h->prof.begin(P_RESIZE, s);
@@ -772,17 +798,9 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], xcd_grid_y(nb)), dim3(256), 0, s2, h->d_geom, src, h->blurTiles, nb);
         h->prof.end(s2);
         HIPCHK(hipEventRecord(h->evBlur[part], s2));
-        if (g.totalCells > 0) {
-            const size_t lds = (size_t)2 * (h->tileRows * h->tileStrideDw + 4) * 4 + (size_t)h->fastListCap * 2;
-            h->prof.begin(P_FAST, s);
-            if (h->tileStrideDw == 12)
-                hipLaunchKernelGGL(k_fast<48>, dim3(g.totalCells, xcd_grid_y(nb)), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
-                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap, nb);
-            else
-                hipLaunchKernelGGL(k_fast<80>, dim3(g.totalCells, xcd_grid_y(nb)), dim3(64), lds, s, h->d_geom, h->d_cells, src, h->d_candRaw,
-                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap, nb);
-            h->prof.end(s);
-        }
+        // FAST of levels >= 1 behind the pyramid (level 0 went ahead, see above)
+        launch_fast(s, cellsL0, g.totalCells - cellsL0);
+        if (splitFast) HIPCHK(hipStreamWaitEvent(s, h->evFast0[part], 0));
         h->prof.begin(P_DISTRIBUTE, s);
         {
             const size_t dl = dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel);
@@ -804,6 +822,7 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
                            h->d_keptCount, r_kps(h, set) + h->maxKp, r_desc(h, set) + (size_t)h->maxKp * 32, r_count(h, set) + 1, nb);
         h->prof.end(s);
         HIPCHK(hipEventRecord(h->evPart[h->lastParts++], s));
+        h->partEverRan[part] = true;
     }
     HIPCHK(hipGetLastError());
     h->lastB = B;

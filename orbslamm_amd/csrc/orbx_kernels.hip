@@ -309,12 +309,13 @@ template <int TSB>
 __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const Cell* __restrict__ cells,
                                             FrameSrc src, uint64_t* __restrict__ cand,
                                             int32_t* __restrict__ cellCount, int32_t* __restrict__ errFlag,
-                                            int tileRows, int listCap, int nframes)
+                                            int tileRows, int listCap, int nframes, int cell0)
 {
     extern __shared__ uint32_t lds[];
     constexpr int TSD = TSB / 4;
     int bx, fr;
     if (!xcd_block_frame(nframes, bx, fr)) return;
+    bx += cell0;  // the launch covers cells [cell0, cell0 + gridDim.x)
     const Cell c = cells[bx];
     const int f = fr + src.f0;
     const int lane = threadIdx.x;
