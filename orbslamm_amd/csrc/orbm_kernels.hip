@@ -3,9 +3,10 @@
 // Reference: /root/reference/SingleRobotScenario/src/ORBmatcher.cc
 //   DescriptorDistance :1649-1665, acceptance/ratio :230-232, rotation histogram
 //   :238-248, ComputeThreeMaxima :1603-1644, pruning :269-287.
-// 256-bit descriptors are 8 dwords; distance = 8 x (v_xor + v_bcnt).  One lane owns
-// one query and keeps (best, second, index); the train descriptor is wave-uniform
-// and comes in through scalar loads, so the inner loop is pure VALU.
+// 256-bit descriptors are 8 dwords; distance = 8 x (v_xor + v_bcnt) in the windowed searches (one lane owns one
+// query and keeps (best, second, index); the train descriptor is wave-uniform and comes in through scalar loads).
+// The all-pairs scan of the stream matcher runs on the matrix cores instead (k_expand_desc + k_match_mfma): with
+// +-1 bytes a . b = 256 - 2 * Hamming exactly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

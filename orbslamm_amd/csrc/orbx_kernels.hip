@@ -1,14 +1,15 @@
 // orbx_kernels.hip -- gfx950 kernels of the ORB extractor hot path.
 //
 // Stage map (reference: /root/reference/SingleRobotScenario/src/ORBextractor.cc):
-//   k_resize        ComputePyramid :1107-1132 (cv::resize INTER_LINEAR, fixed point)
+//   k_pyramid       ComputePyramid :1107-1132 (cv::resize INTER_LINEAR, fixed point; k_resize_level = per-level fallback)
 //   k_fast          ComputeKeyPointsOctTree cell loop :789-829 (cv::FAST 9/16 + NMS + minTh retry)
 //   k_distribute    DistributeOctTree :539-763 + DivideNode :481-537
 //   k_blur          GaussianBlur 7x7 sigma 2 :1085-1086
 //   k_orient_desc   IC_Angle :77-104, computeOrbDescriptor :108-147, scale/pack :837-847,1095-1101
 //
-// Integer/bitwise path: no MFMA.  64-wide waves, LDS tiles, strict IEEE fp32
-// (no contraction: explicit __fmul_rn/__fadd_rn and -ffp-contract=off).
+// Integer/bitwise path, VALU-issue bound: the kernels are shaped to shed instructions (dot4/dot2/perm/min3/med3,
+// SDWA byte operands, compactions).  64-wide waves, LDS tiles, strict IEEE fp32 where the reference computes in
+// float (no contraction: explicit __fmul_rn/__fadd_rn and -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
