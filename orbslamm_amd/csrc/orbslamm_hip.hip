@@ -523,6 +523,14 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipStreamCreateWithFlags(&h->streamP[0], hipStreamNonBlocking));
     CRT(hipStreamCreateWithFlags(&h->streamP[1], hipStreamNonBlocking));
     CRT(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    // hardware queues are bound at a stream's first use: use the four once, now, in this order
+    {
+        void* scratch = nullptr;
+        CRT(hipMalloc(&scratch, 256));
+        hipStream_t four[4] = {h->stream, h->streamP[0], h->streamP[1], h->stream3};
+        for (hipStream_t st : four) { CRT(hipMemsetAsync(scratch, 0, 256, st)); CRT(hipStreamSynchronize(st)); }
+        CRT(hipFree(scratch));
+    }
     for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
         if (i > 1) CRT(hipStreamCreateWithFlags(&h->streamP[i], hipStreamNonBlocking));
         CRT(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
@@ -1108,6 +1116,8 @@ extern "C" int orbx_profile_enable(orbx_t* h, int enable)
     int rc = check_device(h);
     if (rc) return rc;
     h->prof.on = enable != 0;
+    // events for ~250 steps up front, so that the timed region creates none
+    if (enable) while (h->prof.pool.size() < 8192) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; h->prof.pool.push_back(e); }
     return ORBX_OK;
 }
 

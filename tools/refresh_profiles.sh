@@ -15,7 +15,7 @@ ORBX_SERIAL=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o t -- python $R/
 python $R/tools/rocprof_summary.py stats /tmp/prof_s/t_results.db > $O/${TAG}_kernel_stats_serial.txt
 export ORBX_SERIAL=1
 pmc() { # tag, counters
-  rocprofv3 --pmc $2 -d /tmp/pmc_$1 -o p -- python $R/bench.py --no-cpu-baseline --no-profile --steps 3 --warmup 1 > /dev/null 2>&1
+  rocprofv3 --pmc $2 -d /tmp/pmc_$1 -o p -- python $R/bench.py --no-cpu-baseline --no-profile --steps 5 --warmup 2 > /dev/null 2>&1
 }
 pmc fetch "FETCH_SIZE"; python $R/tools/rocprof_summary.py pmc /tmp/pmc_fetch/p_results.db > $O/${TAG}_pmc_fetch.txt
 pmc write "WRITE_SIZE"; python $R/tools/rocprof_summary.py pmc /tmp/pmc_write/p_results.db > $O/${TAG}_pmc_write.txt
