@@ -126,7 +126,7 @@ struct orbx_handle {
     Geom geom;
     int curW = 0, curH = 0;
     std::vector<Cell> cells;
-    int tileStrideDw = 0, tileRows = 0, fastListCap = 0;
+    int tileStrideDw = 0, tileRows = 0, fastListCap = 0, tileRows0 = 0, fastListCap0 = 0;
     int nodeCap = 0;
     BlurTiles blurTiles;
     KpBlocks kpBlocks;
@@ -233,7 +233,7 @@ struct HostGeom {
     std::vector<Cell> cells;
     std::vector<short4> tabs;          // all x/y tables back to back
     int xoff[ORBX_MAXL], yoff[ORBX_MAXL];
-    int tileStrideDw, tileRows, fastListCap, nodeCap;
+    int tileStrideDw, tileRows, fastListCap, tileRows0, fastListCap0, nodeCap;
     BlurTiles bt;
     int blurTilesTotal;
     KpBlocks kb;
@@ -254,7 +254,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     if (w > 8191 || h0 > 8191) return fail(ORBX_E_UNSUPPORTED, "frame larger than 8191 px");
     out.cells.clear();
     out.tabs.clear();
-    int pyrOff = 0, blurOff = 0, candOff = 0, keptOff = 0, maxRoiW = 8, maxRoiH = 8, nodeCap = 16, maxCells = 1;
+    int pyrOff = 0, blurOff = 0, candOff = 0, keptOff = 0, maxRoiW = 8, maxRoiH = 8, maxRoiW0 = 8, maxRoiH0 = 8, nodeCap = 16, maxCells = 1;
     for (int l = 0; l < g.nlevels; l++) {
         LevelGeom& L = g.lv[l];
         const float scale = h->mvInvScaleFactor[l];
@@ -311,6 +311,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
                     candCap += ((c.w - 6 + 1) / 2) * ((c.h - 6 + 1) / 2);
                     maxRoiW = std::max<int>(maxRoiW, c.w);
                     maxRoiH = std::max<int>(maxRoiH, c.h);
+                    if (l == 0) { maxRoiW0 = std::max<int>(maxRoiW0, c.w); maxRoiH0 = std::max<int>(maxRoiH0, c.h); }
                 }
             }
         }
@@ -342,6 +343,9 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     if (maxRoiW + 5 > 80 || maxRoiW - 6 > 127 || maxRoiH - 6 > 127) return fail(ORBX_E_UNSUPPORTED, "cell larger than the FAST tile");
     out.tileRows = maxRoiH;
     out.fastListCap = ((maxRoiW - 6) * (maxRoiH - 6) + 63) / 64 * 64;  // compacted detection pixels
+    // the level-0 launch (a third of the cells, all of one size) gets its own, smaller LDS footprint: more waves per CU
+    out.tileRows0 = maxRoiH0;
+    out.fastListCap0 = ((maxRoiW0 - 6) * (maxRoiH0 - 6) + 63) / 64 * 64;
     out.nodeCap = align_up(nodeCap, 4);  // k_distribute reads its u32 arrays as uint4
 
     // cv::resize INTER_LINEAR coefficient tables, levels >= 1
@@ -702,6 +706,7 @@ static int configure_shape(orbx_handle* h, int w, int hh)
     h->geom = hg.g;
     h->cells = hg.cells;
     h->tileStrideDw = hg.tileStrideDw; h->tileRows = hg.tileRows; h->fastListCap = hg.fastListCap; h->nodeCap = hg.nodeCap;
+    h->tileRows0 = hg.tileRows0; h->fastListCap0 = hg.fastListCap0;
     h->blurTiles = hg.bt; h->kpBlocks = hg.kb; h->kpBlocksTotal = hg.kbTotal;
     h->geom.totalCells = hg.g.totalCells;
     h->curW = w; h->curH = hh;
@@ -764,14 +769,16 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         src.f0 = f0;
         auto launch_fast = [&](hipStream_t fs, int cell0, int ncells) {
             if (ncells <= 0) return;
-            const size_t lds = (size_t)2 * (h->tileRows * h->tileStrideDw + 4) * 4 + (size_t)h->fastListCap * 2;
+            const bool l0 = cell0 == 0 && ncells == g.lv[0].nCells;  // the level-0 launch
+            const int rows = l0 ? h->tileRows0 : h->tileRows, cap = l0 ? h->fastListCap0 : h->fastListCap;
+            const size_t lds = (size_t)2 * (rows * h->tileStrideDw + 4) * 4 + (size_t)cap * 2;
             h->prof.begin(P_FAST, fs);
             if (h->tileStrideDw == 12)
                 hipLaunchKernelGGL(k_fast<48>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
-                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap, nb, cell0);
+                                   h->d_cellCount, h->d_err, rows, cap, nb, cell0);
             else
                 hipLaunchKernelGGL(k_fast<80>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
-                                   h->d_cellCount, h->d_err, h->tileRows, h->fastListCap, nb, cell0);
+                                   h->d_cellCount, h->d_err, rows, cap, nb, cell0);
             h->prof.end(fs);
         };
         // FAST of level 0 needs no pyramid: on the blur stream it runs beside the (latency-bound) pyramid kernel.
