@@ -605,23 +605,18 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                          candB + (int64_t)f * g->candFrameRecs + L.candOff};
 
     // LDS carve-up (all u32 arrays of `cap` entries unless noted)
-    short4* nb[2];      // bounds x0,x1,y0,y1
-    uint32_t* ns[2];    // key range start
-    uint32_t* nc[2];    // key count | bufId<<31
-    {
-        uint32_t* p = smem;
-        nb[0] = (short4*)p; p += 2 * cap;
-        nb[1] = (short4*)p; p += 2 * cap;
-        ns[0] = p; p += cap; ns[1] = p; p += cap;
-        nc[0] = p; p += cap; nc[1] = p; p += cap;
-    }
+    // the two generations of the node list are addressed as base[set * cap + i]: a pointer picked at run time out of
+    // a two-entry array makes the accesses generic (flat) instead of LDS
+    short4* const nbB = (short4*)smem;       // bounds x0,x1,y0,y1   [2][cap]
+    uint32_t* const nsB = smem + 4 * cap;    // key range start      [2][cap]
+    uint32_t* const ncB = smem + 6 * cap;    // key count | bufId<<31 [2][cap]
     uint32_t* cc = smem + 8 * cap;        // [cap*4] child counts per E-entry
     uint32_t* ord = cc + 4 * cap;         // processing order -> list index
     uint32_t* ord2 = ord + cap;
     uint32_t* tA = ord2 + cap;            // scan scratch
     uint32_t* tB = tA + cap;
     uint32_t* proc = tB + cap;            // processed flag per list index
-    uint32_t* nk[2] = {proc + cap, proc + 2 * cap};  // depth << 24 | path code of the node
+    uint32_t* const nkB = proc + cap;     // depth << 24 | path code of the node [2][cap]
     uint32_t* wtmp = proc + 3 * cap;      // [8]
     __shared__ int sJ;
 
@@ -734,10 +729,10 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     for (int i = tid; i < nIni; i += kDistThreads) {
         if (tB[i]) {
             const int pos = ord2[i];
-            nb[cur][pos] = make_short4((short)(int)__fmul_rn(hX, (float)i), (short)(int)__fmul_rn(hX, (float)(i + 1)), 0, (short)L.winH);
-            ns[cur][pos] = tA[i];
-            nc[cur][pos] = ord[i] | (1u << 31);  // keys are in buffer 1
-            nk[cur][pos] = (uint32_t)i;          // depth 0, path code = root index
+            nbB[cur * cap + pos] = make_short4((short)(int)__fmul_rn(hX, (float)i), (short)(int)__fmul_rn(hX, (float)(i + 1)), 0, (short)L.winH);
+            nsB[cur * cap + pos] = tA[i];
+            ncB[cur * cap + pos] = ord[i] | (1u << 31);  // keys are in buffer 1
+            nkB[cur * cap + pos] = (uint32_t)i;          // depth 0, path code = root index
         }
     }
     __syncthreads();
@@ -748,7 +743,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     for (int iter = 0; iter < 64; iter++) {
         const int prevSize = m;
         // E = nodes with more than one key, in list order
-        for (int i = tid; i < m; i += kDistThreads) tA[i] = (nc[cur][i] & 0x7FFFFFFFu) > 1 ? 1u : 0u;
+        for (int i = tid; i < m; i += kDistThreads) tA[i] = (ncB[cur * cap + i] & 0x7FFFFFFFu) > 1 ? 1u : 0u;
         __syncthreads();
         for (int i = tid; i < m; i += kDistThreads) tB[i] = tA[i];
         __syncthreads();
@@ -768,11 +763,11 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
             if (cap > 8192 || n >= (1 << 19)) {  // key does not pack: plain two-field rank sort
                 for (int e = tid; e < E; e += kDistThreads) {
                     const uint32_t i = ord[e];
-                    const uint32_t ci = nc[cur][i] & 0x7FFFFFFFu;
+                    const uint32_t ci = ncB[cur * cap + i] & 0x7FFFFFFFu;
                     int rank = 0;
                     for (int e2 = 0; e2 < E; e2++) {
                         const uint32_t i2 = ord[e2];
-                        const uint32_t c2 = nc[cur][i2] & 0x7FFFFFFFu;
+                        const uint32_t c2 = ncB[cur * cap + i2] & 0x7FFFFFFFu;
                         rank += (c2 > ci || (c2 == ci && i2 < i)) ? 1 : 0;
                     }
                     ord2[rank] = i;
@@ -782,7 +777,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
             const int E4 = (E + 3) & ~3;  // <= cap (a multiple of 4)
             for (int e = tid; e < E4; e += kDistThreads) {
                 const uint32_t i = e < E ? ord[e] : 0;
-                tA[e] = e < E ? ((nc[cur][i] & 0x7FFFFFFFu) << 13) | (8191u - i) : 0u;
+                tA[e] = e < E ? ((ncB[cur * cap + i] & 0x7FFFFFFFu) << 13) | (8191u - i) : 0u;
             }
             __syncthreads();
             int parts = 1;
@@ -825,18 +820,18 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
             }
             for (int t = done + wave; t < done + chunk; t += NW) {
                 const uint32_t i = ord[t];
-                const short4 b = nb[cur][i];
-                const uint32_t cb = nc[cur][i];
+                const short4 b = nbB[cur * cap + i];
+                const uint32_t cb = ncB[cur * cap + i];
                 const uint32_t cnt = cb & 0x7FFFFFFFu, bid = cb >> 31;
                 const int xm = b.x + ((b.y - b.x + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  :483
                 const int ym = b.z + ((b.w - b.z + 1) >> 1);  // UL.y + ceil((BR.y-UL.y)/2)  :484
                 uint32_t c[4];
-                const uint32_t kd = nk[cur][i];
+                const uint32_t kd = nkB[cur * cap + i];
                 if ((int)(kd >> 24) < D) {  // child counts straight from the histogram, keys stay where they are
                     const uint32_t* c4 = &hst[hoff((int)(kd >> 24) + 1) + 4 * (kd & 0xFFFFFFu)];
                     c[0] = c4[0]; c[1] = c4[1]; c[2] = c4[2]; c[3] = c4[3];
                 } else {
-                    wave_divide(bufs[bid], bufs[bid ^ 1], ns[cur][i], cnt, xm, ym, c);
+                    wave_divide(bufs[bid], bufs[bid ^ 1], nsB[cur * cap + i], cnt, xm, ym, c);
                 }
                 if (lane == 0) { cc[4 * t] = c[0]; cc[4 * t + 1] = c[1]; cc[4 * t + 2] = c[2]; cc[4 * t + 3] = c[3]; }
             }
@@ -879,19 +874,19 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         for (int i = tid; i < m; i += kDistThreads) {
             if (!proc[i]) {
                 const int pos = (int)K + (int)ord2[i];
-                nb[nxt][pos] = nb[cur][i];
-                ns[nxt][pos] = ns[cur][i];
-                nc[nxt][pos] = nc[cur][i];
-                nk[nxt][pos] = nk[cur][i];
+                nbB[nxt * cap + pos] = nbB[cur * cap + i];
+                nsB[nxt * cap + pos] = nsB[cur * cap + i];
+                ncB[nxt * cap + pos] = ncB[cur * cap + i];
+                nkB[nxt * cap + pos] = nkB[cur * cap + i];
             }
         }
         // children: groups in reverse processing order, inside a group n4,n3,n2,n1 (push_front, :621-660)
         int nToExpandLocal = 0;
         for (int t = tid; t <= J; t += kDistThreads) {
             const uint32_t i = ord[t];
-            const short4 b = nb[cur][i];
-            const uint32_t cb = nc[cur][i];
-            const uint32_t kd = nk[cur][i];
+            const short4 b = nbB[cur * cap + i];
+            const uint32_t cb = ncB[cur * cap + i];
+            const uint32_t kd = nkB[cur * cap + i];
             const int dep = (int)(kd >> 24);
             const bool virt = dep < D;                       // divided on the histogram: keys did not move
             const uint32_t bid = (cb >> 31) ^ (virt ? 0u : 1u);
@@ -899,12 +894,12 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
             const int xm = b.x + ((b.y - b.x + 1) >> 1);
             const int ym = b.z + ((b.w - b.z + 1) >> 1);
             const uint32_t c0 = cc[4 * t], c1 = cc[4 * t + 1], c2 = cc[4 * t + 2], c3 = cc[4 * t + 3];
-            const uint32_t st = ns[cur][i];
+            const uint32_t st = nsB[cur * cap + i];
             int pos = (int)(K - (tB[t] + tA[t]));  // sum of k_u for u in (t, J]
-            if (c3) { nb[nxt][pos] = make_short4((short)xm, b.y, (short)ym, b.w); ns[nxt][pos] = st + c0 + c1 + c2; nc[nxt][pos] = c3 | (bid << 31); nk[nxt][pos] = kc + 3; pos++; nToExpandLocal += c3 > 1; }
-            if (c2) { nb[nxt][pos] = make_short4(b.x, (short)xm, (short)ym, b.w); ns[nxt][pos] = st + c0 + c1; nc[nxt][pos] = c2 | (bid << 31); nk[nxt][pos] = kc + 2; pos++; nToExpandLocal += c2 > 1; }
-            if (c1) { nb[nxt][pos] = make_short4((short)xm, b.y, b.z, (short)ym); ns[nxt][pos] = st + c0; nc[nxt][pos] = c1 | (bid << 31); nk[nxt][pos] = kc + 1; pos++; nToExpandLocal += c1 > 1; }
-            if (c0) { nb[nxt][pos] = make_short4(b.x, (short)xm, b.z, (short)ym); ns[nxt][pos] = st; nc[nxt][pos] = c0 | (bid << 31); nk[nxt][pos] = kc; pos++; nToExpandLocal += c0 > 1; }
+            if (c3) { nbB[nxt * cap + pos] = make_short4((short)xm, b.y, (short)ym, b.w); nsB[nxt * cap + pos] = st + c0 + c1 + c2; ncB[nxt * cap + pos] = c3 | (bid << 31); nkB[nxt * cap + pos] = kc + 3; pos++; nToExpandLocal += c3 > 1; }
+            if (c2) { nbB[nxt * cap + pos] = make_short4(b.x, (short)xm, (short)ym, b.w); nsB[nxt * cap + pos] = st + c0 + c1; ncB[nxt * cap + pos] = c2 | (bid << 31); nkB[nxt * cap + pos] = kc + 2; pos++; nToExpandLocal += c2 > 1; }
+            if (c1) { nbB[nxt * cap + pos] = make_short4((short)xm, b.y, b.z, (short)ym); nsB[nxt * cap + pos] = st + c0; ncB[nxt * cap + pos] = c1 | (bid << 31); nkB[nxt * cap + pos] = kc + 1; pos++; nToExpandLocal += c1 > 1; }
+            if (c0) { nbB[nxt * cap + pos] = make_short4(b.x, (short)xm, b.z, (short)ym); nsB[nxt * cap + pos] = st; ncB[nxt * cap + pos] = c0 | (bid << 31); nkB[nxt * cap + pos] = kc; pos++; nToExpandLocal += c0 > 1; }
         }
         // block-wide sum of nToExpand (main mode only needs it)
         {
@@ -937,9 +932,9 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         const int i = i0 + (lane >> 3), sub = lane & 7;
         uint64_t best = 0;
         if (i < m) {
-            const uint32_t cb = nc[cur][i];
+            const uint32_t cb = ncB[cur * cap + i];
             const uint32_t cnt = cb & 0x7FFFFFFFu;
-            const uint64_t* srcb = ((cb >> 31) ? bufs[1] : bufs[0]) + ns[cur][i];
+            const uint64_t* srcb = ((cb >> 31) ? bufs[1] : bufs[0]) + nsB[cur * cap + i];
             for (uint32_t p = sub; p < cnt; p += 32) {
                 uint64_t k[4];
 #pragma unroll
