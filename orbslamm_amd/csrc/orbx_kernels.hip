@@ -639,20 +639,43 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     for (int i = tid; i < hTotal; i += kDistThreads) hst[i] = 0;
     __syncthreads();
     const uint64_t* srcb = candRaw + (int64_t)f * g->candFrameRecs + L.candOff;  // raw FAST output stays untouched
-    auto path_code = [&](uint64_t key) {
-        const int x = (int)cand_x(key), y = (int)cand_y(key);
+    // The code separates: code = cx(x) + cy(y), cx = root * 4^D + the x decisions at bit 0 of every base-4 digit,
+    // cy = the y decisions at bit 1 (the y descent is the same under every root).  Two small LDS tables built per
+    // block (one descent per column and per row instead of one per key) turn a key's code into two byte-pair reads.
+    constexpr int kLutX = 2048, kLutY = 1280;
+    __shared__ uint16_t lutx[kLutX], luty[kLutY];
+    const bool useLut = L.winW <= kLutX && L.winH <= kLutY;
+    auto code_x = [&](int x) {
         int r = (int)__fdiv_rn((float)x, hX);
         if (r >= nIni) r = nIni - 1;
-        int x0 = (short)(int)__fmul_rn(hX, (float)r), x1 = (short)(int)__fmul_rn(hX, (float)(r + 1)), y0 = 0, y1 = (short)L.winH;
+        int x0 = (short)(int)__fmul_rn(hX, (float)r), x1 = (short)(int)__fmul_rn(hX, (float)(r + 1));
         int code = r;
         for (int d = 0; d < D; d++) {
-            const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);
-            const int qx = x >= xm, qy = y >= ym;
-            code = code * 4 + qx + 2 * qy;
+            const int xm = x0 + ((x1 - x0 + 1) >> 1);
+            const int qx = x >= xm;
+            code = code * 4 + qx;
             if (qx) x0 = xm; else x1 = xm;
+        }
+        return code;
+    };
+    auto code_y = [&](int y) {
+        int y0 = 0, y1 = (short)L.winH, code = 0;
+        for (int d = 0; d < D; d++) {
+            const int ym = y0 + ((y1 - y0 + 1) >> 1);
+            const int qy = y >= ym;
+            code = code * 4 + 2 * qy;
             if (qy) y0 = ym; else y1 = ym;
         }
         return code;
+    };
+    if (useLut) {
+        for (int i = tid; i < L.winW; i += kDistThreads) lutx[i] = (uint16_t)code_x(i);
+        for (int i = tid; i < L.winH; i += kDistThreads) luty[i] = (uint16_t)code_y(i);
+        __syncthreads();
+    }
+    auto path_code = [&](uint64_t key) {
+        const int x = (int)cand_x(key), y = (int)cand_y(key);
+        return useLut ? (int)lutx[min(x, kLutX - 1)] + (int)luty[min(y, kLutY - 1)] : code_x(x) + code_y(y);
     };
     // flat index -> (cell, slot) by binary search in the cell prefix.  A chunk is 16 keys per thread, all loads
     // in flight together; a level that fits one chunk (<= 8192 candidates, every shipped shape) keeps its keys
