@@ -681,12 +681,37 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // in flight together; a level that fits one chunk (<= 8192 candidates, every shipped shape) keeps its keys
     // in registers between the count and the scatter, larger ones read them twice.
     constexpr int KPT = 16;
+    // two-level search: firstCell[k] = cell of flat position 64k (one full search per 64 positions), then a key only
+    // searches the few cells its 64-block spans -- the search is LDS-issue bound (8 of the block's 70 us went here)
+    constexpr int kFirstCap = 1024;
+    __shared__ uint16_t firstCell[kFirstCap + 1];
+    __shared__ int sSpan;
+    const int nblk = (n + 63) >> 6;
+    const bool twoLevel = nblk <= kFirstCap && nCells <= 65535;
     int topStep = 1;
     while (topStep * 2 < nCells) topStep *= 2;
+    if (twoLevel) {
+        if (tid == 0) sSpan = 1;
+        __syncthreads();
+        for (int k = tid; k <= nblk; k += kDistThreads) {
+            const uint32_t p = (uint32_t)min(64 * k, max(n - 1, 0));
+            int lo = 0;
+            for (int step = topStep; step > 0; step >>= 1) {
+                const int c = lo + step;
+                if (c < nCells && cellPref[c] <= p) lo = c;
+            }
+            firstCell[k] = (uint16_t)lo;
+        }
+        __syncthreads();
+        for (int k = tid; k < nblk; k += kDistThreads) atomicMax(&sSpan, (int)firstCell[k + 1] - (int)firstCell[k]);
+        __syncthreads();
+        topStep = 1;
+        while (topStep * 2 <= sSpan) topStep *= 2;
+    }
     auto load_chunk = [&](int base, uint64_t (&key)[KPT], uint32_t (&code)[KPT]) {
         int lo[KPT], pp[KPT];
 #pragma unroll
-        for (int u = 0; u < KPT; u++) { pp[u] = min(base + tid + u * kDistThreads, n - 1); lo[u] = 0; }
+        for (int u = 0; u < KPT; u++) { pp[u] = min(base + tid + u * kDistThreads, n - 1); lo[u] = twoLevel ? (int)firstCell[pp[u] >> 6] : 0; }
         // largest c with cellPref[c] <= p: fixed-trip search, the 16 chains advance side by side
         for (int step = topStep; step > 0; step >>= 1) {
 #pragma unroll
