@@ -331,31 +331,31 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     const uint8_t* tb = (const uint8_t*)tile;
 
     const int cw = c.w, ch = c.h;
-    const int ndw = (cw + 4) >> 2;
-    // coalesced dword loads of the ROI rows starting one byte left of the ROI (unaligned global
-    // loads are fine on gfx950), 12 per lane in flight; clamped addresses so that out-of-range
-    // lanes re-store a valid dword and no store needs a predicate
+    const int ndq = (cw + 8) >> 3;  // 8-byte columns covering the cw + 1 bytes from x0 - 1 (<= TSB / 8)
+    // coalesced 8-byte loads of the ROI rows starting one byte left of the ROI (unaligned global loads are
+    // fine on gfx950), 6 per lane in flight; clamped addresses so that out-of-range lanes re-store a valid
+    // qword and no store needs a predicate
     {
-        struct __attribute__((packed)) U32 { uint32_t v; };
+        struct __attribute__((packed)) U64 { uint2 v; };
         const uint8_t* rowbase = base + (int64_t)c.y0 * stride + c.x0 - 1;
-        for (int d0 = 0; d0 < ndw; d0 += 16) {
-            const int ddc = min(d0 + (lane & 15), ndw - 1);
+        for (int d0 = 0; d0 < ndq; d0 += 8) {
+            const int qc = min(d0 + (lane & 7), ndq - 1);
             for (int rb = 0; rb < ch; rb += 48) {
-                uint32_t regs[12];
+                uint2 regs[6];
 #pragma unroll
-                for (int k = 0; k < 12; k++) {
-                    const int r = min(rb + (lane >> 4) + 4 * k, ch - 1);
-                    regs[k] = ((const U32*)(rowbase + (int64_t)r * stride + 4 * ddc))->v;
+                for (int k = 0; k < 6; k++) {
+                    const int r = min(rb + (lane >> 3) + 8 * k, ch - 1);
+                    regs[k] = ((const U64*)(rowbase + (int64_t)r * stride + 8 * qc))->v;
                 }
 #pragma unroll
-                for (int k = 0; k < 12; k++) {
-                    const int r = min(rb + (lane >> 4) + 4 * k, ch - 1);
-                    tile[r * TSD + ddc] = regs[k];
+                for (int k = 0; k < 6; k++) {
+                    const int r = min(rb + (lane >> 3) + 8 * k, ch - 1);
+                    *(uint2*)&tile[r * TSD + 2 * qc] = regs[k];
                 }
             }
         }
-        uint32_t* sm32 = (uint32_t*)smap;
-        for (int i = lane; i < ch * TSD; i += 64) sm32[i] = 0;
+        uint2* sm64 = (uint2*)smap;
+        for (int i = lane; i < ch * (TSD / 2); i += 64) sm64[i] = make_uint2(0u, 0u);
     }
     __syncthreads();
 
