@@ -411,27 +411,49 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     // stage 2: exact score on the dense lists; pixels with S > tq (corners at the lower
     // threshold) are compacted in place: writes land at or below entries already consumed
     int nC = 0;
-    for (int i0 = 0; i0 < nA; i0 += 64) {
-        const int i = i0 + lane;
-        const bool act = i < nA;
-        const int e = act ? list[i] : 0;
-        const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
-        const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
-        const bool corner = act && Sx > tq;
-        const uint64_t bal = ballot64(Sx > tq) & tail_mask(nA - i0);
-        if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
-        nC += __popcll(bal);
-    }
-    for (int i0 = 0; i0 < nB; i0 += 64) {  // ascending addresses, see above
-        const int i = i0 + lane;
-        const bool act = i < nB;
-        const int e = act ? list[listCap - nB + i] : 0;
-        const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
-        const int Sx = fast_S<TSB>(tb + pos);
-        const bool corner = act && Sx > tq;
-        const uint64_t bal = ballot64(Sx > tq) & tail_mask(nB - i0);
-        if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
-        nC += __popcll(bal);
+    if (nA + 2 * nB <= listCap) {
+        // one stream of one-sided entries: the A list, then the B list taken once as dark and once as bright (a pixel
+        // is a corner on one side at most, so the two visits never both write).  The in-place compaction cannot reach
+        // the B entries while they are still to be read: nC <= nA + nB <= listCap - nB.
+        const int nV = nA + 2 * nB;
+        for (int i0 = 0; i0 < nV; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < nV;
+            int e = 0;
+            if (act) {
+                if (i < nA) e = list[i];
+                else { const int j = i - nA; e = j < nB ? list[listCap - nB + j] : (list[listCap - nB + (j - nB)] | 0x4000); }
+            }
+            const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+            const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
+            const bool corner = act && Sx > tq;
+            const uint64_t bal = ballot64(Sx > tq) & tail_mask(nV - i0);
+            if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
+            nC += __popcll(bal);
+        }
+    } else {
+        for (int i0 = 0; i0 < nA; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < nA;
+            const int e = act ? list[i] : 0;
+            const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+            const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
+            const bool corner = act && Sx > tq;
+            const uint64_t bal = ballot64(Sx > tq) & tail_mask(nA - i0);
+            if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
+            nC += __popcll(bal);
+        }
+        for (int i0 = 0; i0 < nB; i0 += 64) {  // ascending addresses, see above
+            const int i = i0 + lane;
+            const bool act = i < nB;
+            const int e = act ? list[listCap - nB + i] : 0;
+            const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+            const int Sx = fast_S<TSB>(tb + pos);
+            const bool corner = act && Sx > tq;
+            const uint64_t bal = ballot64(Sx > tq) & tail_mask(nB - i0);
+            if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+            nC += __popcll(bal);
+        }
     }
     __syncthreads();
     if (nC == 0) { if (lane == 0) *myCount = 0; return; }
