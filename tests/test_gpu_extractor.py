@@ -207,6 +207,21 @@ def test_matrix_core_scan_equals_popcount_scan(gpu, monkeypatch):
     assert sum(n for _, n in out[0]) > 5000
 
 
+def test_saddle_texture_exercises_two_sided_fast_path(gpu, oracle):
+    """a periodic saddle texture: a quarter of all pixels pass FAST's compass pre-test on BOTH sides (brighter N/S,
+    darker E/W), more than the one-sided stream can take twice -- k_fast falls back to its two-sided scorer"""
+    w, h = 640, 480
+    y, x = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(12)
+    for period, amp in ((12, 50), (4, 50), (12, 25)):
+        img = 128 + amp * np.cos(2 * np.pi * y / period) - amp * np.cos(2 * np.pi * x / period) + rng.integers(-6, 7, size=(h, w))
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        gex = gpu_extractor(1000, w, h)
+        ref = oracle.Extractor(1000, 1.2, 8, 20, 7)(img)
+        assert len(ref["kps"]) > 500
+        assert_same(ref, *gex(img))
+
+
 def test_properties_full_size(gpu):
     """size-independent properties at BASELINE's full size with 64 frames in flight"""
     w, h, nf, B = 1241, 376, 2000, 64
