@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
 //            9-arc holds two adjacent compass pixels, i.e. one of {N,S} and one of {E,W},
 //            all brighter than v+tq or all darker than v-tq.  Survivors are compacted into
 //            a list tagged with their side; the few that pass on both sides go to a second
-//            list growing down from the top of the same buffer.
+//            list growing down from the top of the same buffer (stage 2 visits them once per side).
 //   stage 2  exact score on the dense lists.  A bright and a dark 9-arc cannot coexist (two
 //            9-arcs of a 16-ring overlap), so one-sided survivors only evaluate their own
 //            side: d_k = +-(v - p_k), S = max(0, max_k min(d_k..d_k+8)).  Pixels with S > tq
