@@ -314,6 +314,13 @@ int orbv_transform(orbv_t* v, const uint8_t* desc, int n, int levelsup,
                    uint32_t* word_id, double* word_value, int* n_words,
                    uint32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int* n_fv_nodes);
 
+/* Frame::ComputeBoW (src/Frame.cc:394-402) on a device-resident frame: BowVector to the host (word id ascending,
+ * value; capacity orbm_frame_size), FeatureVector kept with the frame.  Vocabulary and frame must share the device. */
+int orbm_frame_compute_bow(orbm_frame_t* f, orbv_t* voc, int levelsup, uint32_t* word_id, double* word_value, int* n_words);
+/* orbm_search_by_bow between two frames that ran orbm_frame_compute_bow (query = KeyFrame / pKF1, train = Frame / pKF2) */
+int orbm_search_by_bow_frames(orbm_t* h, orbm_frame_t* q, const uint8_t* qvalid, orbm_frame_t* t, const uint8_t* tvalid,
+                              float nnratio, int check_ori, int out_by_train, int32_t* match, int* nmatches);
+
 #ifdef __cplusplus
 }
 #endif

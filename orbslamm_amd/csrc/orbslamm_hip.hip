@@ -1274,6 +1274,66 @@ extern "C" int orbm_match_bruteforce(orbm_t* h, const uint8_t* qdesc, const floa
 }
 
 // ------------------------------------------------------------------ SearchByBoW
+// one side of a BoW search, resident in HBM (node ids stay on the host: the lock-step walk happens there)
+struct BowSide {
+    const uint8_t* d_desc; const float* d_ang; const int32_t *d_start, *d_idx;
+    const uint32_t* node_id; int n_nodes; int n;
+};
+
+static int bow_core(orbm_handle* h, const BowSide& q, const uint8_t* qvalid, const BowSide& t, const uint8_t* tvalid,
+                    float nnratio, int check_ori, int out_by_train, int32_t* match, int* nmatches)
+{
+    int rc;
+    const int nq = q.n, nt = t.n;
+    const int nout = out_by_train ? nt : nq;
+    // lock-step walk of the two sorted node-id lists (ORBmatcher.cc:180-266): host side,
+    // it only decides WHICH node pairs are searched
+    std::vector<int32_t> pq, pt;
+    {
+        int a = 0, b = 0;
+        while (a < q.n_nodes && b < t.n_nodes) {
+            if (q.node_id[a] == t.node_id[b]) { pq.push_back(a); pt.push_back(b); a++; b++; }
+            else if (q.node_id[a] < t.node_id[b]) a++;
+            else b++;
+        }
+    }
+    const int npairs = (int)pq.size();
+    if (npairs == 0) return ORBX_OK;
+    enum { S_QV = 4, S_TV, S_PQ = 10, S_PT, S_MATCHED, S_MATCH, S_BIN, S_HIST };
+    if ((rc = orbm_reserve(h, S_QV, (size_t)nq)) || (rc = orbm_reserve(h, S_TV, (size_t)nt)) || (rc = orbm_reserve(h, S_PQ, (size_t)npairs * 4)) ||
+        (rc = orbm_reserve(h, S_PT, (size_t)npairs * 4)) || (rc = orbm_reserve(h, S_MATCHED, (size_t)nt)) ||
+        (rc = orbm_reserve(h, S_MATCH, (size_t)nout * 4)) || (rc = orbm_reserve(h, S_BIN, (size_t)nout)) || (rc = orbm_reserve(h, S_HIST, 34 * 4))) return rc;
+    hipStream_t s = h->stream;
+#define UP(slot, src, bytes) HIPCHK(hipMemcpyAsync(h->d_buf[slot], src, bytes, hipMemcpyHostToDevice, s))
+    if (qvalid) UP(S_QV, qvalid, (size_t)nq);
+    if (tvalid) UP(S_TV, tvalid, (size_t)nt);
+    UP(S_PQ, pq.data(), (size_t)npairs * 4); UP(S_PT, pt.data(), (size_t)npairs * 4);
+    HIPCHK(hipMemsetAsync(h->d_buf[S_MATCHED], 0, (size_t)nt, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[S_MATCH], 0xFF, (size_t)nout * 4, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[S_HIST], 0, 34 * 4, s));
+    orbm::BowArgs a;
+    a.qdesc = q.d_desc; a.qang = q.d_ang;
+    a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
+    a.tdesc = t.d_desc; a.tang = t.d_ang;
+    a.tvalid = tvalid ? (const uint8_t*)h->d_buf[S_TV] : nullptr;
+    a.qstart = q.d_start; a.qidx = q.d_idx;
+    a.tstart = t.d_start; a.tidx = t.d_idx;
+    a.pairQ = (const int32_t*)h->d_buf[S_PQ]; a.pairT = (const int32_t*)h->d_buf[S_PT];
+    a.matched = (uint8_t*)h->d_buf[S_MATCHED];
+    a.match = (int32_t*)h->d_buf[S_MATCH]; a.binOf = (uint8_t*)h->d_buf[S_BIN]; a.hist = (int32_t*)h->d_buf[S_HIST];
+    a.nnratio = nnratio; a.thLow = 50; a.checkOri = check_ori; a.outByTrain = out_by_train;
+    hipLaunchKernelGGL(orbm::k_bow_pairs, dim3(npairs), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(orbm::k_prune_flat, dim3(1), dim3(256), 0, s, a.match, nout, check_ori, (const uint8_t*)a.binOf,
+                       a.hist, a.hist + 32);
+    HIPCHK(hipGetLastError());
+    int32_t nm = 0;
+    HIPCHK(hipMemcpyAsync(match, a.match, (size_t)nout * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nm, a.hist + 32, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBX_OK;
+}
+
 extern "C" int orbm_search_by_bow(orbm_t* h,
                                   const uint8_t* qdesc, const float* qangle, const uint8_t* qvalid, int nq,
                                   const OrbmFeatVec* qfv,
@@ -1290,63 +1350,26 @@ extern "C" int orbm_search_by_bow(orbm_t* h,
     for (int i = 0; i < nout; i++) match[i] = -1;
     if (nmatches) *nmatches = 0;
     if (nq == 0 || nt == 0) return ORBX_OK;
-    // lock-step walk of the two sorted node-id lists (ORBmatcher.cc:180-266): host side,
-    // it only decides WHICH node pairs are searched
-    std::vector<int32_t> pq, pt;
-    {
-        int a = 0, b = 0;
-        while (a < qfv->n_nodes && b < tfv->n_nodes) {
-            if (qfv->node_id[a] == tfv->node_id[b]) { pq.push_back(a); pt.push_back(b); a++; b++; }
-            else if (qfv->node_id[a] < tfv->node_id[b]) a++;
-            else b++;
-        }
-    }
-    const int npairs = (int)pq.size();
-    if (npairs == 0) return ORBX_OK;
     const int nqi = qfv->start[qfv->n_nodes], nti = tfv->start[tfv->n_nodes];
     for (int i = 0; i < nqi; i++) if (qfv->idx[i] < 0 || qfv->idx[i] >= nq) return fail(ORBX_E_INVALID, "query feature index out of range");
     for (int i = 0; i < nti; i++) if (tfv->idx[i] < 0 || tfv->idx[i] >= nt) return fail(ORBX_E_INVALID, "train feature index out of range");
-    enum { S_QD, S_TD, S_QA, S_TA, S_QV, S_TV, S_QS, S_QI, S_TS, S_TI, S_PQ, S_PT, S_MATCHED, S_MATCH, S_BIN, S_HIST };
-    const size_t sizes[] = {(size_t)nq * 32, (size_t)nt * 32, (size_t)nq * 4, (size_t)nt * 4, (size_t)nq, (size_t)nt,
-                            (size_t)(qfv->n_nodes + 1) * 4, (size_t)std::max(nqi, 1) * 4, (size_t)(tfv->n_nodes + 1) * 4,
-                            (size_t)std::max(nti, 1) * 4, (size_t)npairs * 4, (size_t)npairs * 4, (size_t)nt,
-                            (size_t)nout * 4, (size_t)nout, 34 * 4};
-    for (int i = 0; i < 16; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    enum { S_QD, S_TD, S_QA, S_TA, S_QS = 6, S_QI, S_TS, S_TI };
+    if ((rc = orbm_reserve(h, S_QD, (size_t)nq * 32)) || (rc = orbm_reserve(h, S_TD, (size_t)nt * 32)) || (rc = orbm_reserve(h, S_QA, (size_t)nq * 4)) ||
+        (rc = orbm_reserve(h, S_TA, (size_t)nt * 4)) || (rc = orbm_reserve(h, S_QS, (size_t)(qfv->n_nodes + 1) * 4)) ||
+        (rc = orbm_reserve(h, S_QI, (size_t)std::max(nqi, 1) * 4)) || (rc = orbm_reserve(h, S_TS, (size_t)(tfv->n_nodes + 1) * 4)) ||
+        (rc = orbm_reserve(h, S_TI, (size_t)std::max(nti, 1) * 4))) return rc;
     hipStream_t s = h->stream;
-#define UP(slot, src, bytes) HIPCHK(hipMemcpyAsync(h->d_buf[slot], src, bytes, hipMemcpyHostToDevice, s))
     UP(S_QD, qdesc, (size_t)nq * 32); UP(S_TD, tdesc, (size_t)nt * 32);
     UP(S_QA, qangle, (size_t)nq * 4); UP(S_TA, tangle, (size_t)nt * 4);
-    if (qvalid) UP(S_QV, qvalid, (size_t)nq);
-    if (tvalid) UP(S_TV, tvalid, (size_t)nt);
     UP(S_QS, qfv->start, (size_t)(qfv->n_nodes + 1) * 4);
     if (nqi) UP(S_QI, qfv->idx, (size_t)nqi * 4);
     UP(S_TS, tfv->start, (size_t)(tfv->n_nodes + 1) * 4);
     if (nti) UP(S_TI, tfv->idx, (size_t)nti * 4);
-    UP(S_PQ, pq.data(), (size_t)npairs * 4); UP(S_PT, pt.data(), (size_t)npairs * 4);
-    HIPCHK(hipMemsetAsync(h->d_buf[S_MATCHED], 0, (size_t)nt, s));
-    HIPCHK(hipMemsetAsync(h->d_buf[S_MATCH], 0xFF, (size_t)nout * 4, s));
-    HIPCHK(hipMemsetAsync(h->d_buf[S_HIST], 0, 34 * 4, s));
-    orbm::BowArgs a;
-    a.qdesc = (const uint8_t*)h->d_buf[S_QD]; a.qang = (const float*)h->d_buf[S_QA];
-    a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
-    a.tdesc = (const uint8_t*)h->d_buf[S_TD]; a.tang = (const float*)h->d_buf[S_TA];
-    a.tvalid = tvalid ? (const uint8_t*)h->d_buf[S_TV] : nullptr;
-    a.qstart = (const int32_t*)h->d_buf[S_QS]; a.qidx = (const int32_t*)h->d_buf[S_QI];
-    a.tstart = (const int32_t*)h->d_buf[S_TS]; a.tidx = (const int32_t*)h->d_buf[S_TI];
-    a.pairQ = (const int32_t*)h->d_buf[S_PQ]; a.pairT = (const int32_t*)h->d_buf[S_PT];
-    a.matched = (uint8_t*)h->d_buf[S_MATCHED];
-    a.match = (int32_t*)h->d_buf[S_MATCH]; a.binOf = (uint8_t*)h->d_buf[S_BIN]; a.hist = (int32_t*)h->d_buf[S_HIST];
-    a.nnratio = nnratio; a.thLow = 50; a.checkOri = check_ori; a.outByTrain = out_by_train;
-    hipLaunchKernelGGL(orbm::k_bow_pairs, dim3(npairs), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(orbm::k_prune_flat, dim3(1), dim3(256), 0, s, a.match, nout, check_ori, (const uint8_t*)a.binOf,
-                       a.hist, a.hist + 32);
-    HIPCHK(hipGetLastError());
-    int32_t nm = 0;
-    HIPCHK(hipMemcpyAsync(match, a.match, (size_t)nout * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&nm, a.hist + 32, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (nmatches) *nmatches = nm;
-    return ORBX_OK;
+    const BowSide q = {(const uint8_t*)h->d_buf[S_QD], (const float*)h->d_buf[S_QA], (const int32_t*)h->d_buf[S_QS], (const int32_t*)h->d_buf[S_QI],
+                       qfv->node_id, qfv->n_nodes, nq};
+    const BowSide t = {(const uint8_t*)h->d_buf[S_TD], (const float*)h->d_buf[S_TA], (const int32_t*)h->d_buf[S_TS], (const int32_t*)h->d_buf[S_TI],
+                       tfv->node_id, tfv->n_nodes, nt};
+    return bow_core(h, q, qvalid, t, tvalid, nnratio, check_ori, out_by_train, match, nmatches);
 }
 
 // ------------------------------------------------------------------ grid + SearchByProjection
@@ -1518,6 +1541,11 @@ struct orbm_frame {
     orbm::KeyDev* d_keysUn = nullptr;
     uint8_t* d_desc = nullptr;
     int32_t *d_cnt = nullptr, *d_start = nullptr, *d_fill = nullptr, *d_idx = nullptr;
+    float* d_ang = nullptr;                  // mvKeysUn[i].angle, contiguous (the BoW search reads angles by feature index)
+    bool hasBow = false;                     // orbm_frame_compute_bow ran: FeatureVector as CSR, node ids on the host
+    std::vector<uint32_t> fvNode;
+    int fvNodes = 0;
+    int32_t *d_fvStart = nullptr, *d_fvIdx = nullptr;
 };
 
 extern "C" int orbm_frame_destroy(orbm_frame_t* f)
@@ -1526,7 +1554,7 @@ extern "C" int orbm_frame_destroy(orbm_frame_t* f)
     if (f->owner && f->owner->device >= 0) {
         (void)hipSetDevice(f->owner->device);
         (void)hipStreamSynchronize(f->owner->stream);
-        void* ptrs[] = {f->d_keysUn, f->d_desc, f->d_cnt, f->d_start, f->d_fill, f->d_idx};
+        void* ptrs[] = {f->d_keysUn, f->d_desc, f->d_cnt, f->d_start, f->d_fill, f->d_idx, f->d_ang, f->d_fvStart, f->d_fvIdx};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
     delete f;
@@ -1551,6 +1579,7 @@ extern "C" int orbm_frame_create(orbm_t* h, const OrbxKeyPoint* d_keys, const ui
     FCR(hipMalloc(&f->d_start, (size_t)(ncell + 1) * 4));
     FCR(hipMalloc(&f->d_fill, (size_t)ncell * 4));
     FCR(hipMalloc(&f->d_idx, (size_t)nn * 4));
+    FCR(hipMalloc(&f->d_ang, (size_t)nn * 4));
     hipStream_t s = h->stream;
     if (n) {
         FCR(hipMemcpyAsync(f->d_desc, d_desc, (size_t)n * 32, hipMemcpyDeviceToDevice, s));
@@ -1561,6 +1590,7 @@ extern "C" int orbm_frame_create(orbm_t* h, const OrbxKeyPoint* d_keys, const ui
             hipLaunchKernelGGL(orbm::k_undistort, dim3((n + 255) / 256), dim3(256), 0, s, (const orbm::KeyDev*)d_keys, n, a, f->d_keysUn);
         }
     }
+    if (n) FCR(hipMemcpy2DAsync(f->d_ang, 4, (const uint8_t*)d_keys + 12, sizeof(OrbxKeyPoint), 4, (size_t)n, hipMemcpyDeviceToDevice, s));
 #undef FCR
     if ((rc = grid_build_device(grid, f->d_keysUn, n, f->d_cnt, f->d_start, f->d_fill, f->d_idx, s, f->gd))) { orbm_frame_destroy(f); return rc; }
     if (hipStreamSynchronize(s) != hipSuccess) { orbm_frame_destroy(f); return fail(ORBX_E_HIP, "frame construction failed"); }
@@ -1942,6 +1972,35 @@ extern "C" int orbv_load_text(int device, const char* path, orbv_t** out)
     return orbv_create(device, k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), out);
 }
 
+// transform of n device-resident descriptors; results stay in the handle's scratch (slots below), counts = {words, fv nodes}
+enum { SV_DESC, SV_WORD, SV_NODE, SV_W, SV_OW, SV_OV, SV_FN, SV_FS, SV_FI, SV_CNT };
+static int voc_transform_device(orbv_handle* h, const uint8_t* d_desc, int n, int levelsup, int32_t counts[2])
+{
+    counts[0] = counts[1] = 0;
+    if (n > 8192) return fail(ORBX_E_UNSUPPORTED, "more than 8192 descriptors per transform");
+    int P = 1;
+    while (P < n) P <<= 1;
+    const size_t sizes[] = {(size_t)n * 32, (size_t)n * 4, (size_t)n * 4, (size_t)n * 8, (size_t)n * 4, (size_t)n * 8,
+                            (size_t)n * 4, (size_t)(n + 1) * 4, (size_t)n * 4, 16};
+    int rc;
+    for (int i = 0; i < 10; i++) if ((rc = orbv_reserve(h, i, sizes[i]))) return rc;
+    hipStream_t s = h->stream;
+    if (!d_desc) d_desc = (const uint8_t*)h->d_buf[SV_DESC];
+    orbv::VocDev v{h->d_childStart, h->d_childIdx, h->d_desc, h->d_wordId, h->d_weight, h->L, h->scoring, h->weighting};
+    hipLaunchKernelGGL(orbv::k_voc_descend, dim3((n + 63) / 64), dim3(64), 0, s, v, d_desc, n, levelsup,
+                       (uint32_t*)h->d_buf[SV_WORD], (uint32_t*)h->d_buf[SV_NODE], (double*)h->d_buf[SV_W]);
+    const size_t lds = (size_t)P * 12;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)orbv::k_voc_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(orbv::k_voc_aggregate, dim3(1), dim3(orbv::kAggThreads), lds, s, v, n, P, (const uint32_t*)h->d_buf[SV_WORD],
+                       (const uint32_t*)h->d_buf[SV_NODE], (const double*)h->d_buf[SV_W], (uint32_t*)h->d_buf[SV_OW],
+                       (double*)h->d_buf[SV_OV], (uint32_t*)h->d_buf[SV_FN], (int32_t*)h->d_buf[SV_FS], (int32_t*)h->d_buf[SV_FI],
+                       (int32_t*)h->d_buf[SV_CNT]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(counts, h->d_buf[SV_CNT], 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
 extern "C" int orbv_transform(orbv_t* h, const uint8_t* desc, int n, int levelsup,
                               uint32_t* word_id, double* word_value, int* n_words,
                               uint32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int* n_fv_nodes)
@@ -1953,38 +2012,74 @@ extern "C" int orbv_transform(orbv_t* h, const uint8_t* desc, int n, int levelsu
     *n_words = 0; *n_fv_nodes = 0; fv_start[0] = 0;
     if (h->nWords == 0 || n == 0) return ORBX_OK;  // empty(): v and fv stay cleared (:1133-1136)
     if (n > 8192) return fail(ORBX_E_UNSUPPORTED, "more than 8192 descriptors per transform");
-    int P = 1;
-    while (P < n) P <<= 1;
-    enum { S_DESC, S_WORD, S_NODE, S_W, S_OW, S_OV, S_FN, S_FS, S_FI, S_CNT };
-    const size_t sizes[] = {(size_t)n * 32, (size_t)n * 4, (size_t)n * 4, (size_t)n * 8, (size_t)n * 4, (size_t)n * 8,
-                            (size_t)n * 4, (size_t)(n + 1) * 4, (size_t)n * 4, 16};
     int rc;
-    for (int i = 0; i < 10; i++) if ((rc = orbv_reserve(h, i, sizes[i]))) return rc;
-    hipStream_t s = h->stream;
-    HIPCHK(hipMemcpyAsync(h->d_buf[S_DESC], desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    orbv::VocDev v{h->d_childStart, h->d_childIdx, h->d_desc, h->d_wordId, h->d_weight, h->L, h->scoring, h->weighting};
-    hipLaunchKernelGGL(orbv::k_voc_descend, dim3((n + 63) / 64), dim3(64), 0, s, v, (const uint8_t*)h->d_buf[S_DESC], n, levelsup,
-                       (uint32_t*)h->d_buf[S_WORD], (uint32_t*)h->d_buf[S_NODE], (double*)h->d_buf[S_W]);
-    const size_t lds = (size_t)P * 12;
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)orbv::k_voc_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(orbv::k_voc_aggregate, dim3(1), dim3(orbv::kAggThreads), lds, s, v, n, P, (const uint32_t*)h->d_buf[S_WORD],
-                       (const uint32_t*)h->d_buf[S_NODE], (const double*)h->d_buf[S_W], (uint32_t*)h->d_buf[S_OW],
-                       (double*)h->d_buf[S_OV], (uint32_t*)h->d_buf[S_FN], (int32_t*)h->d_buf[S_FS], (int32_t*)h->d_buf[S_FI],
-                       (int32_t*)h->d_buf[S_CNT]);
-    HIPCHK(hipGetLastError());
-    int32_t counts[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(counts, h->d_buf[S_CNT], 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = orbv_reserve(h, SV_DESC, (size_t)n * 32))) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_buf[SV_DESC], desc, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
+    int32_t counts[2];
+    if ((rc = voc_transform_device(h, nullptr, n, levelsup, counts))) return rc;
     *n_words = counts[0]; *n_fv_nodes = counts[1];
     if (counts[0]) {
-        HIPCHK(hipMemcpy(word_id, h->d_buf[S_OW], (size_t)counts[0] * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(word_value, h->d_buf[S_OV], (size_t)counts[0] * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(word_id, h->d_buf[SV_OW], (size_t)counts[0] * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(word_value, h->d_buf[SV_OV], (size_t)counts[0] * 8, hipMemcpyDeviceToHost));
     }
-    HIPCHK(hipMemcpy(fv_start, h->d_buf[S_FS], (size_t)(counts[1] + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fv_start, h->d_buf[SV_FS], (size_t)(counts[1] + 1) * 4, hipMemcpyDeviceToHost));
     if (counts[1]) {
-        HIPCHK(hipMemcpy(fv_node, h->d_buf[S_FN], (size_t)counts[1] * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(fv_node, h->d_buf[SV_FN], (size_t)counts[1] * 4, hipMemcpyDeviceToHost));
         const int m = fv_start[counts[1]];
-        if (m) HIPCHK(hipMemcpy(fv_idx, h->d_buf[S_FI], (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (m) HIPCHK(hipMemcpy(fv_idx, h->d_buf[SV_FI], (size_t)m * 4, hipMemcpyDeviceToHost));
     }
     return ORBX_OK;
+}
+
+// ------------------------------------------------------------------ SURVEY 8(f).2+3: BoW on a device-resident Frame
+// Frame::ComputeBoW (src/Frame.cc:394-402) on the frame's descriptors in HBM: the BowVector goes to the host (the
+// KeyFrame database and the relocaliser read it), the FeatureVector stays with the frame for SearchByBoW.
+extern "C" int orbm_frame_compute_bow(orbm_frame_t* f, orbv_t* voc, int levelsup,
+                                      uint32_t* word_id, double* word_value, int* n_words)
+{
+    if (!f || !f->owner || !voc) return fail(ORBX_E_INVALID, "null argument");
+    int rc = orbm_check(f->owner);
+    if (rc) return rc;
+    if (voc->device != f->owner->device) return fail(ORBX_E_INVALID, "vocabulary and frame live on different devices");
+    if (!n_words || (f->n && (!word_id || !word_value))) return fail(ORBX_E_INVALID, "bad argument");
+    *n_words = 0;
+    f->fvNode.clear(); f->fvNodes = 0; f->hasBow = true;
+    if (voc->nWords == 0 || f->n == 0) return ORBX_OK;
+    int32_t counts[2];
+    if ((rc = voc_transform_device(voc, f->d_desc, f->n, levelsup, counts))) return rc;
+    *n_words = counts[0];
+    if (counts[0]) {
+        HIPCHK(hipMemcpy(word_id, voc->d_buf[SV_OW], (size_t)counts[0] * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(word_value, voc->d_buf[SV_OV], (size_t)counts[0] * 8, hipMemcpyDeviceToHost));
+    }
+    f->fvNodes = counts[1];
+    f->fvNode.resize((size_t)counts[1]);
+    if (!f->d_fvStart) {
+        HIPCHK(hipMalloc(&f->d_fvStart, (size_t)(f->n + 1) * 4));
+        HIPCHK(hipMalloc(&f->d_fvIdx, (size_t)f->n * 4));
+    }
+    HIPCHK(hipMemcpy(f->d_fvStart, voc->d_buf[SV_FS], (size_t)(counts[1] + 1) * 4, hipMemcpyDeviceToDevice));
+    if (counts[1]) {
+        HIPCHK(hipMemcpy(f->fvNode.data(), voc->d_buf[SV_FN], (size_t)counts[1] * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(f->d_fvIdx, voc->d_buf[SV_FI], (size_t)f->n * 4, hipMemcpyDeviceToDevice));
+    }
+    return ORBX_OK;
+}
+
+/* SearchByBoW between two device-resident frames (query = the KeyFrame / pKF1, train = the Frame / pKF2) */
+extern "C" int orbm_search_by_bow_frames(orbm_t* h, orbm_frame_t* q, const uint8_t* qvalid, orbm_frame_t* t, const uint8_t* tvalid,
+                                         float nnratio, int check_ori, int out_by_train, int32_t* match, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (!q || !t || q->owner != h || t->owner != h) return fail(ORBX_E_INVALID, "frames do not belong to this matcher handle");
+    if (!q->hasBow || !t->hasBow) return fail(ORBX_E_INVALID, "orbm_frame_compute_bow has not run on both frames");
+    if (!match) return fail(ORBX_E_INVALID, "bad argument");
+    const int nout = out_by_train ? t->n : q->n;
+    for (int i = 0; i < nout; i++) match[i] = -1;
+    if (nmatches) *nmatches = 0;
+    if (q->n == 0 || t->n == 0 || q->fvNodes == 0 || t->fvNodes == 0) return ORBX_OK;
+    const BowSide qs = {q->d_desc, q->d_ang, q->d_fvStart, q->d_fvIdx, q->fvNode.data(), q->fvNodes, q->n};
+    const BowSide ts = {t->d_desc, t->d_ang, t->d_fvStart, t->d_fvIdx, t->fvNode.data(), t->fvNodes, t->n};
+    return bow_core(h, qs, qvalid, ts, tvalid, nnratio, check_ori, out_by_train, match, nmatches);
 }

@@ -133,6 +133,26 @@ class ORBmatcher:
     def frame_destroy(self, frame):
         check(self._L.orbm_frame_destroy(frame))
 
+    def frame_compute_bow(self, frame, voc, levelsup=4):
+        """Frame::ComputeBoW on a device-resident frame: returns the BowVector (word ids, values); the
+        FeatureVector stays with the frame (SearchByBoWFrames)."""
+        n = self._L.orbm_frame_size(frame)
+        wid = np.zeros(max(n, 1), dtype=np.uint32)
+        wval = np.zeros(max(n, 1), dtype=np.float64)
+        nw = C.c_int(0)
+        check(self._L.orbm_frame_compute_bow(frame, voc._h, int(levelsup), ptr(wid), ptr(wval), C.byref(nw)))
+        return wid[:nw.value].copy(), wval[:nw.value].copy()
+
+    def SearchByBoWFrames(self, qframe, qvalid, tframe, tvalid, out_by_train=True):
+        nout = self._L.orbm_frame_size(tframe if out_by_train else qframe)
+        match = np.full(max(nout, 1), -1, dtype=np.int32)
+        qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+        tv = None if tvalid is None else np.ascontiguousarray(tvalid, dtype=np.uint8)
+        n = C.c_int(0)
+        check(self._L.orbm_search_by_bow_frames(self._h, qframe, ptr(qv), tframe, ptr(tv), C.c_float(self.mfNNratio),
+                                                int(self.mbCheckOrientation), int(bool(out_by_train)), ptr(match), C.byref(n)))
+        return match[:nout], n.value
+
     def SearchByProjectionFrame(self, mode, th_dist, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, frame, t_occ, assign):
         """SearchByProjection with a device-resident frame as train side."""
         pp = OrbmProjParams(int(mode), self.mfNNratio, int(self.mbCheckOrientation), int(th_dist))

@@ -54,3 +54,42 @@ def test_bad_vocabulary_is_rejected(gpu):
         ORBVocabulary(10, 3, 0, 0, np.array([5], np.int32), np.array([1], np.uint8), np.zeros((1, 32), np.uint8), np.ones(1), device=0)
     with pytest.raises(OrbError):
         ORBVocabulary(99, 3, 0, 0, np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 32), np.uint8), np.zeros(0), device=0)
+
+
+def test_tracking_front_end_stays_in_hbm(gpu, oracle):
+    """SURVEY 8(f).2+3 together: frames extracted on the GPU never leave it -- the matcher builds their Frame state
+    from the device pointers, Frame::ComputeBoW runs on the device-resident descriptors, and SearchByBoW (the
+    TrackReferenceKeyFrame search) runs between the two device frames.  BowVector, and matches against the oracle
+    fed with the downloaded arrays."""
+    from orbslamm_amd import ORBextractor, ORBmatcher, ORBVocabulary, make_grid, synth
+    w, h, nf = 640, 480, 1000
+    rng = np.random.default_rng(91)
+    voc = make_vocab(rng, 10, 4)
+    G = ORBVocabulary(10, 4, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], device=0)
+    O = oracle.Vocabulary(10, 4, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    fr = synth.make_frames(w, h, 2, stream=4)
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2, device=0)
+    gex.extract_batch_device(*gex.upload_frames(fr))
+    gex.sync()
+    dk, dd, _, cap = gex.device_results()
+    host = [gex.download(f) for f in range(2)]
+    g = make_grid(0.0, 0.0, float(w), float(h))
+    K, D0 = [517.3, 516.5, 318.6, 255.3], [0, 0, 0, 0, 0]
+    for ratio, ori, by_train in ((0.7, True, True), (0.75, True, False), (0.9, False, True)):
+        m = ORBmatcher(ratio, ori, device=0)
+        frames, fvs = [], []
+        for f in range(2):
+            keys, desc = host[f]
+            F = m.frame_from_device(dk + f * cap * 28, dd + f * cap * 32, len(keys), K, D0, g)
+            wid, wval = m.frame_compute_bow(F, G, 4)
+            (owid, owval), ofv = O.transform(desc, 4)
+            assert np.array_equal(wid, owid) and wval.tobytes() == owval.tobytes()
+            frames.append(F); fvs.append(ofv)
+        (k0, d0), (k1, d1) = host
+        qv = (rng.uniform(size=len(k0)) < 0.9).astype(np.uint8)
+        tv = None if by_train else (rng.uniform(size=len(k1)) < 0.9).astype(np.uint8)
+        got, n = m.SearchByBoWFrames(frames[0], qv, frames[1], tv, by_train)
+        want, nw = oracle.search_by_bow(d0, k0["angle"], qv, fvs[0], d1, k1["angle"], tv, fvs[1], ratio, ori, by_train)
+        assert n == nw and np.array_equal(got, want) and nw > 50
+        for F in frames:
+            m.frame_destroy(F)
