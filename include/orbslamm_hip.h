@@ -321,6 +321,11 @@ int orbm_frame_compute_bow(orbm_frame_t* f, orbv_t* voc, int levelsup, uint32_t*
 int orbm_search_by_bow_frames(orbm_t* h, orbm_frame_t* q, const uint8_t* qvalid, orbm_frame_t* t, const uint8_t* tvalid,
                               float nnratio, int check_ori, int out_by_train, int32_t* match, int* nmatches);
 
+/* orbm_search_for_initialization between two device-resident frames (F1 = the initial frame, F2 = the current one);
+ * q_xy = vbPrevMatched (host, F1 size), matches12: F1 size */
+int orbm_search_for_initialization_frames(orbm_t* h, const float* q_xy, float window_size, orbm_frame_t* f1, orbm_frame_t* f2,
+                                          float nnratio, int check_ori, int32_t* matches12, int* nmatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -973,6 +973,13 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ 
 // Frame::UndistortKeyPoints (src/Frame.cc:404-434) = cv::undistortPoints(..., mK, mDistCoef, Mat(), mK):
 // 5 fixed-point iterations of the radial-tangential model in double, one thread per keypoint.
 // Every operation is a separately rounded IEEE binary64 op (no contraction), like the host code.
+// queries of SearchForInitialization: only level-0 keypoints search (ORBmatcher.cc:424-426)
+__global__ void k_octave0_flags(const KeyDev* __restrict__ keys, int n, uint8_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = keys[i].octave <= 0;
+}
+
 struct UndistArgs { double fx, fy, cx, cy, k1, k2, p1, p2, k3; };
 __global__ void k_undistort(const KeyDev* __restrict__ in, int n, UndistArgs a, KeyDev* __restrict__ out)
 {

@@ -1671,45 +1671,32 @@ extern "C" int orbm_window_best(orbm_t* h, const float* q_uvr, const float* q_ur
     return ORBX_OK;
 }
 
-extern "C" int orbm_search_for_initialization(orbm_t* h, const float* q_xy, float window_size,
-                                              const OrbxKeyPoint* q_keys_un, const uint8_t* qdesc, int nq,
-                                              const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc, int nt,
-                                              float nnratio, int check_ori, int32_t* matches12, int* nmatches)
+// query side (F1) of SearchForInitialization resident in HBM: descriptors, angles, "octave 0" flags
+static int init_core(orbm_handle* h, const float* q_xy, float window_size, const uint8_t* d_qdesc, const float* d_qang,
+                     const uint8_t* d_qvalid, int nq, const ProjTrain& tr, float nnratio, int check_ori, int32_t* matches12, int* nmatches)
 {
-    int rc = orbm_check(h);
-    if (rc) return rc;
-    if (nq < 0 || nt < 0 || (nq && (!q_xy || !q_keys_un || !qdesc || !matches12)) || (nt && (!t_keys_un || !tdesc)))
-        return fail(ORBX_E_INVALID, "bad argument");
-    for (int i = 0; i < nq; i++) matches12[i] = -1;
-    if (nmatches) *nmatches = 0;
-    if (nq == 0 || nt == 0) return ORBX_OK;
+    int rc;
+    const int nt = tr.nt;
     if ((size_t)nt * 2 > 150 * 1024) return fail(ORBX_E_UNSUPPORTED, "too many train features for the LDS distance table");
-    orbm::GridDev gd;
-    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, gd))) return rc;
-    // flatten: window query (x, y, windowSize), levels (0, 0), only octave-0 queries search (:424-426)
-    std::vector<float> uvr((size_t)nq * 3), ang(nq);
+    // flatten: window query (x, y, windowSize), levels (0, 0); only octave-0 queries search (:424-426)
+    std::vector<float> uvr((size_t)nq * 3);
     std::vector<int8_t> lvl((size_t)nq * 2, 0);
-    std::vector<uint8_t> valid(nq);
-    for (int i = 0; i < nq; i++) {
-        uvr[3 * i] = q_xy[2 * i]; uvr[3 * i + 1] = q_xy[2 * i + 1]; uvr[3 * i + 2] = window_size;
-        valid[i] = q_keys_un[i].octave <= 0;
-        ang[i] = q_keys_un[i].angle;
-    }
-    enum { S_UVR, S_LVL, S_QD, S_QA, S_QV, S_TD, S_CNT, S_OFF, S_KEY, S_CIDX, S_M12, S_M21, S_NM, S_PUSHT, S_PUSHB };
-    const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 2, (size_t)nq * 32, (size_t)nq * 4, (size_t)nq, (size_t)nt * 32,
-                            (size_t)nq * 4, (size_t)(nq + 1) * 4, 16, 16, (size_t)nq * 4, (size_t)nt * 4, 16, (size_t)nq * 4, (size_t)nq};
-    for (int i = 0; i < 15; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    for (int i = 0; i < nq; i++) { uvr[3 * i] = q_xy[2 * i]; uvr[3 * i + 1] = q_xy[2 * i + 1]; uvr[3 * i + 2] = window_size; }
+    enum { S_UVR, S_LVL, S_CNT = 6, S_OFF, S_KEY, S_CIDX, S_M12, S_M21, S_NM, S_PUSHT, S_PUSHB };
+    const int slots[] = {S_UVR, S_LVL, S_CNT, S_OFF, S_KEY, S_CIDX, S_M12, S_M21, S_NM, S_PUSHT, S_PUSHB};
+    const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 2, (size_t)nq * 4, (size_t)(nq + 1) * 4, 16, 16, (size_t)nq * 4, (size_t)nt * 4, 16,
+                            (size_t)nq * 4, (size_t)nq};
+    for (int i = 0; i < 11; i++) if ((rc = orbm_reserve(h, slots[i], sizes[i]))) return rc;
     hipStream_t s = h->stream;
-    UP(S_UVR, uvr.data(), (size_t)nq * 12); UP(S_LVL, lvl.data(), (size_t)nq * 2); UP(S_QD, qdesc, (size_t)nq * 32);
-    UP(S_QA, ang.data(), (size_t)nq * 4); UP(S_QV, valid.data(), (size_t)nq); UP(S_TD, tdesc, (size_t)nt * 32);
+    UP(S_UVR, uvr.data(), (size_t)nq * 12); UP(S_LVL, lvl.data(), (size_t)nq * 2);
     orbm::ProjArgs a;
-    a.grid = gd;
-    a.tkeys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
-    a.cellStart = (const int32_t*)h->d_buf[G_START]; a.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    a.grid = tr.gd;
+    a.tkeys = tr.keys;
+    a.cellStart = tr.cellStart; a.cellIdx = tr.cellIdx;
     a.quvr = (const float*)h->d_buf[S_UVR]; a.qlvl = (const int8_t*)h->d_buf[S_LVL];
-    a.qdesc = (const uint8_t*)h->d_buf[S_QD]; a.qang = (const float*)h->d_buf[S_QA];
-    a.qvalid = (const uint8_t*)h->d_buf[S_QV]; a.qobs = nullptr;
-    a.tdesc = (const uint8_t*)h->d_buf[S_TD];
+    a.qdesc = d_qdesc; a.qang = d_qang;
+    a.qvalid = d_qvalid; a.qobs = nullptr;
+    a.tdesc = tr.desc;
     a.nq = nq; a.nt = nt;
     a.candCnt = (int32_t*)h->d_buf[S_CNT]; a.candOff = (int32_t*)h->d_buf[S_OFF];
     a.candKey = nullptr; a.candIdx = nullptr;
@@ -1735,6 +1722,54 @@ extern "C" int orbm_search_for_initialization(orbm_t* h, const float* q_xy, floa
     HIPCHK(hipStreamSynchronize(s));
     if (nmatches) *nmatches = nm;
     return ORBX_OK;
+}
+
+extern "C" int orbm_search_for_initialization(orbm_t* h, const float* q_xy, float window_size,
+                                              const OrbxKeyPoint* q_keys_un, const uint8_t* qdesc, int nq,
+                                              const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc, int nt,
+                                              float nnratio, int check_ori, int32_t* matches12, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (nq < 0 || nt < 0 || (nq && (!q_xy || !q_keys_un || !qdesc || !matches12)) || (nt && (!t_keys_un || !tdesc)))
+        return fail(ORBX_E_INVALID, "bad argument");
+    for (int i = 0; i < nq; i++) matches12[i] = -1;
+    if (nmatches) *nmatches = 0;
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    ProjTrain tr;
+    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, tr.gd))) return rc;
+    std::vector<float> ang(nq);
+    std::vector<uint8_t> valid(nq);
+    for (int i = 0; i < nq; i++) { valid[i] = q_keys_un[i].octave <= 0; ang[i] = q_keys_un[i].angle; }
+    enum { S_QD = 2, S_QA, S_QV, S_TD };
+    if ((rc = orbm_reserve(h, S_QD, (size_t)nq * 32)) || (rc = orbm_reserve(h, S_QA, (size_t)nq * 4)) || (rc = orbm_reserve(h, S_QV, (size_t)nq)) ||
+        (rc = orbm_reserve(h, S_TD, (size_t)nt * 32))) return rc;
+    hipStream_t s = h->stream;
+    UP(S_QD, qdesc, (size_t)nq * 32); UP(S_QA, ang.data(), (size_t)nq * 4); UP(S_QV, valid.data(), (size_t)nq); UP(S_TD, tdesc, (size_t)nt * 32);
+    tr.keys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
+    tr.cellStart = (const int32_t*)h->d_buf[G_START]; tr.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    tr.desc = (const uint8_t*)h->d_buf[S_TD];
+    tr.nt = nt;
+    return init_core(h, q_xy, window_size, (const uint8_t*)h->d_buf[S_QD], (const float*)h->d_buf[S_QA], (const uint8_t*)h->d_buf[S_QV], nq, tr,
+                     nnratio, check_ori, matches12, nmatches);
+}
+
+/* SearchForInitialization between two device-resident frames (F1 = the initial frame, F2 = the current one) */
+extern "C" int orbm_search_for_initialization_frames(orbm_t* h, const float* q_xy, float window_size, orbm_frame_t* f1, orbm_frame_t* f2,
+                                                     float nnratio, int check_ori, int32_t* matches12, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (!f1 || !f2 || f1->owner != h || f2->owner != h) return fail(ORBX_E_INVALID, "frames do not belong to this matcher handle");
+    const int nq = f1->n, nt = f2->n;
+    if (nq && (!q_xy || !matches12)) return fail(ORBX_E_INVALID, "bad argument");
+    for (int i = 0; i < nq; i++) matches12[i] = -1;
+    if (nmatches) *nmatches = 0;
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    if ((rc = orbm_reserve(h, 4, (size_t)nq))) return rc;
+    hipLaunchKernelGGL(orbm::k_octave0_flags, dim3((nq + 255) / 256), dim3(256), 0, h->stream, (const orbm::KeyDev*)f1->d_keysUn, nq, (uint8_t*)h->d_buf[4]);
+    const ProjTrain tr = {f2->gd, f2->d_keysUn, f2->d_start, f2->d_idx, f2->d_desc, nt};
+    return init_core(h, q_xy, window_size, f1->d_desc, f1->d_ang, (const uint8_t*)h->d_buf[4], nq, tr, nnratio, check_ori, matches12, nmatches);
 }
 
 extern "C" int orbm_search_for_triangulation(orbm_t* h,

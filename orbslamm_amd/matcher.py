@@ -153,6 +153,15 @@ class ORBmatcher:
                                                 int(self.mbCheckOrientation), int(bool(out_by_train)), ptr(match), C.byref(n)))
         return match[:nout], n.value
 
+    def SearchForInitializationFrames(self, q_xy, window_size, f1, f2):
+        q_xy = np.ascontiguousarray(q_xy, dtype=np.float32)
+        n1 = self._L.orbm_frame_size(f1)
+        m12 = np.full(max(n1, 1), -1, dtype=np.int32)
+        n = C.c_int(0)
+        check(self._L.orbm_search_for_initialization_frames(self._h, ptr(q_xy), C.c_float(window_size), f1, f2, C.c_float(self.mfNNratio),
+                                                            int(self.mbCheckOrientation), ptr(m12), C.byref(n)))
+        return m12[:n1], n.value
+
     def SearchByProjectionFrame(self, mode, th_dist, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, frame, t_occ, assign):
         """SearchByProjection with a device-resident frame as train side."""
         pp = OrbmProjParams(int(mode), self.mfNNratio, int(self.mbCheckOrientation), int(th_dist))

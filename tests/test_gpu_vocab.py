@@ -91,5 +91,12 @@ def test_tracking_front_end_stays_in_hbm(gpu, oracle):
         got, n = m.SearchByBoWFrames(frames[0], qv, frames[1], tv, by_train)
         want, nw = oracle.search_by_bow(d0, k0["angle"], qv, fvs[0], d1, k1["angle"], tv, fvs[1], ratio, ori, by_train)
         assert n == nw and np.array_equal(got, want) and nw > 50
+        # monocular initialisation search between the same two device frames (ORBmatcher.cc:407)
+        q_xy = np.stack([k0["x"], k0["y"]], axis=1).astype(np.float32)
+        gp = oracle.make_grid_params(0.0, 0.0, float(w), float(h))
+        start, idx = oracle.grid_build(gp, k1)
+        gi, gni = m.SearchForInitializationFrames(q_xy, 100.0, frames[0], frames[1])
+        wi, wni = oracle.search_for_initialization(q_xy, 100.0, k0, d0, gp, k1, start, idx, d1, ratio, ori)
+        assert gni == wni and np.array_equal(gi, wi) and wni > 30
         for F in frames:
             m.frame_destroy(F)
