@@ -99,6 +99,16 @@ public:
     }
 #endif
 
+    // Device pointers of the frame the last operator() call extracted (keypoints, descriptor rows); they stay
+    // untouched until the next-but-one call.  Feed them to ORBmatcher::makeFrame so that the frame's undistorted
+    // keys, grid and BoW are built without another trip through the host.
+    void lastOnDevice(const OrbxKeyPoint*& d_keypoints, const uint8_t*& d_descriptors)
+    {
+        OrbxKeyPoint* k = nullptr; uint8_t* d = nullptr;
+        orbx_device_results(h_, &k, &d, nullptr, nullptr);
+        d_keypoints = k; d_descriptors = d;
+    }
+
 protected:
     orbx_t* h_ = nullptr;
     int cap_ = 0;

@@ -9,6 +9,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "orbslamm_hip.h"
@@ -38,6 +39,25 @@ struct FlatFeatVec {
         v.node_id = node_id.data(); v.start = start.data(); v.idx = idx.data();
         return v;
     }
+};
+
+// A Frame's matcher-side state (mvKeysUn, descriptors, 64x48 grid, FeatureVector) held in HBM: orbm_frame_*.
+class DeviceFrame {
+public:
+    explicit DeviceFrame(orbm_frame_t* f) : f_(f) {}
+    ~DeviceFrame() { orbm_frame_destroy(f_); }
+    DeviceFrame(const DeviceFrame&) = delete;
+    DeviceFrame& operator=(const DeviceFrame&) = delete;
+    int size() const { return orbm_frame_size(f_); }
+    // mvKeysUn for the host side (pose optimisation, map point creation)
+    void keysUn(std::vector<OrbxKeyPoint>& out)
+    {
+        out.resize((size_t)size());
+        if (orbm_frame_download_keys_un(f_, out.data()) != ORBX_OK) throw std::runtime_error(std::string("DeviceFrame: ") + orbx_last_error());
+    }
+    orbm_frame_t* get() const { return f_; }
+private:
+    orbm_frame_t* f_;
 };
 
 class ORBmatcher {
@@ -128,6 +148,35 @@ public:
         bestIdx.assign(nq, -1); bestDist.assign(nq, 256);
         check(orbm_window_best(h_, q_uvr, q_ur, q_pred, qdesc, qvalid, nq, &grid, t_keys_un, tdesc, t_uright, nt,
                                mvInvLevelSigma2.data(), (int)mvInvLevelSigma2.size(), chi2, bestIdx.data(), bestDist.data()));
+    }
+
+    // ---- device-resident frames: tail of Frame::Frame (UndistortKeyPoints + AssignFeaturesToGrid)
+    // on the extractor's device output (ORBextractor::lastOnDevice); K = fx, fy, cx, cy; D = mDistCoef
+    std::unique_ptr<DeviceFrame> makeFrame(const OrbxKeyPoint* d_keypoints, const uint8_t* d_descriptors, int n,
+                                           const float K[4], const float D[5], const OrbmGrid& grid)
+    {
+        orbm_frame_t* f = nullptr;
+        check(orbm_frame_create(h_, d_keypoints, d_descriptors, n, K, D, &grid, &f));
+        return std::unique_ptr<DeviceFrame>(new DeviceFrame(f));
+    }
+    // SearchForInitialization(F1, F2, ...) :407 between two device frames
+    int SearchForInitialization(const float* vbPrevMatched_xy, int windowSize, DeviceFrame& F1, DeviceFrame& F2, std::vector<int>& vnMatches12)
+    {
+        vnMatches12.assign((size_t)F1.size(), -1);
+        int n = 0;
+        check(orbm_search_for_initialization_frames(h_, vbPrevMatched_xy, (float)windowSize, F1.get(), F2.get(), mfNNratio, mbCheckOrientation,
+                                                    vnMatches12.data(), &n));
+        return n;
+    }
+    // the four SearchByProjection overloads with a device frame as train side
+    int SearchByProjection(int mode, int thDist, const float* q_uvr, const int8_t* q_lvl, const uint8_t* qdesc, const float* qangle,
+                           const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq, DeviceFrame& train,
+                           std::vector<uint8_t>& tOcc, std::vector<int32_t>& assign)
+    {
+        OrbmProjParams pp = {mode, mfNNratio, mbCheckOrientation ? 1 : 0, thDist};
+        int n = 0;
+        check(orbm_search_by_projection_frame(h_, &pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, train.get(), tOcc.data(), assign.data(), &n));
+        return n;
     }
 
     float mfNNratio;

@@ -63,6 +63,32 @@ int main()
                                                   (const OrcKeyPoint*)kps.data(), cs.data(), ci.data(), d2.data(), n, 0.75f, 1, om12.data());
     EXPECT(ni == oni && ni > 50);
     EXPECT(std::memcmp(m12.data(), om12.data(), (size_t)n * 4) == 0);
+    // device-resident frames: the frame just extracted and a second, noisier one never leave HBM
+    {
+        const OrbxKeyPoint* dk = nullptr; const uint8_t* dd = nullptr;
+        ex.lastOnDevice(dk, dd);
+        const float K[4] = {517.3f, 516.5f, 318.6f, 255.3f}, D0[5] = {0, 0, 0, 0, 0};
+        auto F1 = m.makeFrame(dk, dd, n, K, D0, g);
+        std::vector<uint8_t> img2 = img;
+        for (size_t i = 0; i < img2.size(); i += 3) img2[i] = (uint8_t)(img2[i] ^ (rng() & 3));
+        std::vector<OrbxKeyPoint> kps2; std::vector<uint8_t> desc2;
+        ex(img2.data(), W, H, W, kps2, desc2);
+        ex.lastOnDevice(dk, dd);
+        const int n2 = (int)kps2.size();
+        auto F2 = m.makeFrame(dk, dd, n2, K, D0, g);
+        std::vector<OrbxKeyPoint> un1;
+        F1->keysUn(un1);
+        EXPECT((int)un1.size() == n && std::memcmp(un1.data(), kps.data(), (size_t)n * 28) == 0);  // D = 0: mvKeysUn = mvKeys
+        std::vector<int> f12;
+        const int nf = m.SearchForInitialization(xy.data(), 100, *F1, *F2, f12);
+        std::vector<int32_t> cs2(64 * 48 + 1), ci2(n2), of12(n);
+        orc_grid_build(&og, (const OrcKeyPoint*)kps2.data(), n2, cs2.data(), ci2.data());
+        const int onf = orc_search_for_initialization(xy.data(), 100.f, (const OrcKeyPoint*)kps.data(), desc.data(), n, &og,
+                                                      (const OrcKeyPoint*)kps2.data(), cs2.data(), ci2.data(), desc2.data(), n2, 0.75f, 1, of12.data());
+        EXPECT(nf == onf && nf > 50);
+        EXPECT(std::memcmp(f12.data(), of12.data(), (size_t)n * 4) == 0);
+        std::printf("device frames: %d / %d features, %d init matches\n", n, n2, nf);
+    }
     std::printf(fails ? "adapter_gpu: %d failures\n" : "adapter_gpu ok (%d keypoints, %d BoW matches, %d init matches)\n", fails ? fails : on, nm, ni);
     return fails ? 1 : 0;
 }
