@@ -1189,6 +1189,13 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
 }
 
 // ------------------------------------------------------------------ orientation + rBRIEF + pack
+// dword load (any byte alignment) in the SGPR-base + 32-bit lane offset form.  The compiler does not track it: the
+// consumer waits with an explicit s_waitcnt vmcnt (loads return in issue order).
+__device__ __forceinline__ void gload_sbase(uint32_t& dst, uint32_t voff, const uint8_t* sbase)
+{
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
+}
+
 __device__ const int8_t d_pattern[1024] __attribute__((aligned(16))) = {
 #include "brief_pattern.inc"
 };
@@ -1283,6 +1290,22 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     int bx, fr;
     if (!xcd_block_frame(nframes, bx, fr)) return;
     const int f = fr + src.f0;
+    // The wave's life is a chain of memory latencies (pattern table -> counts -> record -> patches); the first three
+    // are independent, so all of them are issued here, before the table setup and its barrier.  The record is read
+    // unconditionally (the block grid stays inside the frame's kept segment + slack) and masked afterwards.
+    int l = 0;
+    while (l + 1 < g->nlevels && bx >= kb.base[l + 1]) l++;
+    const int idx = (bx - kb.base[l]) * kKpPerBlock + wave * 4 + q;
+    const int nl = g->nlevels;
+    const LevelGeom& L = g->lv[l];
+    const uint64_t rec0 = kept[(int64_t)f * g->keptFrameRecs + L.keptOff + idx];
+    int before = 0, totalAll = 0, mine = 0;
+    for (int i = 0; i < nl; i++) {
+        const int c = keptCount[f * nl + i];
+        if (i < l) before += c;
+        if (i == l) mine = c;
+        totalAll += c;
+    }
     {
         const int32_t pk = ((const int32_t*)d_pattern)[tid];
         spat[tid] = make_float4((float)(int8_t)(pk & 0xFF), (float)(int8_t)((pk >> 8) & 0xFF),
@@ -1299,54 +1322,109 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     }
     __syncthreads();
     OSTAMP();
-    int l = 0;
-    while (l + 1 < g->nlevels && bx >= kb.base[l + 1]) l++;
-    const int idx = (bx - kb.base[l]) * kKpPerBlock + wave * 4 + q;
-    const int nl = g->nlevels;
-    int before = 0, totalAll = 0;
-    for (int i = 0; i < nl; i++) {
-        const int c = keptCount[f * nl + i];
-        if (i < l) before += c;
-        totalAll += c;
-    }
     if (bx == 0 && tid == 0) outCount[f] = totalAll < g->maxKp ? totalAll : g->maxKp;
     const int o = before + idx;
-    const bool active = idx < keptCount[f * nl + l] && o < g->maxKp;   // uniform over the quarter
+    const bool active = idx < mine && o < g->maxKp;   // uniform over the quarter
     if (!__builtin_amdgcn_ballot_w64(active)) return;
     OSTAMP();
-    const LevelGeom& L = g->lv[l];
-    const uint64_t rec = active ? kept[(int64_t)f * g->keptFrameRecs + L.keptOff + idx] : 0;
+    const uint64_t rec = active ? rec0 : 0;
     const int cx = (int)cand_x(rec) + kMinBorder, cy = (int)cand_y(rec) + kMinBorder;  // :843-844
     int stride;
     const uint8_t* img = level_ptr(g, src, f, l, stride);
-    const uint8_t* center = img + (int64_t)cy * stride + cx;
+    const int bs = L.blurStride;
+    const uint8_t* blur = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff;
+    const int ctrOff = cy * stride + cx, bctrOff = cy * bs + cx;  // uniform over the quarter
 
     OSTAMP();
-    // IC_Angle
-    int m10, m01 = 0;
+    // Both patches of the wave's four keypoints are fetched by ALL 64 lanes, one keypoint after the other: the lane ->
+    // (row, dword) map is then the same for every load, the keypoint's origin is a scalar (v_readlane) and the loads
+    // take the SGPR-base form -- no per-load vector address arithmetic (it was a quarter of this kernel's instructions).
+    //  * IC_Angle patch: rows cy-15 .. cy+16 x 8 dwords from cx-16, 8 rows per load (row cy+16 carries zero weights)
+    //  * blurred patch:  rows cy-19 .. cy+19 x 10 dwords from cx-19, 6 rows per load on lanes 0..59; it does not depend
+    //    on the angle, so it is in flight during the moments and lands in LDS before the trigonometry.
+    // (16 bytes per lane -- 12 loads instead of 44 -- is slower: the patch origins have byte alignment, and what bounds
+    // the kernel is the ~90 cache lines a keypoint touches, not the number of load instructions.)
+    uint32_t dw[4][4];
     {
-        struct __attribute__((packed)) U32 { uint32_t v; };
-        uint32_t dw[16];
+        const uint32_t voff = (uint32_t)((lane >> 3) * stride + 4 * (lane & 7));
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int item = ql + 16 * it;
-            const int r = item < 248 ? (item >> 3) : 15, c = item & 7;
-            dw[it] = ((const U32*)(center + (r - kHalfPatch) * stride + (4 * c - 16)))->v;
+        for (int k = 0; k < 4; k++) {
+            const uint8_t* pk = img + (__builtin_amdgcn_readlane(ctrOff, 16 * k) - kHalfPatch * stride - 16);
+#pragma unroll
+            for (int j = 0; j < 4; j++) gload_sbase(dw[k][j], voff, pk + 8 * j * stride);
         }
-        uint32_t su = 0, s1 = 0;
+    }
+    // lanes past the 6 x 10 items of a load (and past row 38 in the last one) repeat an item: same address, same LDS
+    // slot, so neither the loads nor the stores need a predicate; an idle quarter repeats keypoint 0 (always live)
+    constexpr int NPI = (PROWS + 5) / 6;  // 7 loads of 6 rows
+    constexpr int LASTROWS = PROWS - 6 * (NPI - 1);
+    uint32_t pd[4][NPI];
+    const int pr = min(lane, 59) / PDW, pc = min(lane, 59) - pr * PDW;
+    const int sidx = pr * PDW + pc, sidxLast = min(pr, LASTROWS - 1) * PDW + pc;
+    {
+        const uint32_t voff = (uint32_t)(pr * bs + 4 * pc), voffLast = (uint32_t)(min(pr, LASTROWS - 1) * bs + 4 * pc);
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int item = ql + 16 * it;  // items 248..255 carry zero weights
-            const uint32_t rs = __builtin_amdgcn_udot4(dw[it], sw1[item], 0u, false);
-            su = __builtin_amdgcn_udot4(dw[it], swu[item], su, false);
-            s1 += rs;
-            m01 += ((item >> 3) - kHalfPatch) * (int)rs;
+        for (int k = 0; k < 4; k++) {
+            const int so = __builtin_amdgcn_readlane((int)active, 16 * k) ? __builtin_amdgcn_readlane(bctrOff, 16 * k) : __builtin_amdgcn_readlane(bctrOff, 0);
+            const uint8_t* pk = blur + (so - PR * bs - PR);
+#pragma unroll
+            for (int i = 0; i < NPI; i++) gload_sbase(pd[k][i], i + 1 < NPI ? voff : voffLast, pk + 6 * i * bs);
         }
-        m10 = (int)su - 16 * (int)s1;
+    }
+    // IC_Angle: m10 = sum u I, m01 = sum v I over the disc, as v_dot4_u32_u8 sums against byte weights u + 16, v + 16
+    // and the disc flags (one set of weights per lane serves the four keypoints)
+    int m10, m01;
+    asm volatile("s_waitcnt vmcnt(28)"  // the 16 IC_Angle dwords are in; the 28 patch dwords may still be in flight
+                 : "+v"(dw[0][0]), "+v"(dw[0][1]), "+v"(dw[0][2]), "+v"(dw[0][3]), "+v"(dw[1][0]), "+v"(dw[1][1]), "+v"(dw[1][2]), "+v"(dw[1][3]),
+                   "+v"(dw[2][0]), "+v"(dw[2][1]), "+v"(dw[2][2]), "+v"(dw[2][3]), "+v"(dw[3][0]), "+v"(dw[3][1]), "+v"(dw[3][2]), "+v"(dw[3][3]));
+    static_assert(4 * NPI == 28, "vmcnt above");
+    {
+        int A[4], B[4];
+        uint32_t wu[4], w1[4], wv[4];
 #pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d); m01 += __shfl_xor(m01, d); }
+        for (int j = 0; j < 4; j++) {
+            wu[j] = swu[lane + 64 * j];
+            w1[j] = sw1[lane + 64 * j];
+            wv[j] = w1[j] * (uint32_t)(8 * j + (lane >> 3) + 1);  // (v + 16) per flagged byte, v = row - 15
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t su = 0, sv = 0, s1 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                su = __builtin_amdgcn_udot4(dw[k][j], wu[j], su, false);
+                sv = __builtin_amdgcn_udot4(dw[k][j], wv[j], sv, false);
+                s1 = __builtin_amdgcn_udot4(dw[k][j], w1[j], s1, false);
+            }
+            A[k] = (int)su - 16 * (int)s1;
+            B[k] = (int)sv - 16 * (int)s1;
+        }
+        // reduce-scatter over the wave: v_permlane32_swap leaves keypoints {0,1} in lanes 0..31 and {2,3} in 32..63,
+        // v_permlane16_swap leaves keypoint q in quarter q; four row rotations finish the sum inside the quarter
+        auto swap32 = [](int a, int b) { const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false); return (int)(r[0] + r[1]); };
+        auto swap16 = [](int a, int b) { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false); return (int)(r[0] + r[1]); };
+        m10 = swap16(swap32(A[0], A[2]), swap32(A[1], A[3]));
+        m01 = swap16(swap32(B[0], B[2]), swap32(B[1], B[3]));
+        m10 += __builtin_amdgcn_update_dpp(0, m10, 0x128, 0xF, 0xF, false);  // row_ror:8
+        m01 += __builtin_amdgcn_update_dpp(0, m01, 0x128, 0xF, 0xF, false);
+        m10 += __builtin_amdgcn_update_dpp(0, m10, 0x124, 0xF, 0xF, false);
+        m01 += __builtin_amdgcn_update_dpp(0, m01, 0x124, 0xF, 0xF, false);
+        m10 += __builtin_amdgcn_update_dpp(0, m10, 0x122, 0xF, 0xF, false);
+        m01 += __builtin_amdgcn_update_dpp(0, m01, 0x122, 0xF, 0xF, false);
+        m10 += __builtin_amdgcn_update_dpp(0, m10, 0x121, 0xF, 0xF, false);
+        m01 += __builtin_amdgcn_update_dpp(0, m01, 0x121, 0xF, 0xF, false);
     }
     OSTAMP();
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(pd[0][0]), "+v"(pd[0][1]), "+v"(pd[0][2]), "+v"(pd[0][3]), "+v"(pd[0][4]), "+v"(pd[0][5]), "+v"(pd[0][6]),
+                   "+v"(pd[1][0]), "+v"(pd[1][1]), "+v"(pd[1][2]), "+v"(pd[1][3]), "+v"(pd[1][4]), "+v"(pd[1][5]), "+v"(pd[1][6]),
+                   "+v"(pd[2][0]), "+v"(pd[2][1]), "+v"(pd[2][2]), "+v"(pd[2][3]), "+v"(pd[2][4]), "+v"(pd[2][5]), "+v"(pd[2][6]),
+                   "+v"(pd[3][0]), "+v"(pd[3][1]), "+v"(pd[3][2]), "+v"(pd[3][3]), "+v"(pd[3][4]), "+v"(pd[3][5]), "+v"(pd[3][6]));
+    // park the blurred patches: item 60 i + lane of keypoint k is (row 6 i + lane / 10, dword lane % 10)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < NPI; i++) spatch[wave * 4 + k][60 * i + (i + 1 < NPI ? sidx : sidxLast)] = pd[k][i];
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // steered BRIEF on the blurred level
@@ -1355,40 +1433,27 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     double sn, cs;
     sincos_0_2pi((double)ang, sn, cs);
     const float a = (float)cs, b = (float)sn;
-    const int bs = L.blurStride;
-    const uint8_t* bc = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)cy * bs + cx;
     OSTAMP();
-    // The 512 sample points of a keypoint lie within radius 18.4 of it: the quarter first copies that patch of the
-    // blurred level into LDS with row-coalesced (unaligned) dword loads -- 25 per lane, ~100 cache lines per wave --
-    // and gathers from there.  Gathering the bytes straight from memory costs one cache-line access per lane and
-    // test (2048 per wave): the kernel then runs at the address rate of the vector-memory pipe (14 of its 19 us).
-    uint32_t* const mypatch = spatch[wave * 4 + q];
-    {
-        struct __attribute__((packed)) U32 { uint32_t v; };
-        constexpr int NIT = (PROWS * PDW + 15) / 16;
-        uint32_t pd[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int item = min(ql + 16 * it, PROWS * PDW - 1);
-            const int r = item / PDW, c = item - r * PDW;
-            pd[it] = active ? ((const U32*)(bc + (r - PR) * bs + (4 * c - PR)))->v : 0u;
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int item = ql + 16 * it;
-            if (item < PROWS * PDW) mypatch[item] = pd[it];
-        }
-    }
-    const uint8_t* const pb = (const uint8_t*)mypatch + PR * (PDW * 4) + PR;  // the keypoint's own pixel
+    // The 512 sample points of a keypoint lie within radius 18.4 of it, inside the LDS patch (gathering the bytes
+    // straight from memory costs one cache-line access per lane and test: the address rate of the vector-memory pipe).
+    // cvRound (:118-120) = round-half-even = one fp32 add of 1.5 * 2^23: the integer sits in the low mantissa bits,
+    // v_mad_i32_i24 reads exactly those, and the biases are folded into the patch offset.
+    const uint8_t* const sp8 = (const uint8_t*)&spatch[0][0];
+    constexpr float kRnd = 12582912.f;  // 0x4B400000
+    const uint32_t adj = (uint32_t)((wave * 4 + q) * (PROWS * PDW * 4) + PR * (PDW * 4) + PR) - 0x400000u * (uint32_t)(PDW * 4) - 0x4B400000u;
+    static_assert(PDW * 4 == 40, "row pitch is an inline constant of the mad below");
     uint32_t myWord = 0;
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         const float4 pt = spat[ql + 16 * t];
-        const int ry0 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-        const int rx0 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-        const int ry1 = (int)__builtin_rintf(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-        const int rx1 = (int)__builtin_rintf(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-        const int t0 = pb[ry0 * (PDW * 4) + rx0], t1 = pb[ry1 * (PDW * 4) + rx1];
+        const int ry0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)), kRnd));
+        const int rx0 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), kRnd));
+        const int ry1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), kRnd));
+        const int rx1 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)), kRnd));
+        uint32_t o0, o1;
+        asm("v_mad_i32_i24 %0, %1, 40, %2" : "=v"(o0) : "v"(ry0), "v"(rx0));
+        asm("v_mad_i32_i24 %0, %1, 40, %2" : "=v"(o1) : "v"(ry1), "v"(rx1));
+        const int t0 = sp8[o0 + adj], t1 = sp8[o1 + adj];
         const uint64_t bal = __builtin_amdgcn_ballot_w64(t0 < t1);
         const uint32_t w16 = (uint32_t)(bal >> (16 * q)) & 0xFFFFu;  // tests 16t .. 16t+15 of this quarter's keypoint
         if (ql == t) myWord = w16;
