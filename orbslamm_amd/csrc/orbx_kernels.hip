@@ -1290,15 +1290,19 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     int bx, fr;
     if (!xcd_block_frame(nframes, bx, fr)) return;
     const int f = fr + src.f0;
-    // The wave's life is a chain of memory latencies (pattern table -> counts -> record -> patches); the first three
-    // are independent, so all of them are issued here, before the table setup and its barrier.  The record is read
-    // unconditionally (the block grid stays inside the frame's kept segment + slack) and masked afterwards.
+    // The wave's life is a chain of memory latencies (pattern table -> counts -> record -> patches).  The first three
+    // are independent and issued together (the record is read unconditionally -- the block grid stays inside the
+    // frame's kept segment + slack -- and masked afterwards); the patch loads go out as soon as the record is in, and
+    // the block's tables and their barrier are built underneath them.
     int l = 0;
     while (l + 1 < g->nlevels && bx >= kb.base[l + 1]) l++;
     const int idx = (bx - kb.base[l]) * kKpPerBlock + wave * 4 + q;
     const int nl = g->nlevels;
     const LevelGeom& L = g->lv[l];
     const uint64_t rec0 = kept[(int64_t)f * g->keptFrameRecs + L.keptOff + idx];
+    int32_t pk = ((const int32_t*)d_pattern)[tid];
+    const int tv = (tid >> 3) - kHalfPatch;
+    int um = g->umax[(tv < 0 ? -tv : tv) & 15];
     int before = 0, totalAll = 0, mine = 0;
     for (int i = 0; i < nl; i++) {
         const int c = keptCount[f * nl + i];
@@ -1306,26 +1310,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
         if (i == l) mine = c;
         totalAll += c;
     }
-    {
-        const int32_t pk = ((const int32_t*)d_pattern)[tid];
-        spat[tid] = make_float4((float)(int8_t)(pk & 0xFF), (float)(int8_t)((pk >> 8) & 0xFF),
-                                (float)(int8_t)((pk >> 16) & 0xFF), (float)(int8_t)((pk >> 24) & 0xFF));
-        const int v = (tid >> 3) - kHalfPatch, u0 = 4 * (tid & 7) - 16;
-        const int d = tid < 248 ? g->umax[(v < 0 ? -v : v) & 15] : -1;
-        uint32_t wu = 0, w1 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int u = u0 + j;
-            if (u >= -d && u <= d) { wu |= (uint32_t)(u + 16) << (8 * j); w1 |= 1u << (8 * j); }
-        }
-        swu[tid] = wu; sw1[tid] = w1;
-    }
-    __syncthreads();
-    OSTAMP();
     if (bx == 0 && tid == 0) outCount[f] = totalAll < g->maxKp ? totalAll : g->maxKp;
+    asm volatile("" : "+v"(pk), "+v"(um));  // landed here: no compiler-tracked load is in flight next to the untracked ones below
     const int o = before + idx;
     const bool active = idx < mine && o < g->maxKp;   // uniform over the quarter
-    if (!__builtin_amdgcn_ballot_w64(active)) return;
+    const bool anyActive = __builtin_amdgcn_ballot_w64(active) != 0;
     OSTAMP();
     const uint64_t rec = active ? rec0 : 0;
     const int cx = (int)cand_x(rec) + kMinBorder, cy = (int)cand_y(rec) + kMinBorder;  // :843-844
@@ -1345,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     // (16 bytes per lane -- 12 loads instead of 44 -- is slower: the patch origins have byte alignment, and what bounds
     // the kernel is the ~90 cache lines a keypoint touches, not the number of load instructions.)
     uint32_t dw[4][4];
-    {
+    if (anyActive) {
         const uint32_t voff = (uint32_t)((lane >> 3) * stride + 4 * (lane & 7));
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1361,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     uint32_t pd[4][NPI];
     const int pr = min(lane, 59) / PDW, pc = min(lane, 59) - pr * PDW;
     const int sidx = pr * PDW + pc, sidxLast = min(pr, LASTROWS - 1) * PDW + pc;
-    {
+    if (anyActive) {
         const uint32_t voff = (uint32_t)(pr * bs + 4 * pc), voffLast = (uint32_t)(min(pr, LASTROWS - 1) * bs + 4 * pc);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1371,6 +1360,23 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
             for (int i = 0; i < NPI; i++) gload_sbase(pd[k][i], i + 1 < NPI ? voff : voffLast, pk + 6 * i * bs);
         }
     }
+    // the block's tables are built while the patches are in flight
+    {
+        spat[tid] = make_float4((float)(int8_t)(pk & 0xFF), (float)(int8_t)((pk >> 8) & 0xFF),
+                                (float)(int8_t)((pk >> 16) & 0xFF), (float)(int8_t)((pk >> 24) & 0xFF));
+        const int u0 = 4 * (tid & 7) - 16;
+        const int d = tid < 248 ? um : -1;
+        uint32_t wu = 0, w1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int u = u0 + j;
+            if (u >= -d && u <= d) { wu |= (uint32_t)(u + 16) << (8 * j); w1 |= 1u << (8 * j); }
+        }
+        swu[tid] = wu; sw1[tid] = w1;
+    }
+    __syncthreads();
+    if (!anyActive) return;
+    OSTAMP();
     // IC_Angle: m10 = sum u I, m01 = sum v I over the disc, as v_dot4_u32_u8 sums against byte weights u + 16, v + 16
     // and the disc flags (one set of weights per lane serves the four keypoints)
     int m10, m01;
