@@ -152,6 +152,9 @@ typedef struct {
  * blur / matching / sub-batches); used to time kernels in isolation. */
 int orbx_set_serial(orbx_t* h, int serial);
 int orbx_profile_enable(orbx_t* h, int enable);
+/* bracket only the launches of one kernel (name as reported by orbx_profile_read; NULL = all again): the
+ * event records between dependent launches cost ~4 % of a stream-overlapped batch, one kernel's ~1 % */
+int orbx_profile_select(orbx_t* h, const char* kernel);
 int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset);
 
 /* ---------------------------------------------------------------- matcher

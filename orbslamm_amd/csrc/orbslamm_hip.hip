@@ -67,7 +67,8 @@ static const char* kProfNames[P_COUNT] = {"h2d", "k_pyramid", "k_fast", "k_distr
 struct ProfSpan { int id; hipEvent_t a, b; };
 
 struct Profiler {
-    bool on = false;
+    bool on = false, cur = false;
+    int only = -1;  // >= 0: only this kernel's launches are bracketed
     std::vector<ProfSpan> spans;
     std::vector<hipEvent_t> pool;
     double ms[P_COUNT] = {0};
@@ -81,14 +82,15 @@ struct Profiler {
     }
     void begin(int id, hipStream_t s)
     {
-        if (!on) return;
+        cur = on && (only < 0 || only == id);
+        if (!cur) return;
         ProfSpan sp{id, get(), get()};
         (void)hipEventRecord(sp.a, s);
         spans.push_back(sp);
     }
     void end(hipStream_t s)
     {
-        if (!on) return;
+        if (!cur) return;
         (void)hipEventRecord(spans.back().b, s);
     }
     void collect()
@@ -1126,6 +1128,16 @@ extern "C" int orbx_profile_enable(orbx_t* h, int enable)
     // events for ~250 steps up front, so that the timed region creates none
     if (enable) while (h->prof.pool.size() < 8192) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; h->prof.pool.push_back(e); }
     return ORBX_OK;
+}
+
+extern "C" int orbx_profile_select(orbx_t* h, const char* kernel)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!kernel) { h->prof.only = -1; return ORBX_OK; }
+    for (int i = 0; i < P_COUNT; i++)
+        if (!strcmp(kernel, kProfNames[i])) { h->prof.only = i; return ORBX_OK; }
+    return fail(ORBX_E_INVALID, "no kernel named %s", kernel);
 }
 
 extern "C" int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset)

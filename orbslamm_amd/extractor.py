@@ -178,6 +178,10 @@ class ORBextractor:
     def profile_enable(self, on=True):
         check(self._L.orbx_profile_enable(self._h, int(bool(on))))
 
+    def profile_select(self, kernel=None):
+        """bracket only `kernel`'s launches (None: all kernels again)"""
+        check(self._L.orbx_profile_select(self._h, kernel.encode() if kernel else None))
+
     def profile_read(self, reset=True):
         p = _lib.OrbxProfile()
         check(self._L.orbx_profile_read(self._h, C.byref(p), int(bool(reset))))
