@@ -21,7 +21,9 @@ def init(backend, device=None):
     """returns (rank, world, local_rank); no-op for a single process"""
     import torch.distributed as dist
     rank, world, local_rank = env_rank()
-    if world > 1 and not dist.is_initialized():
+    # ORBX_BENCH_FORCE_DIST=1: a 1-rank process group, to exercise the N > 1 initialisation order on a 1-GPU box
+    force = os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -38,9 +40,10 @@ def stream_of_rank(rank, streams_per_rank=1):
 
 
 def barrier(world):
-    if world > 1:
+    if world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
-        dist.barrier()
+        if dist.is_initialized():
+            dist.barrier()
 
 
 def timed_region(step, steps, sync, world):
@@ -77,7 +80,7 @@ def aggregate(gathered, dt_max):
 
 
 def finalize(world):
-    if world > 1:
+    if world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if dist.is_initialized():
             dist.destroy_process_group()
