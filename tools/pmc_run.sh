@@ -4,5 +4,5 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; CTR=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTR -d $R/gpurun_out/pmc_$TAG -o p -- python $R/bench.py --no-cpu-baseline --no-profile --steps 5 --warmup 2 "$@" > /dev/null 2> $R/gpurun_out/pmc_$TAG.err
+timeout 240 rocprofv3 --pmc $CTR -d $R/gpurun_out/pmc_$TAG -o p -- python $R/bench.py --no-cpu-baseline --no-profile --steps 5 --warmup 2 "$@" > /dev/null 2> $R/gpurun_out/pmc_$TAG.err
 python $R/tools/pmc_table.py $R/gpurun_out/pmc_$TAG/p_results.db | tee $R/gpurun_out/pmc_$TAG.txt

@@ -1,21 +1,22 @@
 #!/bin/bash
 # On the GPU box (via gpurun): regenerate everything kept under profiles/ for round TAG (default r01) into
 # gpurun_out/.  rocprofv3 passes are separate runs: --kernel-trace --stats, then one --pmc pass per counter set
-# (never combined with tracing), PMC passes in ORBX_SERIAL=1 so that every kernel is alone on the GPU.
+# (never combined with tracing), PMC passes in ORBX_SERIAL=1 so that every kernel is alone on the GPU.  Every profiler
+# run sits under its own `timeout`: a pass with derived TA_*/TCP_* counters once never returned and cost 10 GPU-minutes.
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 ORBX_SERIAL=1 python $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_serial.json 2>> $O/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats -d /tmp/prof_o -o t -- python $R/bench.py --no-cpu-baseline --no-replay > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_o -o t -- python $R/bench.py --no-cpu-baseline --no-replay > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
 python $R/tools/rocprof_summary.py stats /tmp/prof_o/t_results.db > $O/${TAG}_kernel_stats.txt
-python $R/tools/timeline.py /tmp/prof_o/t_results.db 40 > $O/${TAG}_timeline.txt
-ORBX_SERIAL=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o t -- python $R/bench.py --no-cpu-baseline --no-replay > /dev/null 2>&1
+python $R/tools/timeline.py /tmp/prof_o/t_results.db 70 300 > $O/${TAG}_timeline.txt
+ORBX_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o t -- python $R/bench.py --no-cpu-baseline --no-replay > /dev/null 2>&1
 python $R/tools/rocprof_summary.py stats /tmp/prof_s/t_results.db > $O/${TAG}_kernel_stats_serial.txt
 export ORBX_SERIAL=1
 pmc() { # tag, counters
-  rocprofv3 --pmc $2 -d /tmp/pmc_$1 -o p -- python $R/bench.py --no-cpu-baseline --no-profile --steps 5 --warmup 2 > /dev/null 2>&1
+  timeout 240 rocprofv3 --pmc $2 -d /tmp/pmc_$1 -o p -- python $R/bench.py --no-cpu-baseline --no-profile --steps 5 --warmup 2 > /dev/null 2>&1
 }
 pmc fetch "FETCH_SIZE"; python $R/tools/rocprof_summary.py pmc /tmp/pmc_fetch/p_results.db > $O/${TAG}_pmc_fetch.txt
 pmc write "WRITE_SIZE"; python $R/tools/rocprof_summary.py pmc /tmp/pmc_write/p_results.db > $O/${TAG}_pmc_write.txt
