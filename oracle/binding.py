@@ -375,6 +375,61 @@ class Vocabulary:
         return (wid[:nw.value].copy(), ww[:nw.value].copy()), (fn[:nf.value].copy(), fs[:nf.value + 1].copy(), fi[:fs[nf.value]].copy())
 
 
+    def transform_one(self, desc, levelsup):
+        """per feature: (word id, weight, node id at L - levelsup) -- the stream transform() aggregates"""
+        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        n = desc.shape[0]
+        word = np.zeros(n, np.uint32); w = np.zeros(n, np.float64); nid = np.zeros(n, np.uint32)
+        a, b, c = C.c_uint32(), C.c_double(), C.c_uint32()
+        self.L.orc_vocab_transform_one.restype = None
+        for i in range(n):
+            self.L.orc_vocab_transform_one(self.v, desc[i].ctypes.data_as(C.c_void_p), int(levelsup), C.byref(a), C.byref(b), C.byref(c))
+            word[i], w[i], nid[i] = a.value, b.value, c.value
+        return word, w, nid
+
+
+# ---------------------------------------------------------------- oracle/_ref: the reference's own object code
+REF_SO = os.path.join(_HERE, "_ref", "libdbow2_ref.so")
+
+
+def build_ref():
+    """oracle/Makefile target _ref: DBoW2 BowVector.cpp + FeatureVector.cpp compiled from /root/reference where they
+    lie (no-op without the checkout: the GPU box only has the prebuilt library).  Returns the path or None."""
+    subprocess.call(["make", "-s", "-C", _HERE, "_ref"])
+    return REF_SO if os.path.exists(REF_SO) else None
+
+
+_ref = None
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        so = REF_SO if os.path.exists(REF_SO) else build_ref()
+        if so is None:
+            return None
+        _ref = C.CDLL(so)
+    return _ref
+
+
+def ref_bow_build(ids, w, add_if_not_exist, norm):
+    """DBoW2::BowVector fed (ids[i], w[i]) in order; norm: 0 none, 1 L1, 2 L2 -> (ids, values) in map order"""
+    R = ref_lib()
+    ids = np.ascontiguousarray(ids, dtype=np.uint32); w = np.ascontiguousarray(w, dtype=np.float64)
+    oid = np.zeros(max(len(ids), 1), np.uint32); ow = np.zeros(max(len(ids), 1), np.float64)
+    m = R.ref_bow_build(_p(ids), _p(w), len(ids), int(bool(add_if_not_exist)), int(norm), _p(oid), _p(ow))
+    return oid[:m].copy(), ow[:m].copy()
+
+
+def ref_fv_build(node, feat):
+    """DBoW2::FeatureVector fed addFeature(node[i], feat[i]) in order -> CSR (nodes, start, idx) in map order"""
+    R = ref_lib()
+    node = np.ascontiguousarray(node, dtype=np.uint32); feat = np.ascontiguousarray(feat, dtype=np.uint32)
+    on = np.zeros(max(len(node), 1), np.uint32); st = np.zeros(len(node) + 1, np.int32); ix = np.zeros(max(len(node), 1), np.int32)
+    k = R.ref_fv_build(_p(node), _p(feat), len(node), _p(on), _p(st), _p(ix))
+    return on[:k].copy(), st[:k + 1].copy(), ix[:st[k]].copy()
+
+
 def distinctive_descriptors(desc, start, L=None):
     L = L or lib()
     desc = np.ascontiguousarray(desc, dtype=np.uint8)

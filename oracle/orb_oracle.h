@@ -13,8 +13,11 @@
  * reference target is OpenCV 3.0.0 (CMake asks for >=3.0, fallback
  * 2.4.3); its published generic C++ algorithm is restated here.
  * The reference holds no tests / golden vectors for this path, and
- * the reference cannot be built here without writing stand-ins for OpenCV, so
- * there is no oracle/_ref.  What IS pinned: the FAST-9 corner predicate (fixture from
+ * the extractor / matcher / vocabulary sources cannot be built here without writing
+ * stand-ins for OpenCV.  oracle/_ref holds the one part that can: DBoW2's BowVector.cpp
+ * and FeatureVector.cpp (standard library only), compiled from the reference where they
+ * lie (Makefile target _ref) -- orb_vocab.c's BowVector / FeatureVector assembly is held
+ * to that object code bit for bit (tests/test_oracle_vs_reference_cpu.py).  Also pinned: the FAST-9 corner predicate (fixture from
  * scikit-image's independent implementation), the BRIEF pattern (sha256), the umax
  * table, the per-level feature split, the matcher arithmetic (fully visible in
  * the reference source) -- see tests/test_oracle_*.py.
@@ -212,6 +215,7 @@ typedef struct OrcVocab OrcVocab;
 OrcVocab* orc_vocab_create(int k, int L, int scoring, int weighting, int n, const int32_t* parent,
                            const uint8_t* is_leaf, const uint8_t* desc, const double* weight);
 void orc_vocab_free(OrcVocab* v);
+void orc_vocab_transform_one(const OrcVocab* v, const uint8_t* f, int levelsup, uint32_t* word, double* w, uint32_t* nid);
 /* BowVector as (word_id ascending, weight), FeatureVector as CSR (node ascending, feature
  * indices ascending).  Capacities: n entries each, fv_start n+1. */
 int  orc_vocab_transform(const OrcVocab* v, const uint8_t* desc, int n, int levelsup,

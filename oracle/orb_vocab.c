@@ -87,6 +87,14 @@ static void transform_one(const OrcVocab* v, const uint8_t* f, int levelsup, uin
     *w = v->weight[final_id];
 }
 
+/* the per-feature result of the descent, for tests that feed the REFERENCE's BowVector / FeatureVector classes
+ * (oracle/_ref, tests/test_oracle_vs_reference_cpu.py) with the same (word, weight, node) stream */
+void orc_vocab_transform_one(const OrcVocab* v, const uint8_t* f, int levelsup, uint32_t* word, double* w, uint32_t* nid)
+{
+    *nid = 0;
+    transform_one(v, f, levelsup, word, w, nid);
+}
+
 typedef struct { uint32_t key; uint32_t feat; double w; } Ent;
 static int cmp_ent(const void* a, const void* b)
 {
