@@ -145,6 +145,7 @@ struct orbx_handle {
     hipEvent_t evStart = nullptr, evPart[kMaxSplit] = {nullptr}, evFast0[kMaxSplit] = {nullptr};
     bool partEverRan[kMaxSplit] = {false};
     int lastParts = 0;                        // evPart[0..lastParts) belong to the last extraction
+    int prevB = 0, prevSplit = 0;             // its frame -> sub-batch partition (run_extract: join on a change)
     hipStream_t stream3 = nullptr;            // matching runs beside the next batch's pyramid/FAST
     hipEvent_t evPyr[kMaxSplit] = {nullptr}, evBlur[kMaxSplit] = {nullptr}, evDesc = nullptr, evMatch[2] = {nullptr, nullptr};
     bool matchPending[2] = {false, false};
@@ -758,6 +759,18 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     // buffers) and the upload on the host-facing stream, nothing else -- the next batch's pyramid of sub-batch 0
     // starts while this batch's sub-batch 1 is still in its quadtree.  Consumers join through evPart (join_parts).
     if (!h->serial) HIPCHK(hipEventRecord(h->evStart, s0));
+    // A frame's scratch (pyramid and blur levels, candidate segments, kept records) is ordered between two calls by
+    // the stream of the sub-batch that owns the frame.  When the batch size -- and with it the frame -> sub-batch
+    // map -- changes between two calls that the caller did not separate by a sync, a frame can change hands: its new
+    // owner's pyramid would overwrite what the old owner's descriptor kernel may still be reading.  On such a call
+    // (never in a steady stream) every stream first joins all sub-batches of the previous call.
+    if (!h->serial && h->lastParts > 0 && (B != h->prevB || nsplit != h->prevSplit)) {
+        for (int p = 0; p < h->lastParts; p++) {
+            HIPCHK(hipStreamWaitEvent(s0, h->evPart[p], 0));
+            for (int q = 0; q < nsplit; q++) HIPCHK(hipStreamWaitEvent(h->streamP[q], h->evPart[p], 0));
+        }
+    }
+    h->prevB = B; h->prevSplit = nsplit;
     h->lastParts = 0;
     h->curSet ^= 1;
     const int set = h->curSet;

@@ -344,6 +344,38 @@ def test_pipelined_batches_without_sync(gpu, oracle, B):
             assert nm == nr and np.array_equal(m[:len(k)], mr), "K=%d frame %d matches" % (K, f)
 
 
+@pytest.mark.parametrize("sizes", [(16, 12, 16), (16, 1, 16, 5), (3, 16, 9), (16, 9), (2, 1, 16), (16, 15, 14, 13)])
+def test_batch_size_changes_between_unsynced_calls(gpu, oracle, sizes):
+    """the frame -> sub-batch partition follows the batch size; when it changes between two calls that no sync
+    separates, a frame's scratch buffers change hands between streams (run_extract joins the previous call's
+    sub-batches on such a call).  Every schedule is enqueued back to back; its last batch -- and the match of its
+    first frame against the previous batch's last frame -- must equal the oracle's.
+    (The ordering gap was found by reading the event graph; the library without the join also passes this test
+    -- 54 runs -- i.e. the hazard was never observed to corrupt a result.  The test guards the plumbing of the join
+    and the behaviour under changing B, it is not evidence of a past failure.)"""
+    w, h, nf = 640, 480, 1000
+    fr = frames_for(w, h, sum(sizes), stream=57)
+    gex = gpu_extractor(nf, w, h, B=16)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    dargs = [gex.upload_frames(fr[off[i]:off[i + 1]], stride=640) for i in range(len(sizes))]
+    for rep in range(3):  # the same schedule again on the warm handle: the first batch then follows the last one
+        gex.reset_stream()
+        for a in dargs:
+            gex.extract_batch_device(*a)
+            gex.match_prev_batch_device(0.7, 50, True)
+        first, B = int(off[-2]), sizes[-1]
+        prev = oex(fr[first - 1])
+        for f in range(B):
+            k, d = gex.download(f)
+            r = oex(fr[first + f])
+            assert r["kps"].tobytes() == k.tobytes() and np.array_equal(r["desc"], d), "rep %d frame %d" % (rep, f)
+            m, nm = gex.download_matches(f)
+            mr, nr = oracle.match_bruteforce(d, k["angle"], prev["desc"], prev["kps"]["angle"], 0.7, 50, True)
+            assert nm == nr and np.array_equal(m[:len(k)], mr), "rep %d frame %d matches" % (rep, f)
+            prev = r
+
+
 def test_soak_256_frames_bit_exact(gpu, oracle):
     """4 streams x 64 consecutive frames at the benchmark shape through the device-resident
     batch path: every keypoint record, descriptor byte and match index against the oracle
