@@ -1154,6 +1154,17 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     }
     __syncthreads();
 
+#ifdef ORBX_EXP_INFLATE
+    // experiment hook (off in the product build): ORBX_EXP_INFLATE dependency-free VALU instructions per thread, to
+    // measure how much of the overlapped pipeline is instruction issue (build the variant as
+    // build_ub/libB.so with -DORBX_EXP_INFLATE=100 and run tools/ab_bench.sh)
+    {
+        uint32_t zz = tid;
+#pragma unroll
+        for (int i = 0; i < ORBX_EXP_INFLATE; i++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(zz) : "v"(tid));
+        if (zz == 0xdeadbeefu) vs[0] = zz;
+    }
+#endif
     // horizontal pass on the 16-bit sums: thread = (output dword column cq < 30, rows rq + 8k); outputs
     // x = tx0 + 4cq + i are columns 4cq + 4 + i of vs and need a[i+1] .. a[i+7] of a[k] = vs column 4cq + k
     typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));

@@ -376,6 +376,42 @@ def test_batch_size_changes_between_unsynced_calls(gpu, oracle, sizes):
             prev = r
 
 
+def test_empty_frames_inside_a_device_batch(gpu, oracle):
+    """ragged batches on the benchmarked path: featureless frames (0 keypoints) between textured ones, at the end of
+    a batch (an EMPTY frame is rolled into the next batch's previous-frame slot) and at its start -- every frame's
+    keypoints, descriptors and matches (against a possibly empty previous frame: no train tiles at all for the
+    matrix-core scan) must equal the oracle's"""
+    w, h, nf, B = 640, 480, 1000, 8
+    tex = frames_for(w, h, 2 * B, stream=63)
+    fr = tex.copy()
+    flat = np.full((h, w), 97, np.uint8)
+    ramp = np.tile(np.arange(w, dtype=np.uint32) * 255 // (w - 1), (h, 1)).astype(np.uint8)  # linear ramp: no FAST corner
+    for i, img in ((1, flat), (4, ramp), (5, flat), (7, flat), (8, ramp), (9, flat), (15, flat)):
+        fr[i] = img
+    gex = gpu_extractor(nf, w, h, B=B)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    ref = [oex(f) for f in fr]
+    assert [len(ref[i]["kps"]) for i in (1, 4, 5, 7, 8, 9, 15)] == [0] * 7 and len(ref[0]["kps"]) > 500
+    d0 = gex.upload_frames(fr[:B], stride=640)
+    d1 = gex.upload_frames(fr[B:], stride=640)
+    gex.reset_stream()
+    for b, d in enumerate((d0, d1)):
+        gex.extract_batch_device(*d)
+        gex.match_prev_batch_device(0.7, 50, True)
+        for f in range(B):
+            g = b * B + f
+            k, dsc = gex.download(f)
+            assert ref[g]["kps"].tobytes() == k.tobytes() and np.array_equal(ref[g]["desc"], dsc), "frame %d" % g
+            m, nm = gex.download_matches(f)
+            if g == 0:
+                continue  # first frame of the stream: no previous frame
+            p = ref[g - 1]
+            mr, nr = oracle.match_bruteforce(dsc, k["angle"], p["desc"], p["kps"]["angle"], 0.7, 50, True)
+            assert nm == nr and np.array_equal(m[:len(k)], mr), "frame %d matches" % g
+            if len(k) == 0 or len(p["kps"]) == 0:
+                assert nm == 0
+
+
 def test_soak_256_frames_bit_exact(gpu, oracle):
     """4 streams x 64 consecutive frames at the benchmark shape through the device-resident
     batch path: every keypoint record, descriptor byte and match index against the oracle
