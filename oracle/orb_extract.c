@@ -376,7 +376,10 @@ void orc_brief(const uint8_t* img, int stride, int x, int y, float angle_deg, ui
 {
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float angle = angle_deg * factorPI;
-    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    /* ref:65 `using namespace std;` + ref:113 `(float)cos(angle)` with a float argument: std::cos(float) = cosf
+       (g++ emits `call cosf`), NOT cos((double)angle) rounded -- the two differ for 0.135 % of the binary32 angles
+       in [0, 2pi] on glibc 2.35.  This step is libm-version dependent in the reference itself (orb_oracle.h F6). */
+    float a = cosf(angle), b = sinf(angle);
     const uint8_t* center = img + (size_t)y * stride + x;
     const int8_t* pat = k_pattern;
     for (int i = 0; i < 32; ++i, pat += 32) {

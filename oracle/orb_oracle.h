@@ -30,6 +30,13 @@
  *    heap pointer (ORBextractor.cc:684).  Oracle: tie -> node creation sequence
  *    number, ascending (so walking from the back expands the latest-created first).
  *  - floating point: strict IEEE binary32, no FMA contraction (-ffp-contract=off).
+ *  - F6 (corrects SURVEY.md F6, which read the step as "double libm, cast"): the steering angle's
+ *    `(float)cos(angle)`, `(float)sin(angle)` (ORBextractor.cc:113) take a FLOAT argument under the file-scope
+ *    `using namespace std;` (:65), so they are std::cos(float) = cosf / sinf.  orc_brief calls the HOST libm's
+ *    cosf/sinf: this step is libm-version dependent in the reference itself (glibc >= 2.28 rounds one binary64
+ *    polynomial; older glibc and other libms may differ in the last bit for some angles).  The product restates
+ *    glibc's algorithm (orbslamm_amd/csrc/orbx_sincosf.h); tests/cpp/sincos_check.c compares the two over every
+ *    binary32 angle in [0, 2pi].
  *  - levels whose FAST window is narrower/lower than 30 px (nCols or nRows == 0;
  *    float division by zero in the reference, :785-786) yield no keypoints.
  */

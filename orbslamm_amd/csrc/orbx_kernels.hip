@@ -1236,37 +1236,11 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
-// sin and cos of x in [0, 2pi] in binary64: Cody-Waite reduction by pi/2 (two constants, k <= 4) and the
-// fdlibm kernel polynomials on |r| <= pi/4, every operation a separately rounded IEEE op.  The reference
-// rounds cos((double)angle) / sin((double)angle) to float (ORBextractor.cc:112-113); tests/cpp/sincos_check.c
-// runs this very sequence against the host libm over EVERY binary32 argument in [0, 2pi] (1.09e9 values) and
-// finds the float results identical, so the third of the generic library routine's work is enough here.
-__device__ __forceinline__ double ksin_d(double x)
-{
-    const double z = __dmul_rn(x, x);
-    const double r = __dadd_rn(8.33333333332248946124e-03, __dmul_rn(z, __dadd_rn(-1.98412698298579493134e-04, __dmul_rn(z,
-                     __dadd_rn(2.75573137070700676789e-06, __dmul_rn(z, __dadd_rn(-2.50507602534068634195e-08, __dmul_rn(z, 1.58969099521155010221e-10))))))));
-    return __dadd_rn(x, __dmul_rn(__dmul_rn(x, z), __dadd_rn(-1.66666666666666324348e-01, __dmul_rn(z, r))));
-}
-__device__ __forceinline__ double kcos_d(double x)
-{
-    const double z = __dmul_rn(x, x);
-    const double r = __dmul_rn(z, __dadd_rn(4.16666666666666019037e-02, __dmul_rn(z, __dadd_rn(-1.38888888888741095749e-03, __dmul_rn(z,
-                     __dadd_rn(2.48015872894767294178e-05, __dmul_rn(z, __dadd_rn(-2.75573143513906633035e-07, __dmul_rn(z,
-                     __dadd_rn(2.08757232129817482790e-09, __dmul_rn(z, -1.13596475577881948265e-11)))))))))));
-    return __dsub_rn(1.0, __dsub_rn(__dmul_rn(0.5, z), __dmul_rn(z, r)));
-}
-__device__ __forceinline__ void sincos_0_2pi(double x, double& s, double& c)
-{
-    const int k = (int)__dadd_rn(__dmul_rn(x, 6.36619772367581382433e-01), 0.5);
-    const double kd = (double)k;
-    const double r = __dsub_rn(__dsub_rn(x, __dmul_rn(kd, 1.57079632673412561417e+00)), __dmul_rn(kd, 6.07710050650619224932e-11));
-    const double sr = ksin_d(r), cr = kcos_d(r);
-    s = (k & 1) ? cr : sr;
-    c = (k & 1) ? sr : cr;
-    if (k & 2) s = -s;
-    if ((k + 1) & 2) c = -c;
-}
+// sinf / cosf of the steering angle: the reference's `(float)cos(angle)` has a float argument under `using namespace
+// std` (ORBextractor.cc:65,112-113) = cosf.  orbx_sincosf.h restates glibc's sinf/cosf (one binary64 polynomial, rounded
+// once); tests/cpp/sincos_check.c runs the same text against the host libm over every binary32 angle in [0, 2pi].
+#define ORBX_HD __device__ __forceinline__
+#include "orbx_sincosf.h"
 
 constexpr int kKpPerBlock = 16;
 struct KpBlocks { int32_t base[ORBX_MAXL + 1]; };  // block index -> level (kKpPerBlock keypoints per block)
@@ -1447,9 +1421,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     // steered BRIEF on the blurred level
     constexpr float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
-    double sn, cs;
-    sincos_0_2pi((double)ang, sn, cs);
-    const float a = (float)cs, b = (float)sn;
+    float a, b;  // a = cosf(ang), b = sinf(ang)
+    orbx_sincosf_0_2pi(ang, &b, &a);
     OSTAMP();
     // The 512 sample points of a keypoint lie within radius 18.4 of it, inside the LDS patch (gathering the bytes
     // straight from memory costs one cache-line access per lane and test: the address rate of the vector-memory pipe).
