@@ -1,42 +1,133 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of ORB extract + match-vs-previous-frame on MI355X.
 
-Workload (BASELINE.json configs[2]/[3]): KITTI-shape 1241x376 uint8 mono frames,
-2000 features, 8 levels, scale 1.2, FAST 20/7; every frame is extracted and
-brute-force Hamming matched against the previous frame of its stream.  A "step" is
-one pass of the hot path over one batch of `--batch` (default 64) frames that are
-already resident in HBM.  One process per GPU; each rank owns an independent camera
-stream (MultipleRobotsScenario: one tracking thread per robot) -- no data-path
-collective; RCCL only gathers the match statistics after the timed region.
+Workload (BASELINE.json configs[2]/[3], `--config c3`, the default): KITTI-shape 1241x376 uint8 mono frames, 2000
+features, 8 levels, scale 1.2, FAST 20/7; every frame is extracted and brute-force Hamming matched against the previous
+frame of its stream.  `--config c2` is BASELINE.json configs[1] (640x480, 1000 features) with the same pipeline.
+A "step" is one pass of the hot path over one batch of `--batch` (default 64) frames that are already resident in HBM.
+The frames of consecutive steps are consecutive frames of the camera stream, drawn from a pool of `--pool` batches
+(default 16 = 1024 distinct frames, 0.5 GB: twice the 256 MiB Infinity Cache, so a step's input comes from HBM and not
+from a cache that a 64-frame loop would sit in).
+
+One process per GPU; each rank owns an independent camera stream (MultipleRobotsScenario: one tracking thread per
+robot, mono_kitti.cc:80-101) -- no data-path collective; RCCL only gathers the match statistics after the timed region.
+
+`python bench.py --gpus N` launches itself: without RANK/WORLD_SIZE in the environment and N > 1 it spawns N ranks
+(one per GPU, 127.0.0.1 rendezvous), relays rank 0's record and exits non-zero if any rank failed.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are the launcher's.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 _ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, _ROOT)
 
-W, H, NFEAT = 1241, 376, 2000
-STRIDE = 1280  # device rows are 64-byte aligned
+CONFIGS = {
+    # name: width, height, features, device row stride (64-byte aligned rows)
+    "c3": dict(w=1241, h=376, nfeat=2000, stride=1280,
+               metric="frames/s ORB extract+match, 1241x376 @2000 kp; bit-exact kp/desc vs CPU",
+               workload="KITTI-shape 1241x376 mono, 2000 features, 8 levels x1.2, FAST 20/7, extract + brute-force Hamming "
+                        "match vs previous frame (BASELINE.json configs[2]/[3])"),
+    "c2": dict(w=640, h=480, nfeat=1000, stride=640,
+               metric="frames/s ORB extract+match, 640x480 @1000 kp; bit-exact kp/desc vs CPU",
+               workload="TUM-shape 640x480 mono, 1000 features, 8 levels x1.2, FAST 20/7, extract + brute-force Hamming "
+                        "match vs previous frame (BASELINE.json configs[1])"),
+}
 HBM_PEAK_GBS = 8000.0
-DOMINANT = "k_fast"  # largest isolated time in every serialized replay so far (checked against the replay of each run)
+SIMDS = 1024  # 256 CUs x 4
+DOMINANT = "k_fast"  # bracketed inside the timed region; the serialized replay of every run re-derives the dominant kernel
 
 
-def algorithmic_bytes(ex, w, h, nfeat):
-    """staged dataflow, each stage reads its input once and writes
-    its output once.  Returns per-frame bytes per kernel and the total."""
-    from oracle import binding as ob  # only for level sizes of the documented figure
-    o = ob.Extractor(nfeat, 1.2, 8, 20, 7)
-    px = [a * b for a, b in (o.level_size(w, h, l) for l in range(8))]
-    S = sum(px)
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)   # 0.1 s timed: a 12 ms region (20 steps) is mostly pipeline ramp-up
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--pool", type=int, default=16, help="distinct batches of stream frames resident in HBM, cycled by the steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the (untimed) host-buffer entry measurements")
+    ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
+    ap.add_argument("--no-replay", action="store_true", help="skip the untimed serialized replay (roofline.isolated); used under rocprofv3 so that its per-kernel averages are those of the timed launches")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, timeout=None):
+    """Spawn n ranks of this script (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), relay rank 0's
+    stdout -- the one JSON record -- on ours, everything else on stderr.  Returns the exit code: 0 only if every rank
+    exited 0 and rank 0 printed exactly one line."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ORBX_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    t0 = time.time()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if timeout is not None and time.time() - t0 > timeout:
+            failed = -1
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        for p in procs:  # our own children, by PID
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: rank %s failed (exit codes %s)\n" % ("timeout" if failed < 0 else failed, [p.poll() for p in procs]))
+        return 1
+    out = procs[0].stdout.read().decode()
+    lines = [l for l in out.splitlines() if l.strip()]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d lines instead of one record\n%s\n" % (len(lines), out[:2000]))
+        return 1
+    rec = json.loads(lines[0])
+    if rec.get("n_gpus") != n:
+        sys.stderr.write("bench.py: record says n_gpus=%r, launched %d ranks\n" % (rec.get("n_gpus"), n))
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ reporting helpers
+def algorithmic_bytes(level_px, nfeat):
+    """staged dataflow, each stage reads its input once and writes its output once.
+    level_px: pixels of each pyramid level (from the product's own geometry).  Per-frame bytes per kernel + total."""
+    S = sum(level_px)
     per = {
-        "k_pyramid": (S - px[7]) + (S - px[0]),
+        "k_pyramid": (S - level_px[-1]) + (S - level_px[0]),
         "k_fast": S,
         "k_blur": 2 * S,
         "k_orient_desc": 749 * nfeat + 512 * nfeat + (32 + 28) * nfeat,
@@ -48,54 +139,166 @@ def algorithmic_bytes(ex, w, h, nfeat):
     return per, sum(per.values())
 
 
-def cpu_baseline(frames, seconds_budget=12.0, max_frames=320):
-    """The oracle (a port: kind="port") timed single-threaded on this host, on a bounded
-    sample of the same workload (the batch's frames, cycled)."""
+def _latest_profile(pattern):
+    """newest committed profiles/rNN_<pattern> (the PMC passes are separate rocprofv3 runs; bench.py replays their summary)"""
+    hits = sorted(glob.glob(os.path.join(_ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    return hits[-1] if hits else None
+
+
+def host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def cpu_baseline(cfg, frames, seconds_budget=12.0, max_frames=320, streams_n=8):
+    """The CPU checker (a port of the reference algorithm: kind="port") timed on this host, on a bounded sample of the
+    same workload: (i) ONE thread -- the reference extractor and matchers are single-threaded per stream
+    (Frame.cc:191); (ii) one thread per stream for min(streams_n, cores) streams -- the MultipleRobotsScenario layout."""
+    import threading
     from oracle import binding as ob
     try:
         so = ob.build(march_native=True, out_dir="/tmp")
         L = ob.lib(path=so)
     except Exception:
         L = ob.lib()
-    ex = ob.Extractor(NFEAT, 1.2, 8, 20, 7, L=L)
-    prev = None
+    W, H, NFEAT = cfg["w"], cfg["h"], cfg["nfeat"]
+
+    def run_stream(budget, out, idx):
+        ex = ob.Extractor(NFEAT, 1.2, 8, 20, 7, L=L)
+        prev = None
+        t0 = time.perf_counter()
+        n = 0
+        for f in range(max_frames):
+            r = ex(frames[(f + 7 * idx) % len(frames)])
+            if prev is not None:
+                ob.match_bruteforce(r["desc"], r["kps"]["angle"], prev["desc"], prev["kps"]["angle"], 0.7, 50, True, L=L)
+            prev = r
+            n += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        out[idx] = (n, time.perf_counter() - t0)
+
+    res = {}
+    run_stream(seconds_budget, res, 0)
+    n1, dt1 = res[0]
+    info = host_info()
+    nthr = max(1, min(streams_n, info["nproc"] or 1))
+    resn = {}
     t0 = time.perf_counter()
+    th = [threading.Thread(target=run_stream, args=(seconds_budget * 0.75, resn, i)) for i in range(nthr)]  # ctypes releases the GIL
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dtn = time.perf_counter() - t0
+    nn = sum(v[0] for v in resn.values())
+    return {"value": n1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic %dx%d frames (%.1f s), extract + brute-force match vs previous frame, 1 thread, gcc -O3 -march=native -ffp-contract=off" % (n1, W, H, dt1),
+            "one_thread_per_stream": {"value": nn / dtn, "unit": "frames/s", "cores": nthr, "streams": nthr,
+                                      "sample": "%d frames over %d threads (%.1f s wall)" % (nn, nthr, dtn)},
+            "nproc": info["nproc"], "cpu_model": info["cpu_model"]}
+
+
+def make_extractor(cfg, B, dev_index):
+    """the product's extractor -- or, for the CPU plumbing tests of the N > 1 path, the class named by
+    ORBX_BENCH_EXTRACTOR=module:Class (tests/bench_stub.py), which has the same methods and needs no GPU"""
+    spec = os.environ.get("ORBX_BENCH_EXTRACTOR")
+    if spec:
+        import importlib
+        mod, cls = spec.split(":")
+        return getattr(importlib.import_module(mod), cls)(cfg["nfeat"], 1.2, 8, 20, 7, max_width=cfg["w"], max_height=cfg["h"],
+                                                          max_batch=B, device=dev_index)
+    from orbslamm_amd import ORBextractor
+    return ORBextractor(cfg["nfeat"], 1.2, 8, 20, 7, max_width=cfg["w"], max_height=cfg["h"], max_batch=B, device=dev_index)
+
+
+def device_count():
+    if os.environ.get("ORBX_BENCH_EXTRACTOR"):
+        return int(os.environ.get("ORBX_BENCH_STUB_DEVICES", "1"))
+    from orbslamm_amd import _lib
+    return _lib.lib().orbx_device_count()
+
+
+def host_path(ex, cfg, frames, seconds=1.5):
+    """The host-buffer entries (never `value`): what a drop-in caller sees.
+    b1: Frame::ExtractORB's entry -- one pageable host frame per call (orbx_extract), keypoints + descriptors back on the
+        host, then match vs previous frame and the match table back on the host; per-frame wall time, reported as the
+        reference examples report theirs (median and mean, mono_tum.cc:113-122).
+    b64: orbx_extract_batch with 64 host frames per call, results on the host (PCIe-inclusive throughput)."""
+    import numpy as np
+    W, H = cfg["w"], cfg["h"]
+    out = {}
+    lat = []
+    ex.reset_stream()
+    t_end = time.perf_counter() + seconds
+    i = 0
+    while time.perf_counter() < t_end or len(lat) < 20:
+        f = frames[i % len(frames)]
+        t0 = time.perf_counter()
+        ex.extract_match_host(f[None])
+        lat.append(time.perf_counter() - t0)
+        i += 1
+    lat = np.array(lat[5:]) * 1e3
+    out.update(b1_ms_median=float(np.median(lat)), b1_ms_mean=float(lat.mean()), b1_frames=int(len(lat)),
+               b1_fps=float(1e3 / lat.mean()), b1_what="orbx_extract_match_batch, B=1: pageable host frame in, keypoints + descriptors + match table on the host, per call")
+    B = min(ex.max_batch, len(frames))
+    batch = frames[:B]
+    ex.reset_stream()
+    ex.extract_match_host(batch)
     n = 0
-    for f in range(max_frames):
-        r = ex(frames[f % len(frames)])
-        if prev is not None:
-            ob.match_bruteforce(r["desc"], r["kps"]["angle"], prev["desc"], prev["kps"]["angle"], 0.7, 50, True, L=L)
-        prev = r
-        n += 1
-        if time.perf_counter() - t0 > seconds_budget:
-            break
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        ex.extract_match_host(batch)
+        n += B
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic %dx%d frames (%.1f s), extract + brute-force match vs previous frame, 1 thread, gcc -O3 -march=native -ffp-contract=off" % (n, W, H, dt)}
+    out.update(b64_fps=n / dt, b64_batch=B, b64_what="orbx_extract_match_batch, B=%d host frames per call (synchronous), results on the host" % B)
+    # pipelined form: submit batch n+1 while batch n computes and batch n-1 downloads
+    if hasattr(ex, "submit_host"):
+        ex.reset_stream()
+        tickets = []
+        n = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            tickets.append(ex.submit_host(batch))
+            if len(tickets) > 2:
+                ex.collect_host(tickets.pop(0))
+            n += B
+        while tickets:
+            ex.collect_host(tickets.pop(0))
+        dt = time.perf_counter() - t0
+        out.update(pipelined_fps=n / dt, pipelined_what="orbx_submit_batch / orbx_collect_batch, depth 3, B=%d host frames per ticket, results on the host" % B,
+                   pcie_gbs=n / dt * (W * H + 0.0) / 1e9)
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)   # 0.12 s timed: a 12 ms region (20 steps) is mostly pipeline ramp-up
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
-    ap.add_argument("--no-replay", action="store_true", help="skip the untimed serialized replay (roofline.isolated); used under rocprofv3 so that its per-kernel averages are those of the timed launches")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import numpy as np
+    from orbslamm_amd import streams, synth
 
-    from orbslamm_amd import ORBextractor, streams, synth
-
+    cfg = CONFIGS[args.config]
+    W, H, NFEAT, STRIDE = cfg["w"], cfg["h"], cfg["nfeat"], cfg["stride"]
     rank, world, local_rank = streams.env_rank()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        return 2
     torch = None
     device = "cpu"
     force_dist = os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"  # world 1 through the N > 1 initialisation path
     distributed = world > 1 or force_dist
-    backend = os.environ.get("ORBX_DIST_BACKEND", "nccl")  # "gloo": plumbing test of N ranks on a 1-GPU box
-    from orbslamm_amd import _lib
-    dev_index = local_rank if backend == "nccl" or not distributed else local_rank % max(_lib.lib().orbx_device_count(), 1)
+    backend = os.environ.get("ORBX_DIST_BACKEND", "nccl")  # "gloo": plumbing test of N ranks on a box with fewer GPUs
+    ndev = device_count()
+    if backend == "nccl" and distributed and local_rank >= max(ndev, 1):
+        sys.stderr.write("bench.py: rank %d has no GPU of its own (%d visible); one process per GPU\n" % (rank, ndev))
+        return 2
+    dev_index = streams.device_of_rank(local_rank, ndev, exclusive=(backend == "nccl" or not distributed or os.environ.get("ORBX_DIST_EXCLUSIVE") == "1"))
 
     # stdout carries exactly ONE line, the JSON record.  librccl prints a version banner to fd 1 when its first
     # communicator comes up (and C stdio flushes it at exit, i.e. AFTER anything Python printed), so in a
@@ -112,32 +315,44 @@ def main():
     # frames/s, tools/dist_order.sh) -- which the driver would read as 0.82 scaling efficiency of a path that has no
     # data-path collective.
     B = args.batch
-    frames = synth.make_frames(W, H, B, stream=streams.stream_of_rank(rank)[0])  # this rank's camera stream
-    ex = ORBextractor(NFEAT, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=dev_index)
-    dargs = ex.upload_frames(frames, stride=STRIDE)  # frames resident in HBM before the timed region
+    stream_id = streams.stream_of_rank(rank)[0]  # this rank's camera stream
+    pool = max(1, args.pool)
+    ex = make_extractor(cfg, B, dev_index)
+    canvas = synth.make_scene(W, H, stream_id)
+    dargs = []
+    first_batch = None
+    for p in range(pool):  # frames t = p*B .. p*B+B-1 of the stream, resident in HBM before the timed region
+        fr = np.stack([synth.frame_from_scene(canvas, W, H, p * B + t, stream_id) for t in range(B)])
+        if p == 0:
+            first_batch = fr
+        dargs.append(ex.upload_frames(fr, stride=STRIDE))
+    del fr
 
     if distributed:
-        # torch only for torch.distributed (backend "nccl" = RCCL over xGMI); a 1-GPU run
-        # needs no torch at all (its first import on a cold box can take minutes)
+        # torch only for torch.distributed (backend "nccl" = RCCL over xGMI); a 1-GPU run needs no torch at all
+        # (its first import on a cold box can take minutes)
         import torch
-        torch.cuda.set_device(dev_index)
         if backend == "nccl":
+            torch.cuda.set_device(dev_index)
             device = torch.device("cuda", dev_index)
         streams.init(backend, device if backend == "nccl" else None)
+        import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus, "the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
 
     SAMPLE = 4  # in the timed region the dominant kernel's launches are bracketed in one step out of SAMPLE
-    state = {"i": 0, "sample": False}
+    state = {"i": 0, "sample": False, "n": 0}
 
     def step():
         if state["sample"]:
             ex.profile_enable(state["i"] % SAMPLE == 0)
             state["i"] += 1
-        ex.extract_batch_device(*dargs)
+        ex.extract_batch_device(*dargs[state["n"] % pool])
         ex.match_prev_batch_device(0.7, 50, True)
+        state["n"] += 1
 
     def sync():
         ex.sync()  # orbx_sync: every stream of the handle (all GPU work of this process hangs off it)
-        if torch is not None:
+        if torch is not None and backend == "nccl":
             torch.cuda.synchronize()
 
     import gc
@@ -190,17 +405,23 @@ def main():
 
     if rank == 0:
         fps, total_frames = streams.aggregate(gathered, dt_max)
-        per, bytes_frame = algorithmic_bytes(ex, W, H, NFEAT)
+        level_px = [a * b for a, b in ex.level_sizes()]
+        per, bytes_frame = algorithmic_bytes(level_px, NFEAT)
         out = {
-            "metric": "frames/s ORB extract+match, 1241x376 @2000 kp; bit-exact kp/desc vs CPU",
+            "metric": cfg["metric"],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "KITTI-shape 1241x376 mono, 2000 features, 8 levels x1.2, FAST 20/7, extract + brute-force Hamming match vs previous frame (BASELINE.json configs[2]/[3])",
-                       "frames_per_step_per_gpu": B, "streams": world, "parallelism": "1 independent stream per GPU"},
+            "config": {"workload": cfg["workload"], "name": args.config,
+                       "frames_per_step_per_gpu": B, "streams": world, "parallelism": "1 independent stream per GPU",
+                       "resident_pool_frames_per_gpu": pool * B, "resident_pool_mb_per_gpu": pool * B * STRIDE * H / 1e6},
             "keypoints_last_frame": [int(g[1]) for g in gathered],
             "matches_last_frame": [int(g[2]) for g in gathered],
         }
+        traffic_src = _latest_profile("pmc_traffic.json")
+        sq_src = _latest_profile("pmc_sq.json")
+        traffic_tab = json.load(open(traffic_src)) if traffic_src else {}
+        sq_tab = json.load(open(sq_src)) if sq_src else {}
 
         def roofline_of(prof, dom=None, nsteps=args.steps):
             kern = {k: v for k, v in prof.items() if v[1] > 0 and k.startswith("k_")}
@@ -210,16 +431,28 @@ def main():
             frames_per_launch = B * nsteps / kern[dom][1]
             alg_launch = per.get(dom, 0) * frames_per_launch
             achieved = alg_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            try:  # PMC pass (separate rocprofv3 --pmc runs), KB per 64-frame launch as reported
-                t = json.load(open(os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")))[dom]
-                traffic = (t["fetch_kb"] * t.get("fetch_scale", 1.0) + t["write_kb"]) * 1024.0 * frames_per_launch / t["frames_per_launch"]
-            except Exception:
-                pass
-            return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
-                    "frames_per_launch": frames_per_launch, "algorithmic_bytes_per_launch": alg_launch,
-                    "launches_bracketed": int(kern[dom][1]), "kernel_ms_per_step": {k: v[0] / nsteps for k, v in kern.items()}}
+            r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                 "frames_per_launch": frames_per_launch, "algorithmic_bytes_per_launch": alg_launch,
+                 "launches_bracketed": int(kern[dom][1]), "kernel_ms_per_step": {k: v[0] / nsteps for k, v in kern.items()}}
+            t = traffic_tab.get(dom) if args.config == "c3" else None
+            if t:  # PMC pass (separate rocprofv3 --pmc runs, not this run), KB per 64-frame step as reported
+                r["traffic"] = (t["fetch_kb"] * t.get("fetch_scale", 1.0) + t["write_kb"]) * 1024.0 * frames_per_launch / t["frames_per_launch"]
+                r["traffic_source"] = os.path.relpath(traffic_src, _ROOT) + " (replayed: FETCH_SIZE/WRITE_SIZE passes of an earlier run of this command)"
+            q = sq_tab.get("kernels", {}).get(dom) if args.config == "c3" else None
+            if q:
+                # the yardstick for an issue-bound kernel: VALU wave-instructions x measured cycles per instruction over the
+                # SIMD-cycles the launch had: (1024 SIMDs x clock x time).  Counts from the SQ_* passes (per 64-frame step).
+                cyc = sq_tab["cycles_per_valu_instr"]
+                clk = sq_tab["clock_ghz"] * 1e9
+                winstr = q["valu"] * frames_per_launch / sq_tab["frames_per_step"]
+                r["issue"] = {"valu_wave_instr_per_launch": winstr, "cycles_per_instr": cyc, "clock_ghz": sq_tab["clock_ghz"], "simds": SIMDS,
+                              "frac": winstr * cyc / (SIMDS * clk * avg_ms * 1e-3),
+                              "salu_wave_instr_per_launch": q.get("salu", 0) * frames_per_launch / sq_tab["frames_per_step"],
+                              "lds_wave_instr_per_launch": q.get("lds", 0) * frames_per_launch / sq_tab["frames_per_step"],
+                              "lds_bank_conflict_cycles_per_launch": q.get("lds_bank_conflict", 0) * frames_per_launch / sq_tab["frames_per_step"],
+                              "source": os.path.relpath(sq_src, _ROOT) + " (replayed: SQ_INSTS_* passes, kernels alone on the GPU)"}
+            return r
 
         if prof_serial:
             # the dominant kernel is picked where kernels run alone; its figure inside the timed
@@ -230,15 +463,21 @@ def main():
             out["roofline"]["measured_in_timed_region"] = timed is prof
             out["roofline"]["kernel_ms_per_step_all_bracketed"] = {k: v[0] / args.steps for k, v in prof_all.items() if v[1] > 0 and k.startswith("k_")}
             out["roofline"]["overlapped_streams"] = True
-            out["roofline"]["isolated"] = {k: iso[k] for k in ("achieved", "frac", "avg_launch_ms", "frames_per_launch", "kernel_ms_per_step")}
+            out["roofline"]["isolated"] = {k: iso[k] for k in ("achieved", "frac", "avg_launch_ms", "frames_per_launch", "kernel_ms_per_step", "issue") if k in iso}
             out["roofline"]["pipeline_bytes_per_frame"] = bytes_frame
             out["roofline"]["pipeline_achieved_GBs"] = fps / world * bytes_frame / 1e9
             out["roofline"]["pipeline_frac"] = fps / world * bytes_frame / 1e9 / HBM_PEAK_GBS
+            if sq_tab and args.config == "c3":
+                cyc, clk = sq_tab["cycles_per_valu_instr"], sq_tab["clock_ghz"] * 1e9
+                tot = sum(v["valu"] for v in sq_tab["kernels"].values()) * B / sq_tab["frames_per_step"]
+                out["roofline"]["pipeline_issue_frac"] = tot * cyc / (SIMDS * clk * dt_max / args.steps)
         elif prof:
             out["roofline"] = roofline_of(prof, DOMINANT, steps_bracketed)  # --no-replay: the kernel named by the isolated runs so far
             out["roofline"]["overlapped_streams"] = True
+        if world == 1 and not args.no_host_path and hasattr(ex, "extract_match_host"):
+            out["host_path"] = host_path(ex, cfg, first_batch)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames)
+            out["cpu_baseline"] = cpu_baseline(cfg, first_batch)
         line = json.dumps(out) + "\n"
         if json_fd is not None:
             os.write(json_fd, line.encode())
@@ -246,7 +485,16 @@ def main():
             sys.stdout.write(line)
             sys.stdout.flush()
     streams.finalize(world)
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -164,6 +164,15 @@ class ORBextractor:
         check(self._L.orbx_pyramid_level(self._h, int(frame), int(level), int(blurred), ptr(out), C.byref(w), C.byref(h)))
         return out
 
+    def level_sizes(self):
+        """(width, height) of every pyramid level of the last extracted shape (ORBextractor.cc:1111-1112)"""
+        out = []
+        for l in range(self.GetLevels()):
+            w, h = C.c_int(), C.c_int()
+            check(self._L.orbx_pyramid_level(self._h, 0, l, 0, None, C.byref(w), C.byref(h)))
+            out.append((w.value, h.value))
+        return out
+
     def level_candidates(self, frame, level):
         n = C.c_int()
         check(self._L.orbx_level_candidates(self._h, int(frame), int(level), None, 0, C.byref(n)))

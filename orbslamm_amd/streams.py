@@ -39,6 +39,16 @@ def stream_of_rank(rank, streams_per_rank=1):
     return [rank * streams_per_rank + i for i in range(streams_per_rank)]
 
 
+def device_of_rank(local_rank, ndev, exclusive=True):
+    """GPU of a rank: one process per GPU (stream s -> GPU s mod 8).  exclusive=False is the plumbing mode
+    of the tests (more ranks than GPUs, backend gloo): ranks wrap around the visible devices."""
+    if exclusive:
+        if ndev > 0 and local_rank >= ndev:
+            raise ValueError("rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
+        return local_rank
+    return local_rank % max(ndev, 1)
+
+
 def barrier(world):
     if world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
@@ -61,11 +71,11 @@ def timed_region(step, steps, sync, world):
 
 def gather_stats(stats, world, device="cpu"):
     """all_gather of the per-rank record (STATS_FIELDS) and MAX of the elapsed time"""
+    if world == 1:  # no torch in a single-process run
+        return [[float(v) for v in stats]], float(stats[3])
     import torch
-    t = torch.tensor([float(v) for v in stats], dtype=torch.float64, device=device)
-    if world == 1:
-        return [t.cpu().tolist()], float(stats[3])
     import torch.distributed as dist
+    t = torch.tensor([float(v) for v in stats], dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     tmax = t[3:4].clone()

@@ -23,7 +23,8 @@ def run_bench(extra_env, extra_args=()):
     env = dict(os.environ)
     env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29537", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     env.update(extra_env)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-replay"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-replay",
+           "--no-host-path", "--pool", "2"]
     return subprocess.run(cmd + list(extra_args), capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
 
 
@@ -46,3 +47,52 @@ def test_stdout_is_one_json_record(gpu, mode):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     if mode == "rccl_world1":
         assert "RCCL version" not in out.stdout  # the banner belongs on stderr
+
+
+def _plain_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+@pytest.mark.timeout(900)
+def test_self_launch_one_rank_per_visible_gpu(gpu):
+    """`python3 bench.py --gpus N` the way the driver invokes it (no RANK/WORLD_SIZE), N = every visible GPU: bench.py
+    launches its own ranks over RCCL.  On a 1-GPU box this is the plain single-process run."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpu), "--steps", "20", "--warmup", "2",
+           "--no-cpu-baseline", "--no-replay", "--no-host-path", "--pool", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=_plain_env(), cwd=ROOT, timeout=850)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == gpu and len(rec["keypoints_last_frame"]) == gpu
+    assert all(k > 1000 for k in rec["keypoints_last_frame"]) and all(m > 100 for m in rec["matches_last_frame"])
+    if gpu > 1:  # independent streams: different scenes, different counts
+        assert len(set(rec["matches_last_frame"])) > 1
+
+
+@pytest.mark.timeout(900)
+def test_self_launch_two_ranks_real_extractor(gpu):
+    """two self-launched ranks with the real extractor.  With >= 2 GPUs: one each over RCCL.  On a 1-GPU box: the
+    plumbing mode (gloo, both ranks on GPU 0) -- the process layout, the stream -> rank map and the single record are
+    the real ones, only the device is shared (so the figure is not a scaling number and is not used as one)."""
+    env = _plain_env()
+    if gpu < 2:
+        env["ORBX_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+           "--no-cpu-baseline", "--no-replay", "--no-host-path", "--pool", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=850)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:400]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["streams"] == 2
+    kp, nm = rec["keypoints_last_frame"], rec["matches_last_frame"]
+    assert len(kp) == 2 and min(kp) > 1000 and min(nm) > 100 and (kp[0], nm[0]) != (kp[1], nm[1])  # two different camera streams
+
+
+@pytest.mark.timeout(600)
+def test_c2_config_has_a_bench_line(gpu):
+    out = run_bench({}, ["--config", "c2"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout)
+    assert "640x480" in rec["metric"] and rec["config"]["name"] == "c2" and rec["keypoints_last_frame"][0] > 500
