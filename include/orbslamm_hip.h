@@ -90,9 +90,54 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int w, int h_, int stride,
                  OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
 
 /* Batched form: B independent frames of identical shape, host memory.
- * kps[B*cap], desc[B*cap*32], n_out[B]. */
+ * kps[B*cap], desc[B*cap*32], n_out[B].  Synchronous: = orbx_submit_batch + orbx_collect_batch. */
 int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int h_, int stride,
                        OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* ---- pipelined host-buffer entry --------------------------------------------------------------------------------
+ * What a multi-robot front-end does with Frame::ExtractORB (src/Frame.cc:247-253) + the match against the previous
+ * frame: up to three batches of one stream in flight, the upload of batch n+1 and the download of batch n-1 running
+ * (on two copy streams) beside the kernels of batch n.  Tickets are collected in submission order.
+ *   - frames in memory from orbx_host_alloc_frames (pinned, rows 64-byte aligned: the device layout) are read by the
+ *     DMA engine in place; other pinned / registered memory (orbx_host_register) goes through a strided DMA;
+ *     pageable frames are first copied to the handle's pinned staging (row bands over a few threads).
+ *     The caller must not touch the frames of a ticket before it has been collected.
+ *   - match_prev: every frame is also matched against the previous frame of the stream (rule of
+ *     orbx_match_prev_batch_device) and the match tables come back with the batch. */
+typedef struct {
+    int32_t match_prev;   /* != 0: match vs the previous frame of the stream */
+    float nnratio;        /* 0.7 */
+    int32_t th_low;       /* TH_LOW = 50 */
+    int32_t check_ori;
+} OrbxStreamOpts;
+/* results of one ticket in handle-owned pinned host memory, valid until orbx_release(ticket) */
+typedef struct {
+    int32_t B, cap;
+    const int32_t* n;         /* [B] keypoints per frame */
+    const OrbxKeyPoint* kps;  /* [B][cap] */
+    const uint8_t* desc;      /* [B][cap][32] */
+    const int32_t* match;     /* [B][cap] index into the previous frame or -1; NULL without match_prev */
+    const int32_t* nmatch;    /* [B] */
+} OrbxBatchView;
+int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int h_, int stride,
+                      const OrbxStreamOpts* opts /* may be NULL: extract only */, int* ticket);
+/* waits for the ticket; zero-copy view of its results */
+int orbx_collect_view(orbx_t* h, int ticket, OrbxBatchView* view);
+int orbx_release(orbx_t* h, int ticket);
+/* waits, copies the exact n entries per frame to the caller's arrays (kps[B*cap], desc[B*cap*32], match[B*cap];
+ * NULL pointers are skipped) and releases the ticket */
+int orbx_collect_batch(orbx_t* h, int ticket, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out,
+                       int32_t* match, int* nmatch);
+/* synchronous form of the pair above (the per-frame drop-in entry when B = 1) */
+int orbx_extract_match_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int h_, int stride,
+                             const OrbxStreamOpts* opts, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out,
+                             int32_t* match, int* nmatch);
+/* pinned host frames in the device layout (a cv::Mat can wrap them: cv::Mat(h, w, CV_8UC1, ptr, stride)) */
+int orbx_host_alloc_frames(orbx_t* h, int B, int w, int h_, uint8_t** frames, int* stride, size_t* pitch);
+int orbx_host_free(orbx_t* h, void* p);
+/* pin caller-owned frame memory (e.g. a capture ring buffer) for in-place DMA */
+int orbx_host_register(orbx_t* h, void* p, size_t bytes);
+int orbx_host_unregister(orbx_t* h, void* p);
 
 /* Device-resident form: frames already in HBM (d_imgs + f*frame_pitch, rows `stride`
  * bytes apart; base, stride and frame_pitch must be multiples of 4).  Results stay

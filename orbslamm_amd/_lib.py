@@ -34,6 +34,15 @@ class OrbxProfile(C.Structure):
                 ("launches", C.c_int64 * ORBX_PROF_MAX)]
 
 
+class OrbxStreamOpts(C.Structure):
+    _fields_ = [("match_prev", C.c_int32), ("nnratio", C.c_float), ("th_low", C.c_int32), ("check_ori", C.c_int32)]
+
+
+class OrbxBatchView(C.Structure):
+    _fields_ = [("B", C.c_int32), ("cap", C.c_int32), ("n", C.c_void_p), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("match", C.c_void_p), ("nmatch", C.c_void_p)]
+
+
 class OrbmFeatVec(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("start", C.c_void_p), ("idx", C.c_void_p)]
 
@@ -51,7 +60,8 @@ class OrbmProjParams(C.Structure):
 EXPORTS = [
     "orbx_last_error", "orbx_device_count", "orbx_create", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
     "orbx_scale_tables", "orbx_features_per_level", "orbx_umax", "orbx_max_keypoints", "orbx_extract",
-    "orbx_extract_batch", "orbx_extract_batch_device", "orbx_device_results", "orbx_download",
+    "orbx_extract_batch", "orbx_submit_batch", "orbx_collect_view", "orbx_release", "orbx_collect_batch", "orbx_extract_match_batch",
+    "orbx_host_alloc_frames", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_device_results", "orbx_download",
     "orbx_pyramid_level", "orbx_level_candidates", "orbx_sync", "orbx_device_alloc", "orbx_device_free", "orbx_upload", "orbx_match_prev_batch_device",
     "orbx_device_matches", "orbx_download_matches", "orbx_reset_stream", "orbx_set_serial", "orbx_profile_enable",
     "orbx_profile_read", "orbx_profile_select", "orbm_create", "orbm_destroy", "orbm_distance_matrix", "orbm_match_bruteforce",

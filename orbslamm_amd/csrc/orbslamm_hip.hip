@@ -14,7 +14,12 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbslamm_hip.h"
@@ -114,6 +119,73 @@ struct Profiler {
     }
 };
 
+// ------------------------------------------------------------------ host-side helpers of the host-buffer entries
+// A few persistent threads for the bulk memcpys of the host path (pageable frames -> pinned staging, pinned results ->
+// caller arrays): 30 MB per 64-frame batch is 3 ms on one core, which alone would cap the path at 20 k frames/s.
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cvWork, cvDone;
+    std::function<void(int)> job;
+    int nItems = 0, next = 0, pending = 0;
+    uint64_t gen = 0;
+    bool quit = false;
+    void start(int n)
+    {
+        for (int i = 0; i < n; i++)
+            th.emplace_back([this] {
+                uint64_t seen = 0;
+                std::unique_lock<std::mutex> lk(m);
+                for (;;) {
+                    cvWork.wait(lk, [&] { return quit || (gen != seen && next < nItems); });
+                    if (quit) return;
+                    while (next < nItems) {
+                        const int i = next++;
+                        lk.unlock();
+                        job(i);
+                        lk.lock();
+                        if (--pending == 0) cvDone.notify_all();
+                    }
+                    seen = gen;
+                }
+            });
+    }
+    // run f(0) .. f(n-1), the caller takes part
+    void run(int n, const std::function<void(int)>& f)
+    {
+        if (th.empty() || n <= 1) { for (int i = 0; i < n; i++) f(i); return; }
+        std::unique_lock<std::mutex> lk(m);
+        job = f; nItems = n; next = 0; pending = n; gen++;
+        cvWork.notify_all();
+        while (next < nItems) {
+            const int i = next++;
+            lk.unlock();
+            f(i);
+            lk.lock();
+            --pending;
+        }
+        cvDone.wait(lk, [&] { return pending == 0; });
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cvWork.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+    }
+};
+
+// One batch in flight through the host-buffer entries (orbx_submit_batch .. orbx_release)
+struct HostSlot {
+    uint8_t* h_in = nullptr;    // pinned staging for pageable caller frames
+    uint8_t* d_in = nullptr;    // the batch's frames in HBM (rows 64-byte aligned)
+    uint8_t* h_out = nullptr;   // pinned results: [err | n[B] | nmatch[B] | kps[B][maxKp] | desc[B][maxKp][32] | match[B][maxKp]]
+    hipEvent_t evUp = nullptr, evOut = nullptr;
+    int state = 0;              // 0 free, 1 in flight, 2 collected (a view is out)
+    int ticket = -1, B = 0;
+    bool matched = false;
+};
+
 // ------------------------------------------------------------------ handle
 struct orbx_handle {
     OrbxParams prm;
@@ -159,7 +231,7 @@ struct orbx_handle {
     Cell* d_cells = nullptr; size_t cellsCap = 0;
     short4* d_tabs = nullptr; size_t tabsCap = 0;
     ResizeTabs tabs;
-    uint8_t* d_img = nullptr; size_t imgFrameBytes = 0; int imgStride = 0;  // staging for host frames
+    size_t imgFrameBytes = 0; int imgStride = 0;  // one frame of the host path's device staging (HostSlot::d_in)
     uint8_t* d_pyr = nullptr; size_t pyrCapFrame = 0;
     uint8_t* d_blur = nullptr; size_t blurCapFrame = 0;
     uint64_t* d_candRaw = nullptr; uint64_t* d_candA = nullptr; uint64_t* d_candB = nullptr; size_t candCapFrame = 0;
@@ -173,14 +245,23 @@ struct orbx_handle {
     OrbxKeyPointDev* d_kps = nullptr;    // [maxB+1][maxKp]  slot 0 = previous frame of the stream
     uint8_t* d_desc = nullptr;           // [maxB+1][maxKp][32]
     int32_t* d_count = nullptr;          // [maxB+1]
-    int32_t* d_match = nullptr;          // [maxB][maxKp]
+    int32_t* d_match = nullptr;          // [2][maxB][maxKp]  one table per result set
     uint8_t* d_binOf = nullptr;          // [maxB][maxKp]
     int32_t* d_hist = nullptr;           // [maxB][32]
-    int32_t* d_nmatch = nullptr;         // [maxB]
+    int32_t* d_nmatch = nullptr;         // [2][maxB]
     uint2* d_partial = nullptr;          // [maxB][kMatchChunks][maxKp] chunk partials of the brute-force scan
     uint8_t* d_xdesc = nullptr;          // [maxB + 1] slots of +-1 byte descriptors in MFMA tile order (k_expand_desc)
     int64_t xPitch = 0;
-    uint8_t* h_pinned = nullptr; size_t pinnedBytes = 0;
+    // host-buffer entries: kSlots batches in flight (upload of n+1 | kernels of n | download of n-1), allocated at first use
+    static constexpr int kSlots = 3;
+    HostSlot slot[kSlots];
+    bool slotsReady = false;
+    int nextTicket = 0;
+    size_t outOffN = 0, outOffNm = 0, outOffKp = 0, outOffDesc = 0, outOffMatch = 0, outBytes = 0;
+    hipStream_t streamUp = nullptr, streamDown = nullptr;  // copies only (SDMA): never a kernel
+    hipEvent_t evOutOfSet[2] = {nullptr, nullptr};         // the download that last read result set s
+    CopyPool pool;
+    int matchSet = 0;                    // result set the last matching wrote (d_match / d_nmatch half)
     int lastB = 0;
     FrameSrc lastSrc{};
     bool havePrev = false;
@@ -478,11 +559,22 @@ static void free_device(orbx_handle* h)
     }
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     h->prof.destroy();
-    void* ptrs[] = {h->d_distScratch, h->d_pyrRanges, h->d_geom, h->d_cells, h->d_tabs, h->d_img, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
+    void* ptrs[] = {h->d_distScratch, h->d_pyrRanges, h->d_geom, h->d_cells, h->d_tabs, h->d_pyr, h->d_blur, h->d_candRaw, h->d_candA, h->d_candB,
                     h->d_candCount, h->d_cellCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
                     h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial, h->d_xdesc};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    h->pool.stop();
+    if (h->streamUp) (void)hipStreamSynchronize(h->streamUp);
+    if (h->streamDown) (void)hipStreamSynchronize(h->streamDown);
+    for (auto& sl : h->slot) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.evUp) (void)hipEventDestroy(sl.evUp);
+        if (sl.evOut) (void)hipEventDestroy(sl.evOut);
+    }
+    if (h->streamUp) (void)hipStreamDestroy(h->streamUp);
+    if (h->streamDown) (void)hipStreamDestroy(h->streamDown);
     for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
         if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]);
         if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]);
@@ -564,7 +656,6 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_tabs, h->tabsCap * sizeof(short4)));
     h->pyrRangesCap = 64 * ORBX_MAXL;
     CRT(hipMalloc(&h->d_pyrRanges, h->pyrRangesCap * sizeof(PyrRange)));
-    CRT(hipMalloc(&h->d_img, h->imgFrameBytes * B));
     CRT(hipMalloc(&h->d_pyr, h->pyrCapFrame * B));
     CRT(hipMalloc(&h->d_blur, h->blurCapFrame * B));
     CRT(hipMalloc(&h->d_candRaw, h->candCapFrame * B * sizeof(uint64_t)));
@@ -578,10 +669,10 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_kps, 2 * (B + 1) * h->maxKp * sizeof(OrbxKeyPointDev)));
     CRT(hipMalloc(&h->d_desc, 2 * (B + 1) * (size_t)h->maxKp * 32));
     CRT(hipMalloc(&h->d_count, 2 * (B + 1) * sizeof(int32_t)));
-    CRT(hipMalloc(&h->d_match, B * h->maxKp * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_match, 2 * B * h->maxKp * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_binOf, B * (size_t)h->maxKp));
     CRT(hipMalloc(&h->d_hist, B * 32 * sizeof(int32_t)));
-    CRT(hipMalloc(&h->d_nmatch, B * sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_nmatch, 2 * B * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_partial, B * kMatchChunks * h->maxKp * sizeof(uint2)));
     h->xPitch = (int64_t)align_up(h->maxKp, orbm::kMfmaRowsPerBlock) * 256;
     CRT(hipMalloc(&h->d_xdesc, 2 * (B + 1) * (size_t)h->xPitch));
@@ -589,9 +680,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMemset(h->d_err, 0, sizeof(int32_t)));
     CRT(hipMemset(h->d_count, 0, 2 * (B + 1) * sizeof(int32_t)));
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
-    CRT(hipMemset(h->d_nmatch, 0, B * sizeof(int32_t)));
-    h->pinnedBytes = std::max(h->imgFrameBytes * B, B * (size_t)h->maxKp * (sizeof(OrbxKeyPointDev) + 32) + B * 4 + 4096);
-    CRT(hipHostMalloc(&h->h_pinned, h->pinnedBytes));
+    CRT(hipMemset(h->d_nmatch, 0, 2 * B * sizeof(int32_t)));
 #undef CRT
     *out = h;
     return ORBX_OK;
@@ -654,7 +743,10 @@ static int sync_all(orbx_handle* h)
         if (h->streamB[i]) HIPCHK(hipStreamSynchronize(h->streamB[i]));
     }
     HIPCHK(hipStreamSynchronize(h->stream3));
+    if (h->streamUp) HIPCHK(hipStreamSynchronize(h->streamUp));
+    if (h->streamDown) HIPCHK(hipStreamSynchronize(h->streamDown));
     h->matchPending[0] = h->matchPending[1] = false;
+    h->evOutOfSet[0] = h->evOutOfSet[1] = nullptr;
     return ORBX_OK;
 }
 
@@ -741,7 +833,7 @@ static int join_parts(orbx_handle* h, hipStream_t s)
 // The batch is cut into kSplit sub-batches that run on separate stream groups: the
 // latency-bound kernels of one sub-batch (quadtree, descriptors) overlap the
 // throughput-bound ones (FAST, matching) of the other.
-static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int hh, int stride, size_t pitch)
+static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int hh, int stride, size_t pitch, hipEvent_t evUploaded = nullptr)
 {
     int rc = configure_shape(h, w, hh);
     if (rc) return rc;
@@ -758,6 +850,7 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     // Sub-batch p owns stream streamP[p] across calls: it follows its own previous work (its frames' scratch
     // buffers) and the upload on the host-facing stream, nothing else -- the next batch's pyramid of sub-batch 0
     // starts while this batch's sub-batch 1 is still in its quadtree.  Consumers join through evPart (join_parts).
+    if (evUploaded) HIPCHK(hipStreamWaitEvent(s0, evUploaded, 0));  // host path: the frames arrive on the copy stream
     if (!h->serial) HIPCHK(hipEventRecord(h->evStart, s0));
     // A frame's scratch (pyramid and blur levels, candidate segments, kept records) is ordered between two calls by
     // the stream of the sub-batch that owns the frame.  When the batch size -- and with it the frame -> sub-batch
@@ -847,6 +940,7 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
         HIPCHK(hipStreamWaitEvent(s, h->evBlur[part], 0));
         // the output slots are still being read by the previous batch's matching on stream3
         if (h->matchPending[set]) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set], 0));  // the matching two batches back read this set
+        if (h->evOutOfSet[set]) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));  // ... and so did its download (host path)
         h->prof.begin(P_ORIENT_DESC, s);
         hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, xcd_grid_y(nb)), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
                            h->d_keptCount, r_kps(h, set) + h->maxKp, r_desc(h, set) + (size_t)h->maxKp * 32, r_count(h, set) + 1, nb);
@@ -937,6 +1031,251 @@ extern "C" int orbx_download(orbx_t* h, int frame, OrbxKeyPoint* kps, uint8_t* d
     return ORBX_OK;
 }
 
+// ------------------------------------------------------------------ host-buffer entries
+// Frame::ExtractORB (src/Frame.cc:247-253) hands the extractor a host image and gets host vectors back.  Behind that
+// boundary a batch goes through three stages that overlap across batches: upload on a copy stream | kernels | download
+// on a second copy stream; a batch owns one HostSlot from orbx_submit_batch to orbx_release.
+static int ensure_slots(orbx_handle* h)
+{
+    if (h->slotsReady) return ORBX_OK;
+    const size_t B = (size_t)h->maxB;
+    size_t o = 64;                                                    // [0]: the device error flag
+    h->outOffN = o; o += align_up((int)(B * 4), 64);
+    h->outOffNm = o; o += align_up((int)(B * 4), 64);
+    h->outOffKp = o; o += B * h->maxKp * sizeof(OrbxKeyPointDev); o = (o + 63) & ~(size_t)63;
+    h->outOffDesc = o; o += B * (size_t)h->maxKp * 32;
+    h->outOffMatch = o; o += B * (size_t)h->maxKp * 4;
+    h->outBytes = o;
+    HIPCHK(hipStreamCreateWithFlags(&h->streamUp, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->streamDown, hipStreamNonBlocking));
+    for (auto& sl : h->slot) {
+        HIPCHK(hipHostMalloc(&sl.h_in, h->imgFrameBytes * B));
+        HIPCHK(hipHostMalloc(&sl.h_out, h->outBytes));
+        HIPCHK(hipMalloc(&sl.d_in, h->imgFrameBytes * B));
+        HIPCHK(hipEventCreateWithFlags(&sl.evUp, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
+    }
+    const unsigned hc = std::thread::hardware_concurrency();
+    int nth = hc > 8 ? 6 : (hc > 2 ? (int)hc / 2 : 0);
+    if (const char* e = getenv("ORBX_COPY_THREADS")) nth = atoi(e);
+    if (nth > 0) h->pool.start(std::min(nth, 16));
+    h->slotsReady = true;
+    return ORBX_OK;
+}
+
+// memory the DMA engines can read in place: hipHostMalloc'ed or hipHostRegister'ed (orbx_host_alloc_frames / orbx_host_register)
+static bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" int orbx_host_alloc_frames(orbx_t* h, int B, int w, int hh, uint8_t** frames, int* stride, size_t* pitch)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!frames || B < 1 || w < 1 || hh < 1) return fail(ORBX_E_INVALID, "bad argument");
+    const int st = align_up(w, 64);
+    void* p = nullptr;
+    HIPCHK(hipHostMalloc(&p, (size_t)st * hh * B));
+    *frames = (uint8_t*)p;
+    if (stride) *stride = st;
+    if (pitch) *pitch = (size_t)st * hh;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_host_free(orbx_t* h, void* p)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if ((rc = sync_all(h))) return rc;
+    if (p) HIPCHK(hipHostFree(p));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_host_register(orbx_t* h, void* p, size_t bytes)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!p || !bytes) return fail(ORBX_E_INVALID, "bad argument");
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_host_unregister(orbx_t* h, void* p)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if ((rc = sync_all(h))) return rc;
+    if (p) HIPCHK(hipHostUnregister(p));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int hh, int stride,
+                                 const OrbxStreamOpts* opts, int* ticket)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!imgs || B < 1 || !ticket) return fail(ORBX_E_INVALID, "no frames");
+    if (B > h->maxB) return fail(ORBX_E_INVALID, "batch %d exceeds %d", B, h->maxB);
+    if (w < 1 || hh < 1) return fail(ORBX_E_INVALID, "empty frame");
+    if (w > h->maxW || hh > h->maxH) return fail(ORBX_E_INVALID, "frame exceeds the handle's maximum");
+    if (stride < w) return fail(ORBX_E_INVALID, "stride < width");
+    for (int f = 0; f < B; f++) if (!imgs[f]) return fail(ORBX_E_INVALID, "null frame %d", f);
+    if ((rc = ensure_slots(h))) return rc;
+    HostSlot& sl = h->slot[h->nextTicket % orbx_handle::kSlots];
+    if (sl.state != 0) return fail(ORBX_E_INVALID, "%d batches in flight: collect / release ticket %d first", orbx_handle::kSlots, sl.ticket);
+    if ((rc = configure_shape(h, w, hh))) return rc;  // a new shape drains the streams before anything is overwritten
+
+    const int dstride = align_up(w, 64);
+    const size_t dpitch = (size_t)dstride * hh;
+    hipStream_t up = h->streamUp;
+    h->prof.begin(P_H2D, up);
+    const bool pinned = is_pinned(imgs[0]);
+    bool contiguous = true;  // frames back to back at a constant pitch of whole rows
+    for (int f = 1; f < B && contiguous; f++) contiguous = imgs[f] == imgs[0] + (size_t)f * stride * hh;
+    if (pinned && contiguous && stride == dstride) {
+        // frames from orbx_host_alloc_frames: already in the device layout, the DMA reads the caller's memory
+        HIPCHK(hipMemcpyAsync(sl.d_in, imgs[0], dpitch * B, hipMemcpyHostToDevice, up));
+    } else if (pinned && contiguous) {
+        HIPCHK(hipMemcpy2DAsync(sl.d_in, dstride, imgs[0], stride, w, (size_t)hh * B, hipMemcpyHostToDevice, up));
+    } else if (pinned) {
+        for (int f = 0; f < B; f++) {
+            if (f && !is_pinned(imgs[f])) return fail(ORBX_E_INVALID, "frame %d is pageable, frame 0 pinned: one kind per batch", f);
+            HIPCHK(hipMemcpy2DAsync(sl.d_in + f * dpitch, dstride, imgs[f], stride, w, hh, hipMemcpyHostToDevice, up));
+        }
+    } else if (B <= 2) {
+        // latency path: the pageable frame is staged in row chunks, each on its way while the next is copied
+        constexpr int kChunks = 4;
+        for (int f = 0; f < B; f++)
+            for (int c = 0; c < kChunks; c++) {
+                const int y0 = (int)((int64_t)hh * c / kChunks), y1 = (int)((int64_t)hh * (c + 1) / kChunks);
+                uint8_t* dst = sl.h_in + f * dpitch + (size_t)y0 * dstride;
+                if (stride == dstride) memcpy(dst, imgs[f] + (size_t)y0 * stride, (size_t)(y1 - y0) * stride);
+                else for (int y = y0; y < y1; y++) memcpy(sl.h_in + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
+                HIPCHK(hipMemcpyAsync(sl.d_in + f * dpitch + (size_t)y0 * dstride, dst, (size_t)(y1 - y0) * dstride, hipMemcpyHostToDevice, up));
+            }
+    } else {
+        // throughput path: row-band jobs over the copy threads, one DMA for the batch
+        const int bands = 4, jobs = B * bands;
+        uint8_t* const hin = sl.h_in;
+        h->pool.run(jobs, [=](int j) {
+            const int f = j / bands, c = j - f * bands;
+            const int y0 = (int)((int64_t)hh * c / bands), y1 = (int)((int64_t)hh * (c + 1) / bands);
+            for (int y = y0; y < y1; y++) memcpy(hin + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
+        });
+        HIPCHK(hipMemcpyAsync(sl.d_in, sl.h_in, dpitch * B, hipMemcpyHostToDevice, up));
+    }
+    h->prof.end(up);
+    HIPCHK(hipEventRecord(sl.evUp, up));
+
+    if ((rc = run_extract(h, sl.d_in, B, w, hh, dstride, dpitch, sl.evUp))) return rc;
+    const bool match = opts && opts->match_prev;
+    if (match && (rc = orbx_match_prev_batch_device(h, opts->nnratio, opts->th_low, opts->check_ori))) return rc;
+
+    // download behind the batch's kernels on the second copy stream: full-capacity slots, one pass, no host sync
+    hipStream_t dn = h->streamDown;
+    const int set = h->curSet;
+    if ((rc = join_parts(h, dn))) return rc;
+    if (match) HIPCHK(hipStreamWaitEvent(dn, h->evMatch[set], 0));
+    h->prof.begin(P_D2H, dn);
+    HIPCHK(hipMemcpyAsync(sl.h_out, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, dn));
+    HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffN, r_count(h, set) + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, dn));
+    HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffKp, r_kps(h, set) + h->maxKp, (size_t)B * h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToHost, dn));
+    HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffDesc, r_desc(h, set) + (size_t)h->maxKp * 32, (size_t)B * h->maxKp * 32, hipMemcpyDeviceToHost, dn));
+    if (match) {
+        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffNm, h->d_nmatch + (size_t)set * h->maxB, B * sizeof(int32_t), hipMemcpyDeviceToHost, dn));
+        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffMatch, h->d_match + (size_t)set * h->maxB * h->maxKp, (size_t)B * h->maxKp * 4, hipMemcpyDeviceToHost, dn));
+    }
+    h->prof.end(dn);
+    HIPCHK(hipEventRecord(sl.evOut, dn));
+    h->evOutOfSet[set] = sl.evOut;
+    sl.state = 1; sl.B = B; sl.matched = match; sl.ticket = h->nextTicket;
+    *ticket = h->nextTicket++;
+    return ORBX_OK;
+}
+
+static int slot_of(orbx_handle* h, int ticket, int want, HostSlot** out)
+{
+    if (!h->slotsReady || ticket < 0) return fail(ORBX_E_INVALID, "unknown ticket %d", ticket);
+    HostSlot& sl = h->slot[ticket % orbx_handle::kSlots];
+    if (sl.ticket != ticket || sl.state == 0 || (want && sl.state != want)) return fail(ORBX_E_INVALID, "ticket %d is not %s", ticket, want == 1 ? "in flight" : "outstanding");
+    *out = &sl;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_collect_view(orbx_t* h, int ticket, OrbxBatchView* view)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    HostSlot* sl;
+    if ((rc = slot_of(h, ticket, 1, &sl))) return rc;
+    if (!view) return fail(ORBX_E_INVALID, "null view");
+    HIPCHK(hipEventSynchronize(sl->evOut));
+    sl->state = 2;
+    const int32_t err = *(const int32_t*)sl->h_out;
+    view->B = sl->B; view->cap = h->maxKp;
+    view->n = (const int32_t*)(sl->h_out + h->outOffN);
+    view->kps = (const OrbxKeyPoint*)(sl->h_out + h->outOffKp);
+    view->desc = sl->h_out + h->outOffDesc;
+    view->match = sl->matched ? (const int32_t*)(sl->h_out + h->outOffMatch) : nullptr;
+    view->nmatch = sl->matched ? (const int32_t*)(sl->h_out + h->outOffNm) : nullptr;
+    if (err) {
+        (void)hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->streamDown);
+        return fail(ORBX_E_CAPACITY, "device scratch overflow (flags 0x%x)", err);
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_release(orbx_t* h, int ticket)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    HostSlot* sl;
+    if ((rc = slot_of(h, ticket, 0, &sl))) return rc;
+    if (sl->state == 1) HIPCHK(hipEventSynchronize(sl->evOut));  // abandoned in flight: its buffers are free once it has drained
+    sl->state = 0;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_collect_batch(orbx_t* h, int ticket, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out,
+                                  int32_t* match, int* nmatch)
+{
+    OrbxBatchView v;
+    int rc = orbx_collect_view(h, ticket, &v);
+    if (rc) { if (rc != ORBX_E_INVALID) { const std::string keep = g_err; (void)orbx_release(h, ticket); g_err = keep; } return rc; }
+    int over = 0;
+    for (int f = 0; f < v.B; f++) {
+        if (n_out) n_out[f] = v.n[f];
+        if (nmatch) nmatch[f] = v.nmatch ? v.nmatch[f] : 0;
+        if (v.n[f] > cap) over = 1;
+    }
+    if (!over) {
+        const int mk = h->maxKp;
+        h->pool.run(v.B, [=](int f) {
+            const size_t n = (size_t)v.n[f];
+            if (!n) return;
+            if (kps) memcpy(kps + (size_t)f * cap, v.kps + (size_t)f * mk, n * sizeof(OrbxKeyPoint));
+            if (desc) memcpy(desc + (size_t)f * cap * 32, v.desc + (size_t)f * mk * 32, n * 32);
+            if (match && v.match) memcpy(match + (size_t)f * cap, v.match + (size_t)f * mk, n * 4);
+        });
+    }
+    if ((rc = orbx_release(h, ticket))) return rc;
+    if (over) return fail(ORBX_E_CAPACITY, "a frame produced more keypoints than cap=%d", cap);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_match_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int hh, int stride,
+                                        const OrbxStreamOpts* opts, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out,
+                                        int32_t* match, int* nmatch)
+{
+    int t = -1;
+    int rc = orbx_submit_batch(h, imgs, B, w, hh, stride, opts, &t);
+    if (rc) return rc;
+    return orbx_collect_batch(h, t, kps, desc, cap, n_out, match, nmatch);
+}
+
 extern "C" int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int hh, int stride,
                                   OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out)
 {
@@ -945,50 +1284,7 @@ extern "C" int orbx_extract_batch(orbx_t* h, const uint8_t* const* imgs, int B, 
     if (!imgs || B < 1) return fail(ORBX_E_INVALID, "no frames");
     if (B > h->maxB) return fail(ORBX_E_INVALID, "batch %d exceeds %d", B, h->maxB);
     if (w < 1 || hh < 1) { for (int f = 0; f < B; f++) if (n_out) n_out[f] = 0; return ORBX_OK; }  // :1046-1047
-    if (w > h->maxW || hh > h->maxH) return fail(ORBX_E_INVALID, "frame exceeds the handle's maximum");
-    if (stride < w) return fail(ORBX_E_INVALID, "stride < width");
-    // stage through pinned memory into the aligned device frames
-    const int dstride = align_up(w, 64);
-    const size_t dpitch = (size_t)dstride * hh;
-    if ((rc = sync_all(h))) return rc;  // the staging frames may still be read by the previous call
-    for (int f = 0; f < B; f++) {
-        if (!imgs[f]) return fail(ORBX_E_INVALID, "null frame %d", f);
-        for (int y = 0; y < hh; y++) memcpy(h->h_pinned + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
-    }
-    h->prof.begin(P_H2D, h->stream);
-    HIPCHK(hipMemcpyAsync(h->d_img, h->h_pinned, dpitch * B, hipMemcpyHostToDevice, h->stream));
-    h->prof.end(h->stream);
-    rc = run_extract(h, h->d_img, B, w, hh, dstride, dpitch);
-    if (rc) return rc;
-    // One device->host pass behind the kernels, no intermediate host sync: the counts and the full-capacity
-    // keypoint / descriptor slots of the batch go to the pinned staging buffer (the frames it held were consumed
-    // by the upload above), one synchronisation, then the exact n entries are copied out to the caller's arrays.
-    hipStream_t s0 = h->stream;
-    if ((rc = join_parts(h, s0))) return rc;
-    const size_t kpBytes = (size_t)B * h->maxKp * sizeof(OrbxKeyPointDev), dBytes = (size_t)B * h->maxKp * 32;
-    uint8_t* st = h->h_pinned;
-    int32_t* st_cnt = (int32_t*)st;
-    uint8_t* st_kp = st + align_up(B * 4, 64);
-    uint8_t* st_d = st_kp + kpBytes;
-    h->prof.begin(P_D2H, s0);
-    HIPCHK(hipMemcpyAsync(st_cnt, r_count(h, h->curSet) + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
-    if (kps) HIPCHK(hipMemcpyAsync(st_kp, r_kps(h, h->curSet) + h->maxKp, kpBytes, hipMemcpyDeviceToHost, s0));
-    if (desc) HIPCHK(hipMemcpyAsync(st_d, r_desc(h, h->curSet) + (size_t)h->maxKp * 32, dBytes, hipMemcpyDeviceToHost, s0));
-    h->prof.end(s0);
-    rc = orbx_sync(h);
-    if (rc) return rc;
-    int over = 0;
-    for (int f = 0; f < B; f++) {
-        const int n = st_cnt[f];
-        if (n_out) n_out[f] = n;
-        if (n > cap) { over = 1; continue; }
-        if (n > 0) {
-            if (kps) memcpy(kps + (size_t)f * cap, st_kp + (size_t)f * h->maxKp * sizeof(OrbxKeyPointDev), (size_t)n * sizeof(OrbxKeyPoint));
-            if (desc) memcpy(desc + (size_t)f * cap * 32, st_d + (size_t)f * h->maxKp * 32, (size_t)n * 32);
-        }
-    }
-    if (over) return fail(ORBX_E_CAPACITY, "a frame produced more keypoints than cap=%d", cap);
-    return ORBX_OK;
+    return orbx_extract_match_batch(h, imgs, B, w, hh, stride, nullptr, kps, desc, cap, n_out, nullptr, nullptr);
 }
 
 extern "C" int orbx_extract(orbx_t* h, const uint8_t* img, int w, int hh, int stride,
@@ -1060,11 +1356,16 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     if ((rc = join_parts(h, s))) return rc;
     const int set = h->curSet;
     orbm::MatchIO io = slots_io(h, set);
+    int32_t* const d_match = h->d_match + (size_t)set * h->maxB * h->maxKp;  // one table per result set: the host path's
+    int32_t* const d_nmatch = h->d_nmatch + (size_t)set * h->maxB;           // download of batch n-1 runs beside batch n
+    if (h->evOutOfSet[set]) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));
+    h->matchSet = set;
     h->prof.begin(P_MATCH_BEST2, s);
     // slots 0..B expanded to +-1 bytes, then the Hamming scan as an int8 MFMA product (train slot f, query slot f+1)
     // with the acceptance rule in its epilogue
-    const orbm::AcceptArgs aa = {io, io, 1, 0, nnratio, th_low, check_ori, h->d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist};
-    if (h->matchPopcount) {  // the literal xor + popcount scan (lane = query, train descriptor wave-uniform), kept for A/B runs
+    const orbm::AcceptArgs aa = {io, io, 1, 0, nnratio, th_low, check_ori, d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist};
+    // the MFMA scan packs the train index into 16 bits of its key: larger frames take the popcount scan (20-bit index)
+    if (h->matchPopcount || h->maxKp >= 65536) {  // the literal xor + popcount scan (lane = query, train descriptor wave-uniform), kept for A/B runs
         hipLaunchKernelGGL(orbm::k_match_best2, dim3((h->maxKp + 255) / 256, B, kMatchChunks), dim3(256), 0, s, io, io, 1, 0,
                            kMatchChunks, h->d_partial, (int64_t)h->maxKp);
         hipLaunchKernelGGL(orbm::k_match_accept, dim3((h->maxKp + 255) / 256, B), dim3(256), 0, s, aa, kMatchChunks,
@@ -1076,8 +1377,8 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     }
     h->prof.end(s);
     h->prof.begin(P_MATCH_PRUNE, s);
-    hipLaunchKernelGGL(orbm::k_match_prune, dim3(B), dim3(256), 0, s, io, 1, check_ori, h->d_match, (int64_t)h->maxKp,
-                       h->d_binOf, h->d_hist, h->d_nmatch);
+    hipLaunchKernelGGL(orbm::k_match_prune, dim3(B), dim3(256), 0, s, io, 1, check_ori, d_match, (int64_t)h->maxKp,
+                       h->d_binOf, h->d_hist, d_nmatch);
     h->prof.end(s);
     // last frame of this batch becomes the stream's previous frame: slot 0 of the set the next extraction fills
     HIPCHK(hipMemcpyAsync(r_kps(h, set ^ 1), r_kps(h, set) + (size_t)B * h->maxKp, (size_t)h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToDevice, s));
@@ -1094,8 +1395,8 @@ extern "C" int orbx_device_matches(orbx_t* h, int32_t** d_match, int32_t** d_nma
 {
     int rc = check_device(h);
     if (rc) return rc;
-    if (d_match) *d_match = h->d_match;
-    if (d_nmatch) *d_nmatch = h->d_nmatch;
+    if (d_match) *d_match = h->d_match + (size_t)h->matchSet * h->maxB * h->maxKp;
+    if (d_nmatch) *d_nmatch = h->d_nmatch + (size_t)h->matchSet * h->maxB;
     return ORBX_OK;
 }
 
@@ -1106,10 +1407,10 @@ extern "C" int orbx_download_matches(orbx_t* h, int frame, int32_t* match, int c
     if (frame < 0 || frame >= h->lastB) return fail(ORBX_E_INVALID, "frame %d not in the last batch", frame);
     int32_t n = 0, nm = 0;
     HIPCHK(hipMemcpy(&n, r_count(h, h->curSet) + 1 + frame, sizeof n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&nm, h->d_nmatch + frame, sizeof nm, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&nm, h->d_nmatch + (size_t)h->matchSet * h->maxB + frame, sizeof nm, hipMemcpyDeviceToHost));
     if (nmatch) *nmatch = nm;
     if (n > cap) return fail(ORBX_E_CAPACITY, "%d queries, caller capacity %d", n, cap);
-    if (match && n > 0) HIPCHK(hipMemcpy(match, h->d_match + (size_t)frame * h->maxKp, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (match && n > 0) HIPCHK(hipMemcpy(match, h->d_match + ((size_t)h->matchSet * h->maxB + frame) * h->maxKp, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

@@ -102,6 +102,83 @@ class ORBextractor:
         self._last_shape = (w, h)
         return [kps[f, :n[f]].copy() for f in range(B)], [desc[f, :n[f]].copy() for f in range(B)]
 
+    # ---- host-buffer entries with matching (orbx_extract_match_batch / orbx_submit_batch .. orbx_collect_*)
+    def _opts(self, match, nnratio, th_low, check_ori):
+        return _lib.OrbxStreamOpts(int(bool(match)), float(nnratio), int(th_low), int(bool(check_ori)))
+
+    def _frame_ptrs(self, images):
+        """(keep-alive list, pointer array, B, w, h, stride) for [B,H,W] uint8 arrays, lists of [H,W], or PinnedFrames"""
+        if isinstance(images, PinnedFrames):
+            B = images.B
+            arr = (C.c_void_p * B)(*[images.ptr + f * images.pitch for f in range(B)])
+            return images, arr, B, images.w, images.h, images.stride
+        if isinstance(images, np.ndarray) and images.ndim == 3 and images.dtype == np.uint8 and images.flags.c_contiguous:
+            B, h, w = images.shape
+            base = images.ctypes.data
+            arr = (C.c_void_p * B)(*[base + f * h * w for f in range(B)])
+            return images, arr, B, w, h, w
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        h, w = imgs[0].shape
+        return imgs, (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs]), len(imgs), w, h, w
+
+    def _out_arrays(self, B):
+        """reused output arrays of the synchronous host entries (no allocation per call on the latency path)"""
+        o = getattr(self, "_out", None)
+        if o is None or o[0].shape[0] < B:
+            cap = self._cap
+            o = (np.zeros((B, cap), dtype=KP_DTYPE), np.zeros((B, cap, 32), dtype=np.uint8), np.zeros(B, dtype=np.int32),
+                 np.full((B, cap), -1, dtype=np.int32), np.zeros(B, dtype=np.int32))
+            self._out = o
+        return o
+
+    def extract_match_host(self, images, match=True, nnratio=0.7, th_low=50, check_ori=True, copy=False):
+        """orbx_extract_match_batch: host frames in, (kps, desc, n, match, nmatch) on the host; synchronous.
+        Returns views into arrays this object reuses (copy=True for private copies)."""
+        keep, arr, B, w, h, stride = self._frame_ptrs(images)
+        kps, desc, n, m, nm = self._out_arrays(B)
+        opts = self._opts(match, nnratio, th_low, check_ori)
+        check(self._L.orbx_extract_match_batch(self._h, arr, B, w, h, stride, C.byref(opts), ptr(kps), ptr(desc), self._cap,
+                                               ptr(n), ptr(m), ptr(nm)))
+        self._last_shape = (w, h)
+        res = (kps[:B], desc[:B], n[:B], m[:B], nm[:B])
+        return tuple(a.copy() for a in res) if copy else res
+
+    def submit_host(self, images, match=True, nnratio=0.7, th_low=50, check_ori=True):
+        """orbx_submit_batch: returns a ticket; the frames must stay untouched until it is collected"""
+        keep, arr, B, w, h, stride = self._frame_ptrs(images)
+        t = C.c_int(-1)
+        opts = self._opts(match, nnratio, th_low, check_ori)
+        check(self._L.orbx_submit_batch(self._h, arr, B, w, h, stride, C.byref(opts), C.byref(t)))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[t.value] = keep
+        return t.value
+
+    def collect_host(self, ticket, view=True):
+        """view=True: orbx_collect_view + copies of the per-frame counts only + orbx_release -- what a consumer that reads
+        the pinned results in place costs; view=False: orbx_collect_batch into fresh arrays."""
+        self._inflight.pop(ticket, None)
+        if view:
+            v = _lib.OrbxBatchView()
+            check(self._L.orbx_collect_view(self._h, int(ticket), C.byref(v)))
+            n = np.ctypeslib.as_array(C.cast(v.n, C.POINTER(C.c_int32)), (v.B,)).copy()
+            nm = np.ctypeslib.as_array(C.cast(v.nmatch, C.POINTER(C.c_int32)), (v.B,)).copy() if v.nmatch else None
+            check(self._L.orbx_release(self._h, int(ticket)))
+            return n, nm
+        B, cap = self.max_batch, self._cap
+        kps = np.zeros((B, cap), dtype=KP_DTYPE)
+        desc = np.zeros((B, cap, 32), dtype=np.uint8)
+        n = np.zeros(B, dtype=np.int32)
+        m = np.full((B, cap), -1, dtype=np.int32)
+        nm = np.zeros(B, dtype=np.int32)
+        check(self._L.orbx_collect_batch(self._h, int(ticket), ptr(kps), ptr(desc), cap, ptr(n), ptr(m), ptr(nm)))
+        return kps, desc, n, m, nm
+
+    def alloc_pinned_frames(self, B, w, h):
+        """orbx_host_alloc_frames: pinned host frames in the device layout, as a PinnedFrames (numpy view in .array)"""
+        p, st, pitch = C.c_void_p(), C.c_int(), C.c_size_t()
+        check(self._L.orbx_host_alloc_frames(self._h, int(B), int(w), int(h), C.byref(p), C.byref(st), C.byref(pitch)))
+        return PinnedFrames(self, p.value, B, w, h, st.value, pitch.value)
+
     # ---- device-resident path (frames already in HBM)
     def upload_frames(self, frames, stride=None):
         """copy [B,H,W] uint8 host frames into a device buffer with 64-byte aligned rows;
@@ -195,6 +272,24 @@ class ORBextractor:
         p = _lib.OrbxProfile()
         check(self._L.orbx_profile_read(self._h, C.byref(p), int(bool(reset))))
         return {p.name[i].decode(): (p.ms[i], p.launches[i]) for i in range(p.n)}
+
+
+class PinnedFrames:
+    """B pinned host frames in the device layout (rows `stride` bytes apart); .array is a [B, h, stride] numpy view,
+    .array[:, :, :w] the pixels"""
+    def __init__(self, owner, ptr_, B, w, h, stride, pitch):
+        self.owner, self.ptr, self.B, self.w, self.h, self.stride, self.pitch = owner, ptr_, B, w, h, stride, pitch
+        buf = (C.c_uint8 * (pitch * B)).from_address(ptr_)
+        self.array = np.frombuffer(buf, dtype=np.uint8).reshape(B, h, stride)
+
+    def fill(self, frames):
+        self.array[:, :, :self.w] = frames
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            check(self.owner._L.orbx_host_free(self.owner._h, C.c_void_p(self.ptr)))
+            self.ptr = 0
 
 
 def unpack_candidates(rec):

@@ -1,0 +1,145 @@
+"""The host-buffer entries (orbx_extract_match_batch, orbx_submit_batch / orbx_collect_*) against the oracle: what a
+drop-in caller of Frame::ExtractORB sees -- pageable, pinned and registered frames, one frame per call and pipelined
+batches, keypoints, descriptors AND the match table against the previous frame of the stream."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import frames_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_stream(oracle, frames, nf):
+    """per frame: (kps, desc, match-vs-previous table, nmatch) of one camera stream"""
+    ex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    out, prev = [], None
+    for f in frames:
+        r = ex(f)
+        if prev is None:
+            m, n = np.full(len(r["kps"]), -1, dtype=np.int32), 0
+        else:
+            m, n = oracle.match_bruteforce(r["desc"], r["kps"]["angle"], prev["desc"], prev["kps"]["angle"], 0.7, 50, True)
+        out.append((r["kps"], r["desc"], m, n))
+        prev = r
+    return out
+
+
+def _check(ref, kps, desc, n, m, nm):
+    rk, rd, rm, rn = ref
+    assert n == len(rk)
+    assert kps[:n].tobytes() == rk.tobytes()
+    assert np.array_equal(desc[:n], rd)
+    assert nm == rn and np.array_equal(m[:n], rm)
+
+
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (1241, 376, 2000)])
+def test_one_frame_per_call(gpu, oracle, w, h, nf):
+    """B = 1, pageable frames: Frame::ExtractORB's entry followed by the match against the previous frame"""
+    from orbslamm_amd import ORBextractor
+    fr = frames_for(w, h, 5, stream=2)
+    ref = _oracle_stream(oracle, fr, nf)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1, device=0)
+    for t in range(5):
+        kps, desc, n, m, nm = ex.extract_match_host(fr[t][None])
+        _check(ref[t], kps[0], desc[0], int(n[0]), m[0], int(nm[0]))
+
+
+@pytest.mark.parametrize("kind", ["pageable", "pinned_device_layout", "registered_tight", "pageable_strided"])
+def test_pipelined_batches(gpu, oracle, kind):
+    """three tickets in flight, collected in order; batches 5, 5, 5, 3, 2 of one stream (the batch size changes inside
+    the pipeline) -- every frame and every match table equals the oracle's, also across batch boundaries"""
+    from orbslamm_amd import ORBextractor
+    w, h, nf = 640, 480, 1000
+    sizes = [5, 5, 5, 3, 2]
+    fr = frames_for(w, h, sum(sizes), stream=5)
+    ref = _oracle_stream(oracle, fr, nf)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=5, device=0)
+    L = ex._L
+    pins, keep = [], []
+    batches, o = [], 0
+    for i, b in enumerate(sizes):
+        chunk = fr[o:o + b]
+        if kind == "pinned_device_layout":
+            p = ex.alloc_pinned_frames(b, w, h)
+            p.fill(chunk)
+            pins.append(p)
+            batches.append(p)
+        elif kind == "registered_tight":
+            a = np.ascontiguousarray(chunk)
+            assert L.orbx_host_register(ex._h, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)) == 0
+            keep.append(a)
+            batches.append(a)
+        elif kind == "pageable_strided":
+            big = np.zeros((b, h, w + 37), dtype=np.uint8)
+            big[:, :, :w] = chunk
+            batches.append([big[f, :, :w] for f in range(b)])  # non-contiguous rows: the mirror makes them contiguous per frame
+        else:
+            batches.append(np.ascontiguousarray(chunk))
+        o += b
+    tickets, got = [], []
+    for i, b in enumerate(batches):
+        tickets.append(ex.submit_host(b))
+        if len(tickets) == 3:
+            got.append(ex.collect_host(tickets.pop(0), view=False))
+    while tickets:
+        got.append(ex.collect_host(tickets.pop(0), view=False))
+    o = 0
+    for i, b in enumerate(sizes):
+        kps, desc, n, m, nm = got[i]
+        for f in range(b):
+            _check(ref[o + f], kps[f], desc[f], int(n[f]), m[f], int(nm[f]))
+        o += b
+    for a in keep:
+        assert L.orbx_host_unregister(ex._h, C.c_void_p(a.ctypes.data)) == 0
+    for p in pins:
+        p.free()
+
+
+def test_view_collect_and_ticket_errors(gpu, oracle):
+    from orbslamm_amd import ORBextractor, OrbError, _lib
+    w, h, nf = 320, 240, 500
+    fr = frames_for(w, h, 4, stream=1)
+    ref = _oracle_stream(oracle, fr, nf)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1, device=0)
+    t = [ex.submit_host(fr[i][None]) for i in range(3)]
+    with pytest.raises(OrbError) as e:   # a fourth batch needs a free slot
+        ex.submit_host(fr[3][None])
+    assert e.value.code == -1 and "in flight" in str(e.value)
+    v = _lib.OrbxBatchView()
+    assert ex._L.orbx_collect_view(ex._h, t[0], C.byref(v)) == 0
+    n0 = C.cast(v.n, C.POINTER(C.c_int32))[0]
+    kps = np.frombuffer((C.c_uint8 * (n0 * 28)).from_address(v.kps), dtype=_lib.KP_DTYPE)
+    assert kps.tobytes() == ref[0][0].tobytes() and v.B == 1 and v.cap == ex.max_keypoints
+    assert ex._L.orbx_collect_view(ex._h, t[0], C.byref(v)) == -1     # already collected
+    assert ex._L.orbx_release(ex._h, t[0]) == 0
+    assert ex._L.orbx_release(ex._h, t[0]) == -1                      # already released
+    assert ex._L.orbx_release(ex._h, 99) == -1
+    t.append(ex.submit_host(fr[3][None]))                             # the freed slot
+    for i in (1, 2, 3):
+        kps, desc, n, m, nm = ex.collect_host(t[i], view=False)
+        _check(ref[i], kps[0], desc[0], int(n[0]), m[0], int(nm[0]))
+
+
+def test_host_and_device_paths_interleave(gpu, oracle):
+    """a stream may switch between the host entry and the device-resident entry: the previous-frame slot is shared"""
+    from orbslamm_amd import ORBextractor
+    w, h, nf = 640, 480, 1000
+    fr = frames_for(w, h, 6, stream=8)
+    ref = _oracle_stream(oracle, fr, nf)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2, device=0)
+    kps, desc, n, m, nm = ex.extract_match_host(fr[0:2], copy=True)
+    for f in range(2):
+        _check(ref[f], kps[f], desc[f], int(n[f]), m[f], int(nm[f]))
+    d = ex.upload_frames(fr[2:4])
+    ex.extract_batch_device(*d)
+    ex.match_prev_batch_device(0.7, 50, True)
+    for f in range(2):
+        k, dd = ex.download(f)
+        mm, nmm = ex.download_matches(f)
+        assert k.tobytes() == ref[2 + f][0].tobytes() and np.array_equal(dd, ref[2 + f][1])
+        assert nmm == ref[2 + f][3] and np.array_equal(mm[:len(k)], ref[2 + f][2])
+    kps, desc, n, m, nm = ex.extract_match_host(fr[4:6], copy=True)
+    for f in range(2):
+        _check(ref[4 + f], kps[f], desc[f], int(n[f]), m[f], int(nm[f]))
