@@ -121,9 +121,11 @@ struct AcceptArgs {
     uint8_t* binOf;
     int32_t* hist;
 };
-__device__ __forceinline__ void accept_one(const AcceptArgs& a, int f, int qi, uint32_t k1, uint32_t k2)
+// returns the accepted train index or -1; `bin` = rotation bin of an accepted match when checkOri
+__device__ __forceinline__ int accept_decide(const AcceptArgs& a, int f, int qi, uint32_t k1, uint32_t k2, int& bin)
 {
     int m = -1;
+    bin = -1;
     if (k1 != 0xFFFFFFFFu) {
         const int best1 = (int)(k1 >> 20), bestIdx = (int)(k1 & 0xFFFFFu);
         const int best2 = k2 == 0xFFFFFFFFu ? 256 : min(256, (int)(k2 >> 20));
@@ -132,11 +134,19 @@ __device__ __forceinline__ void accept_one(const AcceptArgs& a, int f, int qi, u
             if (a.checkOri) {
                 const float aq = a.q.ang[(int64_t)(a.qslot0 + f) * a.q.angPitch + (int64_t)qi * a.q.angStride];
                 const float at = a.t.ang[(int64_t)(a.tslot0 + f) * a.t.angPitch + (int64_t)bestIdx * a.t.angStride];
-                const int bin = rot_bin(aq, at);
-                a.binOf[(int64_t)f * a.matchPitch + qi] = (uint8_t)bin;
-                atomicAdd(&a.hist[f * 32 + bin], 1);
+                bin = rot_bin(aq, at);
             }
         }
+    }
+    return m;
+}
+__device__ __forceinline__ void accept_one(const AcceptArgs& a, int f, int qi, uint32_t k1, uint32_t k2)
+{
+    int bin;
+    const int m = accept_decide(a, f, qi, k1, k2, bin);
+    if (bin >= 0) {
+        a.binOf[(int64_t)f * a.matchPitch + qi] = (uint8_t)bin;
+        atomicAdd(&a.hist[f * 32 + bin], 1);
     }
     a.match[(int64_t)f * a.matchPitch + qi] = m;
 }
@@ -181,8 +191,12 @@ constexpr int kMfmaRowsPerBlock = 256;  // 4 waves x 2 query blocks of 32
 // keeps, per lane and accumulator element, the running (best, second) keys of "its" train residue class.
 // key = Hamming << 16 | j - 2^23 (one v_lshl_add from the negated dot product), so signed min = best with the
 // lowest index on ties (the reference scans j ascending with strict <) and med3(best, key, second) = new second.
+// Few frames (the one-frame-per-call entry): gridDim.y > 1 cuts the train side into chunks of whole tiles, one
+// workgroup each, which leave their (k1, k2) keys in `partial` for k_match_accept to merge -- 9 workgroups walking
+// 63 tiles each become 72 walking 8.
 __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict__ xdesc, int64_t xPitch,
-                                                      AcceptArgs acc, int nqb, int nframes)
+                                                      AcceptArgs acc, int nqb, int nframes,
+                                                      uint2* __restrict__ partial, int64_t partialPitch)
 {
     const int32_t* __restrict__ count = acc.q.count;  // q.count and t.count index the same slot table here
     const int qslot0 = acc.qslot0, tslot0 = acc.tslot0;
@@ -196,8 +210,17 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
     const int q0 = (k % nqb) * kMfmaRowsPerBlock;
     if (q0 >= nq) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nchunks = gridDim.y, chunk = blockIdx.y;
+    const int tilesPer = (((nt + 31) >> 5) + nchunks - 1) / nchunks;
+    const int tile0 = chunk * tilesPer;                                  // this workgroup's first train tile
+    const int ntiles = max(0, min((nt + 31) >> 5, tile0 + tilesPer) - tile0);
+    if (nchunks > 1 && ntiles == 0) {  // an empty chunk still owes its partials
+        const int qi = q0 + tid;
+        if (qi < nq) partial[((int64_t)f * nchunks + chunk) * partialPitch + qi] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        return;
+    }
     const uint8_t* qx = xdesc + (int64_t)(qslot0 + f) * xPitch;
-    const uint4* tsrc = (const uint4*)(xdesc + (int64_t)(tslot0 + f) * xPitch);
+    const uint4* tsrc = (const uint4*)(xdesc + (int64_t)(tslot0 + f) * xPitch) + (int64_t)tile0 * 512;
     const int qblk0 = (q0 >> 5) + wave * 2;
 
     v4i A[2][8];
@@ -212,7 +235,6 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
 #pragma unroll
         for (int r = 0; r < 16; r++) best[qb][r] = second[qb][r] = 0x7FFFFFFF;
 
-    const int ntiles = (nt + 31) >> 5;
     // train tiles: prefetch distance 2 through registers (ga: even tiles, gb: odd tiles), LDS ring of 3.  The
     // loads and their counted waits are inline asm: hipcc cannot count vmcnt across the loop back-edge and
     // would drain the newest prefetch with vmcnt(0) at every LDS store.  Every step issues exactly two loads
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], Bf[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], Bf[s], acc1, 0, 0, 0);
         }
-        const int j = t * 32 + (lane & 31);
+        const int j = (tile0 + t) * 32 + (lane & 31);
         const int jv = j < nt ? j : 0x3FFFFFFF;  // rows past the end decode to a distance >= 256: never taken
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -300,10 +322,11 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
         const int qb = (lane >> 4) & 1, r = lane & 15;
         const int qi = q0 + wave * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (qi < nq) {
-            const uint32_t h1 = (uint32_t)(myB + (1 << 23)) >> 16, h2 = (uint32_t)(myS + (1 << 23)) >> 16;
+            const uint32_t h1 = ((uint32_t)myB + (1u << 23)) >> 16, h2 = ((uint32_t)myS + (1u << 23)) >> 16;  // unsigned: an empty train slot leaves 0x7FFFFFFF
             const uint32_t k1 = h1 >= 256u ? 0xFFFFFFFFu : ((h1 << 20) | ((uint32_t)myB & 0xFFFFu));
             const uint32_t k2 = ((h2 >= 256u ? 256u : h2) << 20) | 0xFFFFFu;
-            accept_one(acc, f, qi, k1, k2);
+            if (nchunks > 1) partial[((int64_t)f * nchunks + chunk) * partialPitch + qi] = make_uint2(k1, k2);
+            else accept_one(acc, f, qi, k1, k2);
         }
     }
 }
@@ -361,6 +384,66 @@ __global__ __launch_bounds__(256) void k_match_prune(MatchIO q, int qslot0, int 
             if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) {
                 m = -1;
                 match[(int64_t)f * matchPitch + i] = -1;
+            }
+        }
+        local += m >= 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if ((tid & 63) == 0) atomicAdd(&sCnt, local);
+    __syncthreads();
+    if (tid == 0) nmatch[f] = sCnt;
+}
+
+// k_match_accept + k_match_prune in one workgroup per frame, for the few-frame (latency) mode: merge of the chunk
+// partials, acceptance rule, rotation histogram in LDS, three maxima, pruning, count -- one launch instead of two and
+// no global histogram.
+__global__ __launch_bounds__(1024) void k_match_accept_prune(AcceptArgs a, int nchunks, const uint2* __restrict__ partial,
+                                                            int64_t pitch, int32_t* __restrict__ nmatch)
+{
+    __shared__ int sh[32];
+    __shared__ int sInd[3];
+    __shared__ int sCnt;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int nq = a.q.count[a.qslot0 + f];
+    if (tid < 32) sh[tid] = 0;
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    for (int qi = tid; qi < nq; qi += 1024) {
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        for (int c = 0; c < nchunks; c++) {
+            const uint2 p = partial[((int64_t)f * nchunks + c) * pitch + qi];
+            const uint32_t lo = min(k1, p.x), hi = max(k1, p.x);
+            k2 = min(hi, min(k2, p.y));
+            k1 = lo;
+        }
+        int bin;
+        const int m = accept_decide(a, f, qi, k1, k2, bin);
+        a.match[(int64_t)f * a.matchPitch + qi] = m;
+        if (bin >= 0) { a.binOf[(int64_t)f * a.matchPitch + qi] = (uint8_t)bin; atomicAdd(&sh[bin], 1); }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < kHistoLength; i++) {  // :1609-1633
+            const int s = sh[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+    }
+    __syncthreads();
+    int local = 0;
+    for (int qi = tid; qi < nq; qi += 1024) {  // the thread re-reads what it wrote above
+        int m = a.match[(int64_t)f * a.matchPitch + qi];
+        if (m >= 0 && a.checkOri) {
+            const int bin = a.binOf[(int64_t)f * a.matchPitch + qi];
+            if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) {
+                m = -1;
+                a.match[(int64_t)f * a.matchPitch + qi] = -1;
             }
         }
         local += m >= 0;

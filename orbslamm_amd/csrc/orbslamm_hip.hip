@@ -6,6 +6,7 @@
 // tables, one-time device allocation, kernel launches on the handle's stream.
 // No CPU compute path exists: without a HIP device every compute entry fails.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -130,10 +131,11 @@ struct CopyPool {
     int nItems = 0, next = 0, pending = 0;
     uint64_t gen = 0;
     bool quit = false;
-    void start(int n)
+    void start(int n, int device)
     {
         for (int i = 0; i < n; i++)
-            th.emplace_back([this] {
+            th.emplace_back([this, device] {
+                (void)hipSetDevice(device);  // the latency path lets a worker send off the band it has just staged
                 uint64_t seen = 0;
                 std::unique_lock<std::mutex> lk(m);
                 for (;;) {
@@ -182,6 +184,7 @@ struct HostSlot {
     uint8_t* h_out = nullptr;   // pinned results: [err | n[B] | nmatch[B] | kps[B][maxKp] | desc[B][maxKp][32] | match[B][maxKp]]
     hipEvent_t evUp = nullptr, evOut = nullptr;
     int state = 0;              // 0 free, 1 in flight, 2 collected (a view is out)
+    bool lat = false;           // results written by k_pack_host: h_out[1] holds ticket + 1 once they are all there
     int ticket = -1, B = 0;
     bool matched = false;
 };
@@ -225,6 +228,9 @@ struct orbx_handle {
     // extractions, so that the matching of batch n (set n & 1) never holds back the descriptors of batch n + 1
     int curSet = 0;
     bool serial = false;                      // ORBX_SERIAL=1: everything on one stream (profiling aid)
+    hipStream_t matchStream[2] = {nullptr, nullptr}, outStream[2] = {nullptr, nullptr};  // where evMatch[s] / evOutOfSet[s] were recorded
+    hipEvent_t evMatched[2] = {nullptr, nullptr};  // the batch's match tables are final (recorded before the roll of the previous frame)
+    size_t partialSlots = 0;                  // (frame, chunk) slots of d_partial
     bool matchPopcount = false;               // ORBX_MATCH_POPCOUNT=1: xor/popcount scan instead of the int8 MFMA scan
     // device buffers (sized for maxW x maxH x maxB at create)
     Geom* d_geom = nullptr;
@@ -267,6 +273,9 @@ struct orbx_handle {
     bool havePrev = false;
     Profiler prof;
 };
+
+static int match_prev_on(orbx_handle* h, hipStream_t s, float nnratio, int th_low, int check_ori, bool roll);
+static int roll_prev_on(orbx_handle* h, hipStream_t s, int set);
 
 // ------------------------------------------------------------------ tables, ref :410-470
 static int init_tables(orbx_handle* h)
@@ -484,8 +493,11 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     // the computed range of level l = owned range + what level l+1's computed range reads.
     // The block grid is refined until the LDS tiles fit; if the halo chain cannot fit at all
     // (scale factors near 2, huge frames) the per-level kernel is used instead.
+    // A latency handle (max_batch <= 2) starts one refinement finer: 128 blocks instead of 32 for the one frame in flight
     out.pyrFused = false;
-    for (int refine = 0; refine < 4 && !out.pyrFused; refine++) {
+    int refine0 = h->maxB <= 2 ? 1 : 0;
+    if (const char* e = getenv("ORBX_PYR_REFINE")) refine0 = std::max(0, std::min(3, atoi(e)));
+    for (int refine = refine0; refine < 4 && !out.pyrFused; refine++) {
         const int nl = g.nlevels;
         const int top = nl - 1;
         int BX = 8 << refine, BY = 4 << refine;
@@ -586,6 +598,7 @@ static void free_device(orbx_handle* h)
     if (h->evStart) (void)hipEventDestroy(h->evStart);
     if (h->evDesc) (void)hipEventDestroy(h->evDesc);
     for (int i = 0; i < 2; i++) if (h->evMatch[i]) (void)hipEventDestroy(h->evMatch[i]);
+    for (int i = 0; i < 2; i++) if (h->evMatched[i]) (void)hipEventDestroy(h->evMatched[i]);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
     if (h->stream) (void)hipStreamDestroy(h->stream);
 }
@@ -640,6 +653,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
     CRT(hipEventCreateWithFlags(&h->evDesc, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) CRT(hipEventCreateWithFlags(&h->evMatch[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) CRT(hipEventCreateWithFlags(&h->evMatched[i], hipEventDisableTiming));
     const size_t B = (size_t)max_batch;
     // capacities with head-room so that smaller shapes (different cell layouts) also fit
     h->cellsCap = hg.cells.size() * 2 + 64;
@@ -665,7 +679,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_cellCount, B * h->cellsCap * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_kept, h->keptCapFrame * B * sizeof(uint64_t)));
     CRT(hipMalloc(&h->d_keptCount, B * ORBX_MAXL * sizeof(int32_t)));
-    CRT(hipMalloc(&h->d_err, sizeof(int32_t)));
+    CRT(hipMalloc(&h->d_err, 2 * sizeof(int32_t)));  // [0] error flags, [1] block counter of k_pack_host
     CRT(hipMalloc(&h->d_kps, 2 * (B + 1) * h->maxKp * sizeof(OrbxKeyPointDev)));
     CRT(hipMalloc(&h->d_desc, 2 * (B + 1) * (size_t)h->maxKp * 32));
     CRT(hipMalloc(&h->d_count, 2 * (B + 1) * sizeof(int32_t)));
@@ -673,11 +687,12 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_binOf, B * (size_t)h->maxKp));
     CRT(hipMalloc(&h->d_hist, B * 32 * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_nmatch, 2 * B * sizeof(int32_t)));
-    CRT(hipMalloc(&h->d_partial, B * kMatchChunks * h->maxKp * sizeof(uint2)));
+    h->partialSlots = std::max<size_t>(B * kMatchChunks, 16);  // few frames: up to 8 train chunks per frame (k_match_mfma)
+    CRT(hipMalloc(&h->d_partial, h->partialSlots * h->maxKp * sizeof(uint2)));
     h->xPitch = (int64_t)align_up(h->maxKp, orbm::kMfmaRowsPerBlock) * 256;
     CRT(hipMalloc(&h->d_xdesc, 2 * (B + 1) * (size_t)h->xPitch));
     CRT(hipMemset(h->d_xdesc, 0, 2 * (B + 1) * (size_t)h->xPitch));
-    CRT(hipMemset(h->d_err, 0, sizeof(int32_t)));
+    CRT(hipMemset(h->d_err, 0, 2 * sizeof(int32_t)));
     CRT(hipMemset(h->d_count, 0, 2 * (B + 1) * sizeof(int32_t)));
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
     CRT(hipMemset(h->d_nmatch, 0, 2 * B * sizeof(int32_t)));
@@ -830,10 +845,113 @@ static int join_parts(orbx_handle* h, hipStream_t s)
     return ORBX_OK;
 }
 
-// The batch is cut into kSplit sub-batches that run on separate stream groups: the
-// latency-bound kernels of one sub-batch (quadtree, descriptors) overlap the
-// throughput-bound ones (FAST, matching) of the other.
-static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int hh, int stride, size_t pitch, hipEvent_t evUploaded = nullptr)
+// kernel launches of one (sub-)batch: frames [f0, f0 + nb) of `src`
+struct Launcher {
+    orbx_handle* h;
+    FrameSrc src;   // src.f0 = first frame
+    int nb;
+    void fast(hipStream_t fs, int cell0, int ncells) const
+    {
+        if (ncells <= 0) return;
+        const Geom& g = h->geom;
+        const bool l0 = cell0 == 0 && ncells == g.lv[0].nCells;  // the level-0 launch has its own, smaller LDS footprint
+        const int rows = l0 ? h->tileRows0 : h->tileRows, cap = l0 ? h->fastListCap0 : h->fastListCap;
+        const size_t lds = (size_t)2 * (rows * h->tileStrideDw + 4) * 4 + (size_t)cap * 2;
+        h->prof.begin(P_FAST, fs);
+        if (h->tileStrideDw == 12)
+            hipLaunchKernelGGL(k_fast<48>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
+                               h->d_cellCount, h->d_err, rows, cap, nb, cell0);
+        else
+            hipLaunchKernelGGL(k_fast<80>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
+                               h->d_cellCount, h->d_err, rows, cap, nb, cell0);
+        h->prof.end(fs);
+    }
+    void dist(hipStream_t ds, int l0, int nl) const  // quadtree of levels [l0, l0 + nl)
+    {
+        if (nl <= 0) return;
+        const Geom& g = h->geom;
+        h->prof.begin(P_DISTRIBUTE, ds);
+        const size_t dl = dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel);
+        if (h->distInLds)
+            hipLaunchKernelGGL(k_distribute<true>, dim3(nl, nb), dim3(kDistThreads), dl, ds, h->d_geom, h->d_candRaw,
+                               h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept, h->d_keptCount,
+                               h->d_err, h->nodeCap, src.f0, (uint32_t*)nullptr, 0, l0);
+        else
+            hipLaunchKernelGGL(k_distribute<false>, dim3(nl, nb), dim3(kDistThreads), 0, ds, h->d_geom, h->d_candRaw,
+                               h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept, h->d_keptCount,
+                               h->d_err, h->nodeCap, src.f0, h->d_distScratch + (size_t)src.f0 * g.nlevels * (dl / 4), (int)(dl / 4), l0);
+        h->prof.end(ds);
+    }
+    // done != nullptr: the event rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL) -- a separate
+    // hipEventRecord between two kernels of a stream costs ~6 us of gap (tools/b1_timeline.sh), which only matters
+    // where the chain of kernels IS the latency of a call
+    int pyramid(hipStream_t s, hipEvent_t done = nullptr) const
+    {
+        const Geom& g = h->geom;
+        if (g.nlevels > 1 && h->pyrFused) {
+            const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
+            h->prof.begin(P_RESIZE, s);
+            if (done && !h->prof.cur)
+                hipExtLaunchKernelGGL(k_pyramid, dim3(h->pyrBlocks, nb), dim3(256), pl, s, nullptr, done, 0, (const Geom*)h->d_geom, src, h->tabs,
+                                      (const PyrRange*)h->d_pyrRanges, h->pyrBufA, h->pyrBufB, h->pyrTabCap);
+            else
+                hipLaunchKernelGGL(k_pyramid, dim3(h->pyrBlocks, nb), dim3(256), pl, s, h->d_geom, src, h->tabs,
+                                   (const PyrRange*)h->d_pyrRanges, h->pyrBufA, h->pyrBufB, h->pyrTabCap);
+            h->prof.end(s);
+            if (done && h->prof.cur) HIPCHK(hipEventRecord(done, s));
+        } else {
+            for (int l = 1; l < g.nlevels; l++) {
+                h->prof.begin(P_RESIZE, s);
+                hipLaunchKernelGGL(k_resize_level, dim3((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nb), dim3(64, 4, 1), 0, s,
+                                   h->d_geom, src, h->tabs, l);
+                h->prof.end(s);
+            }
+            if (done) HIPCHK(hipEventRecord(done, s));
+        }
+        return ORBX_OK;
+    }
+    void blur(hipStream_t s) const
+    {
+        h->prof.begin(P_BLUR, s);
+        hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[h->geom.nlevels], xcd_grid_y(nb)), dim3(256), 0, s, h->d_geom, src, h->blurTiles, nb);
+        h->prof.end(s);
+    }
+    // The output slots of `set` were read by the matching two batches back and by its download (host path); a wait is
+    // only enqueued when that work sits on another stream (every cross-stream wait costs microseconds of latency).
+    int desc(hipStream_t s, int set, hipEvent_t done = nullptr) const
+    {
+        if (h->matchPending[set] && h->matchStream[set] != s) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set], 0));
+        if (h->evOutOfSet[set] && h->outStream[set] != s) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));
+        h->prof.begin(P_ORIENT_DESC, s);
+        if (done && !h->prof.cur)
+            hipExtLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, xcd_grid_y(nb)), dim3(256), 0, s, nullptr, done, 0, (const Geom*)h->d_geom, src, h->kpBlocks,
+                                  (const uint64_t*)h->d_kept, (const int32_t*)h->d_keptCount, r_kps(h, set) + h->maxKp, r_desc(h, set) + (size_t)h->maxKp * 32,
+                                  r_count(h, set) + 1, nb);
+        else
+            hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, xcd_grid_y(nb)), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
+                               h->d_keptCount, r_kps(h, set) + h->maxKp, r_desc(h, set) + (size_t)h->maxKp * 32, r_count(h, set) + 1, nb);
+        h->prof.end(s);
+        if (done && h->prof.cur) HIPCHK(hipEventRecord(done, s));
+        return ORBX_OK;
+    }
+};
+
+// Two event graphs.
+// THROUGHPUT (B > 2): the batch is cut into sub-batches that run on separate stream groups: the latency-bound kernels
+// of one sub-batch (quadtree, descriptors) overlap the throughput-bound ones (FAST, matching) of the other.  Level-0
+// FAST runs beside the pyramid on the blur stream; the quadtree of all levels follows FAST on the sub-batch's stream.
+// (Moving the level-0 quadtree ahead -- right behind the level-0 FAST, or behind the blur -- was measured at 64 frames
+// per step: 128.3 k -> 118.8 k and 111.2 k frames/s, two A/B rounds each: on the blur stream it delays the blur and
+// with it the descriptors.  It stays where it was.)
+// LATENCY (one or two frames, the per-frame drop-in entry): nothing else keeps the GPU busy, the chain IS the call.
+//   main (streamP[0]):  [frames arrive here on the host path] pyramid -> FAST 1.. -> quadtree 1.. -> descriptors
+//   aux  (stream):      FAST 0 -> quadtree 0 -> blur
+// one cross-stream wait in front of the descriptors; the level-0 quadtree (as long as levels 1.. together: one
+// workgroup per level) runs beside pyramid + FAST instead of behind them.
+// sIn = the stream on which the frames become available (nullptr: the host-facing stream, where the device-resident
+// entry has always taken them from).
+static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int hh, int stride, size_t pitch,
+                       hipEvent_t evUploaded = nullptr, hipStream_t sIn = nullptr)
 {
     int rc = configure_shape(h, w, hh);
     if (rc) return rc;
@@ -846,12 +964,14 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     src.pyr = h->d_pyr; src.blur = h->d_blur; src.f0 = 0;
     // the pyramid/blur buffers use the geometry's per-frame sizes as pitch
     hipStream_t s0 = h->stream;
-    const int nsplit = h->serial ? 1 : std::min(h->nsplit, B);
+    if (!sIn) sIn = s0;
+    const int nsplit = h->serial || B <= 2 ? 1 : std::min(h->nsplit, B);
+    const bool lat = !h->serial && B <= 2 && g.nlevels > 1;
     // Sub-batch p owns stream streamP[p] across calls: it follows its own previous work (its frames' scratch
-    // buffers) and the upload on the host-facing stream, nothing else -- the next batch's pyramid of sub-batch 0
-    // starts while this batch's sub-batch 1 is still in its quadtree.  Consumers join through evPart (join_parts).
-    if (evUploaded) HIPCHK(hipStreamWaitEvent(s0, evUploaded, 0));  // host path: the frames arrive on the copy stream
-    if (!h->serial) HIPCHK(hipEventRecord(h->evStart, s0));
+    // buffers) and the upload, nothing else -- the next batch's pyramid of sub-batch 0 starts while this batch's
+    // sub-batch 1 is still in its quadtree.  Consumers join through evPart (join_parts).
+    if (evUploaded) HIPCHK(hipStreamWaitEvent(sIn, evUploaded, 0));  // host path, throughput mode: the frames arrive on the copy stream
+    if (!h->serial) HIPCHK(hipEventRecord(h->evStart, sIn));
     // A frame's scratch (pyramid and blur levels, candidate segments, kept records) is ordered between two calls by
     // the stream of the sub-batch that owns the frame.  When the batch size -- and with it the frame -> sub-batch
     // map -- changes between two calls that the caller did not separate by a sync, a frame can change hands: its new
@@ -867,86 +987,62 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     h->lastParts = 0;
     h->curSet ^= 1;
     const int set = h->curSet;
-    for (int part = 0; part < nsplit; part++) {
-        const int f0 = (int)((int64_t)B * part / nsplit), f1 = (int)((int64_t)B * (part + 1) / nsplit);
-        const int nb = f1 - f0;
-        if (nb <= 0) continue;
-        hipStream_t s = h->serial ? s0 : h->streamP[part];
-        hipStream_t s2 = h->serial ? s : s0;  // blur: see orbx_create on the choice of streams
-        if (!h->serial) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
-        src.f0 = f0;
-        auto launch_fast = [&](hipStream_t fs, int cell0, int ncells) {
-            if (ncells <= 0) return;
-            const bool l0 = cell0 == 0 && ncells == g.lv[0].nCells;  // the level-0 launch
-            const int rows = l0 ? h->tileRows0 : h->tileRows, cap = l0 ? h->fastListCap0 : h->fastListCap;
-            const size_t lds = (size_t)2 * (rows * h->tileStrideDw + 4) * 4 + (size_t)cap * 2;
-            h->prof.begin(P_FAST, fs);
-            if (h->tileStrideDw == 12)
-                hipLaunchKernelGGL(k_fast<48>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
-                                   h->d_cellCount, h->d_err, rows, cap, nb, cell0);
-            else
-                hipLaunchKernelGGL(k_fast<80>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
-                                   h->d_cellCount, h->d_err, rows, cap, nb, cell0);
-            h->prof.end(fs);
-        };
-        // FAST of level 0 needs no pyramid: on the blur stream it runs beside the (latency-bound) pyramid kernel.
-        // It overwrites this sub-batch's candidate segments, which the previous batch's quadtree read.
-        const int cellsL0 = g.lv[0].nCells;
-        const bool splitFast = !h->serial && g.nlevels > 1;
-        if (splitFast) {
-            if (h->partEverRan[part]) HIPCHK(hipStreamWaitEvent(s2, h->evPart[part], 0));
-            launch_fast(s2, 0, cellsL0);
-            HIPCHK(hipEventRecord(h->evFast0[part], s2));
-        } else {
-            launch_fast(s, 0, cellsL0);
-        }
-        if (g.nlevels > 1 && h->pyrFused) {
-            const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
-            h->prof.begin(P_RESIZE, s);
-            hipLaunchKernelGGL(k_pyramid, dim3(h->pyrBlocks, nb), dim3(256), pl, s, h->d_geom, src, h->tabs,
-                               (const PyrRange*)h->d_pyrRanges, h->pyrBufA, h->pyrBufB, h->pyrTabCap);
-            h->prof.end(s);
-        } else {
-            for (int l = 1; l < g.nlevels; l++) {
-                h->prof.begin(P_RESIZE, s);
-                hipLaunchKernelGGL(k_resize_level, dim3((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nb), dim3(64, 4, 1), 0, s,
-                                   h->d_geom, src, h->tabs, l);
-                h->prof.end(s);
+    const int cellsL0 = g.lv[0].nCells;
+    if (lat) {
+        hipStream_t sm = h->streamP[0], sa = s0;
+        Launcher L{h, src, B};
+        if (sIn != sm) HIPCHK(hipStreamWaitEvent(sm, h->evStart, 0));
+        if (sIn != sa) HIPCHK(hipStreamWaitEvent(sa, h->evStart, 0));
+        // aux: level 0 needs no pyramid.  (The previous call's quadtree and descriptors, which read what these two
+        // overwrite, ran on `sm` in front of the upload / evStart that `sa` has just been made to follow.)
+        if (sIn == sa && h->partEverRan[0]) HIPCHK(hipStreamWaitEvent(sa, h->evPart[0], 0));
+        L.fast(sa, 0, cellsL0);
+        L.dist(sa, 0, 1);
+        if ((rc = L.pyramid(sm, h->evPyr[0]))) return rc;
+        L.fast(sm, cellsL0, g.totalCells - cellsL0);
+        L.dist(sm, 1, g.nlevels - 1);
+        HIPCHK(hipStreamWaitEvent(sa, h->evPyr[0], 0));
+        L.blur(sa);
+        HIPCHK(hipEventRecord(h->evFast0[0], sa));  // the aux chain is through
+        HIPCHK(hipStreamWaitEvent(sm, h->evFast0[0], 0));
+        if ((rc = L.desc(sm, set, h->evPart[h->lastParts++]))) return rc;
+        h->partEverRan[0] = true;
+    } else {
+        for (int part = 0; part < nsplit; part++) {
+            const int f0 = (int)((int64_t)B * part / nsplit), f1 = (int)((int64_t)B * (part + 1) / nsplit);
+            const int nb = f1 - f0;
+            if (nb <= 0) continue;
+            hipStream_t s = h->serial ? s0 : h->streamP[part];
+            hipStream_t s2 = h->serial ? s : s0;  // blur: see orbx_create on the choice of streams
+            if (!h->serial) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
+            if (!h->serial && sIn != s0 && part == 0) HIPCHK(hipStreamWaitEvent(s0, h->evStart, 0));
+            src.f0 = f0;
+            Launcher L{h, src, nb};
+            // FAST of level 0 needs no pyramid: on the blur stream it runs beside the (latency-bound) pyramid kernel.
+            // It overwrites this sub-batch's candidate segments, which the previous batch's quadtree read.
+            const bool splitFast = !h->serial && g.nlevels > 1;
+            if (splitFast) {
+                if (h->partEverRan[part]) HIPCHK(hipStreamWaitEvent(s2, h->evPart[part], 0));
+                L.fast(s2, 0, cellsL0);
+                HIPCHK(hipEventRecord(h->evFast0[part], s2));
+            } else {
+                L.fast(s, 0, cellsL0);
             }
+            if ((rc = L.pyramid(s))) return rc;
+            // blur only needs the pyramid: run it on a second stream beside FAST + quadtree
+            HIPCHK(hipEventRecord(h->evPyr[part], s));
+            HIPCHK(hipStreamWaitEvent(s2, h->evPyr[part], 0));
+            L.blur(s2);
+            HIPCHK(hipEventRecord(h->evBlur[part], s2));
+            // FAST of levels >= 1 behind the pyramid (level 0 went ahead, see above)
+            L.fast(s, cellsL0, g.totalCells - cellsL0);
+            if (splitFast) HIPCHK(hipStreamWaitEvent(s, h->evFast0[part], 0));
+            L.dist(s, 0, g.nlevels);
+            HIPCHK(hipStreamWaitEvent(s, h->evBlur[part], 0));
+            if ((rc = L.desc(s, set))) return rc;
+            HIPCHK(hipEventRecord(h->evPart[h->lastParts++], s));
+            h->partEverRan[part] = true;
         }
-        // blur only needs the pyramid: run it on a second stream beside FAST + quadtree
-        HIPCHK(hipEventRecord(h->evPyr[part], s));
-        HIPCHK(hipStreamWaitEvent(s2, h->evPyr[part], 0));
-        h->prof.begin(P_BLUR, s2);
-        hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[g.nlevels], xcd_grid_y(nb)), dim3(256), 0, s2, h->d_geom, src, h->blurTiles, nb);
-        h->prof.end(s2);
-        HIPCHK(hipEventRecord(h->evBlur[part], s2));
-        // FAST of levels >= 1 behind the pyramid (level 0 went ahead, see above)
-        launch_fast(s, cellsL0, g.totalCells - cellsL0);
-        if (splitFast) HIPCHK(hipStreamWaitEvent(s, h->evFast0[part], 0));
-        h->prof.begin(P_DISTRIBUTE, s);
-        {
-            const size_t dl = dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel);
-            if (h->distInLds)
-                hipLaunchKernelGGL(k_distribute<true>, dim3(g.nlevels, nb), dim3(kDistThreads), dl, s, h->d_geom, h->d_candRaw,
-                                   h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept, h->d_keptCount,
-                                   h->d_err, h->nodeCap, f0, (uint32_t*)nullptr, 0);
-            else
-                hipLaunchKernelGGL(k_distribute<false>, dim3(g.nlevels, nb), dim3(kDistThreads), 0, s, h->d_geom, h->d_candRaw,
-                                   h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept, h->d_keptCount,
-                                   h->d_err, h->nodeCap, f0, h->d_distScratch + (size_t)f0 * g.nlevels * (dl / 4), (int)(dl / 4));
-        }
-        h->prof.end(s);
-        HIPCHK(hipStreamWaitEvent(s, h->evBlur[part], 0));
-        // the output slots are still being read by the previous batch's matching on stream3
-        if (h->matchPending[set]) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set], 0));  // the matching two batches back read this set
-        if (h->evOutOfSet[set]) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));  // ... and so did its download (host path)
-        h->prof.begin(P_ORIENT_DESC, s);
-        hipLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, xcd_grid_y(nb)), dim3(256), 0, s, h->d_geom, src, h->kpBlocks, h->d_kept,
-                           h->d_keptCount, r_kps(h, set) + h->maxKp, r_desc(h, set) + (size_t)h->maxKp * 32, r_count(h, set) + 1, nb);
-        h->prof.end(s);
-        HIPCHK(hipEventRecord(h->evPart[h->lastParts++], s));
-        h->partEverRan[part] = true;
     }
     HIPCHK(hipGetLastError());
     h->lastB = B;
@@ -1058,7 +1154,7 @@ static int ensure_slots(orbx_handle* h)
     const unsigned hc = std::thread::hardware_concurrency();
     int nth = hc > 8 ? 6 : (hc > 2 ? (int)hc / 2 : 0);
     if (const char* e = getenv("ORBX_COPY_THREADS")) nth = atoi(e);
-    if (nth > 0) h->pool.start(std::min(nth, 16));
+    if (nth > 0) h->pool.start(std::min(nth, 16), h->device);
     h->slotsReady = true;
     return ORBX_OK;
 }
@@ -1130,7 +1226,12 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
 
     const int dstride = align_up(w, 64);
     const size_t dpitch = (size_t)dstride * hh;
-    hipStream_t up = h->streamUp;
+    // One or two frames per call is the latency mode: the chain upload -> kernels -> results IS the call, so the frame
+    // goes up on the stream its first kernel runs on (no event hop) and the results come back through one kernel that
+    // writes the pinned host buffer (k_pack_host) instead of six copies.  Larger batches are the throughput mode: copy
+    // streams of their own, so that the DMA of neighbouring batches runs beside the kernels.
+    const bool lat = B <= 2 && !h->serial;
+    hipStream_t up = lat ? h->streamP[0] : h->streamUp;  // latency mode: the stream of the pyramid, the chain's first kernel
     h->prof.begin(P_H2D, up);
     const bool pinned = is_pinned(imgs[0]);
     bool contiguous = true;  // frames back to back at a constant pitch of whole rows
@@ -1145,19 +1246,9 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
             if (f && !is_pinned(imgs[f])) return fail(ORBX_E_INVALID, "frame %d is pageable, frame 0 pinned: one kind per batch", f);
             HIPCHK(hipMemcpy2DAsync(sl.d_in + f * dpitch, dstride, imgs[f], stride, w, hh, hipMemcpyHostToDevice, up));
         }
-    } else if (B <= 2) {
-        // latency path: the pageable frame is staged in row chunks, each on its way while the next is copied
-        constexpr int kChunks = 4;
-        for (int f = 0; f < B; f++)
-            for (int c = 0; c < kChunks; c++) {
-                const int y0 = (int)((int64_t)hh * c / kChunks), y1 = (int)((int64_t)hh * (c + 1) / kChunks);
-                uint8_t* dst = sl.h_in + f * dpitch + (size_t)y0 * dstride;
-                if (stride == dstride) memcpy(dst, imgs[f] + (size_t)y0 * stride, (size_t)(y1 - y0) * stride);
-                else for (int y = y0; y < y1; y++) memcpy(sl.h_in + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
-                HIPCHK(hipMemcpyAsync(sl.d_in + f * dpitch + (size_t)y0 * dstride, dst, (size_t)(y1 - y0) * dstride, hipMemcpyHostToDevice, up));
-            }
     } else {
-        // throughput path: row-band jobs over the copy threads, one DMA for the batch
+        // pageable frames: row-band jobs over the copy threads into the pinned staging, one DMA for the batch
+        // (one 1241x376 frame: 34 us on one core -- 376 row copies -- against ~15 us over four)
         const int bands = 4, jobs = B * bands;
         uint8_t* const hin = sl.h_in;
         h->pool.run(jobs, [=](int j) {
@@ -1165,33 +1256,61 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
             const int y0 = (int)((int64_t)hh * c / bands), y1 = (int)((int64_t)hh * (c + 1) / bands);
             for (int y = y0; y < y1; y++) memcpy(hin + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
         });
+        // (one DMA also in the latency mode: four band DMAs sent off by the workers as they finish were slower --
+        // a copy of this size is mostly its fixed cost, ~7 of 16 us)
         HIPCHK(hipMemcpyAsync(sl.d_in, sl.h_in, dpitch * B, hipMemcpyHostToDevice, up));
     }
     h->prof.end(up);
-    HIPCHK(hipEventRecord(sl.evUp, up));
+    if (!lat) HIPCHK(hipEventRecord(sl.evUp, up));
 
-    if ((rc = run_extract(h, sl.d_in, B, w, hh, dstride, dpitch, sl.evUp))) return rc;
+    if ((rc = run_extract(h, sl.d_in, B, w, hh, dstride, dpitch, lat ? nullptr : sl.evUp, lat ? up : nullptr))) return rc;
     const bool match = opts && opts->match_prev;
-    if (match && (rc = orbx_match_prev_batch_device(h, opts->nnratio, opts->th_low, opts->check_ori))) return rc;
-
-    // download behind the batch's kernels on the second copy stream: full-capacity slots, one pass, no host sync
-    hipStream_t dn = h->streamDown;
     const int set = h->curSet;
-    if ((rc = join_parts(h, dn))) return rc;
-    if (match) HIPCHK(hipStreamWaitEvent(dn, h->evMatch[set], 0));
-    h->prof.begin(P_D2H, dn);
-    HIPCHK(hipMemcpyAsync(sl.h_out, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, dn));
-    HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffN, r_count(h, set) + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, dn));
-    HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffKp, r_kps(h, set) + h->maxKp, (size_t)B * h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToHost, dn));
-    HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffDesc, r_desc(h, set) + (size_t)h->maxKp * 32, (size_t)B * h->maxKp * 32, hipMemcpyDeviceToHost, dn));
-    if (match) {
-        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffNm, h->d_nmatch + (size_t)set * h->maxB, B * sizeof(int32_t), hipMemcpyDeviceToHost, dn));
-        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffMatch, h->d_match + (size_t)set * h->maxB * h->maxKp, (size_t)B * h->maxKp * 4, hipMemcpyDeviceToHost, dn));
+    int32_t* const dm = h->d_match + (size_t)set * h->maxB * h->maxKp;
+    int32_t* const dnm = h->d_nmatch + (size_t)set * h->maxB;
+    hipStream_t outS = nullptr;
+    if (lat) {
+        // One chain on one stream: descriptors -> matching -> the result kernel, which writes the pinned buffer directly
+        // and raises the flag the caller polls -> only then the roll of the previous-frame slot.
+        hipStream_t ps = h->streamP[0];
+        if (match && (rc = match_prev_on(h, ps, opts->nnratio, opts->th_low, opts->check_ori, false))) return rc;
+        PackArgs pa;
+        pa.kps = (const uint32_t*)(r_kps(h, set) + h->maxKp); pa.desc = (const uint32_t*)(r_desc(h, set) + (size_t)h->maxKp * 32);
+        pa.count = r_count(h, set) + 1; pa.match = match ? dm : nullptr; pa.nmatch = match ? dnm : nullptr; pa.err = h->d_err;
+        pa.hKps = (uint32_t*)(sl.h_out + h->outOffKp); pa.hDesc = (uint32_t*)(sl.h_out + h->outOffDesc);
+        pa.hN = (int32_t*)(sl.h_out + h->outOffN); pa.hMatch = (int32_t*)(sl.h_out + h->outOffMatch);
+        pa.hNmatch = (int32_t*)(sl.h_out + h->outOffNm); pa.hErr = (int32_t*)sl.h_out; pa.maxKp = h->maxKp;
+        pa.hFlag = (int32_t*)sl.h_out + 1; pa.flagValue = h->nextTicket + 1; pa.blocksDone = h->d_err + 1;
+        ((volatile int32_t*)sl.h_out)[1] = 0;
+        h->prof.begin(P_D2H, ps);
+        hipLaunchKernelGGL(k_pack_host, dim3(16, B), dim3(256), 0, ps, pa);
+        h->prof.end(ps);
+        HIPCHK(hipEventRecord(sl.evOut, ps));
+        outS = ps;
+        if (match && (rc = roll_prev_on(h, ps, set))) return rc;
+    } else {
+        // download behind the batch's kernels on the second copy stream: full-capacity slots, one pass, no host sync
+        hipStream_t dn = h->streamDown;
+        if ((rc = join_parts(h, dn))) return rc;
+        if (match && (rc = orbx_match_prev_batch_device(h, opts->nnratio, opts->th_low, opts->check_ori))) return rc;
+        if (match) HIPCHK(hipStreamWaitEvent(dn, h->evMatched[set], 0));
+        h->prof.begin(P_D2H, dn);
+        HIPCHK(hipMemcpyAsync(sl.h_out, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, dn));
+        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffN, r_count(h, set) + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, dn));
+        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffKp, r_kps(h, set) + h->maxKp, (size_t)B * h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToHost, dn));
+        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffDesc, r_desc(h, set) + (size_t)h->maxKp * 32, (size_t)B * h->maxKp * 32, hipMemcpyDeviceToHost, dn));
+        if (match) {
+            HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffNm, dnm, B * sizeof(int32_t), hipMemcpyDeviceToHost, dn));
+            HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffMatch, dm, (size_t)B * h->maxKp * 4, hipMemcpyDeviceToHost, dn));
+        }
+        h->prof.end(dn);
+        HIPCHK(hipEventRecord(sl.evOut, dn));
+        outS = dn;
     }
-    h->prof.end(dn);
-    HIPCHK(hipEventRecord(sl.evOut, dn));
+    HIPCHK(hipGetLastError());
     h->evOutOfSet[set] = sl.evOut;
-    sl.state = 1; sl.B = B; sl.matched = match; sl.ticket = h->nextTicket;
+    h->outStream[set] = outS;
+    sl.state = 1; sl.B = B; sl.matched = match; sl.ticket = h->nextTicket; sl.lat = lat;
     *ticket = h->nextTicket++;
     return ORBX_OK;
 }
@@ -1212,7 +1331,15 @@ extern "C" int orbx_collect_view(orbx_t* h, int ticket, OrbxBatchView* view)
     HostSlot* sl;
     if ((rc = slot_of(h, ticket, 1, &sl))) return rc;
     if (!view) return fail(ORBX_E_INVALID, "null view");
-    HIPCHK(hipEventSynchronize(sl->evOut));
+    bool landed = false;
+    if (sl->lat) {
+        // the pack kernel's last block writes ticket + 1 behind the results (system-scope release): polling the pinned
+        // word saves the wake-up of an event wait on the one-frame-per-call path
+        volatile int32_t* flag = (volatile int32_t*)sl->h_out + 1;
+        for (int spin = 0; spin < 400000 && !landed; spin++) { landed = *flag == ticket + 1; if (!landed) __builtin_ia32_pause(); }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (!landed) HIPCHK(hipEventSynchronize(sl->evOut));
     sl->state = 2;
     const int32_t err = *(const int32_t*)sl->h_out;
     view->B = sl->B; view->cap = h->maxKp;
@@ -1345,22 +1472,41 @@ static orbm::MatchIO slots_io(orbx_handle* h, int set)
     return io;
 }
 
-extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low, int check_ori)
+// last frame of the batch in `set` becomes the stream's previous frame: slot 0 of the set the next extraction fills
+static int roll_prev_on(orbx_handle* h, hipStream_t s, int set)
 {
-    int rc = check_device(h);
-    if (rc) return rc;
+    const int B = h->lastB;
+    hipLaunchKernelGGL(k_roll_prev, dim3(16), dim3(256), 0, s, (const uint32_t*)(r_kps(h, set) + (size_t)B * h->maxKp),
+                       (const uint32_t*)(r_desc(h, set) + (size_t)B * h->maxKp * 32), (const int32_t*)(r_count(h, set) + B),
+                       (uint32_t*)r_kps(h, set ^ 1), (uint32_t*)r_desc(h, set ^ 1), r_count(h, set ^ 1));
+    HIPCHK(hipEventRecord(h->evMatch[set], s));
+    HIPCHK(hipGetLastError());
+    h->matchPending[set] = true;
+    h->matchStream[set] = s;
+    h->havePrev = true;
+    return ORBX_OK;
+}
+
+// the matching of the last extracted batch on stream s; roll = false leaves the roll of the previous-frame slot to the
+// caller (the latency path puts the result kernel in front of it)
+static int match_prev_on(orbx_handle* h, hipStream_t s, float nnratio, int th_low, int check_ori, bool roll)
+{
+    int rc;
     const int B = h->lastB;
     if (B < 1) return fail(ORBX_E_INVALID, "no extracted batch to match");
-    // matching runs on its own stream so that the next batch's pyramid/FAST can start beside it
-    hipStream_t s = h->serial ? h->stream : h->stream3;
-    if ((rc = join_parts(h, s))) return rc;
     const int set = h->curSet;
+    // what this stream does not already follow: the batch's descriptors, the previous batch's roll into slot 0 of this
+    // set, the download that last read this set's tables
+    for (int p = 0; p < h->lastParts; p++)
+        if (!(h->lastParts == 1 && h->prevSplit == 1 && !h->serial && s == h->streamP[0])) HIPCHK(hipStreamWaitEvent(s, h->evPart[p], 0));
+    if (h->matchPending[set ^ 1] && h->matchStream[set ^ 1] != s) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set ^ 1], 0));
+    if (h->evOutOfSet[set] && h->outStream[set] != s) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));
     orbm::MatchIO io = slots_io(h, set);
     int32_t* const d_match = h->d_match + (size_t)set * h->maxB * h->maxKp;  // one table per result set: the host path's
     int32_t* const d_nmatch = h->d_nmatch + (size_t)set * h->maxB;           // download of batch n-1 runs beside batch n
-    if (h->evOutOfSet[set]) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));
     h->matchSet = set;
     h->prof.begin(P_MATCH_BEST2, s);
+    bool fused = false;
     // slots 0..B expanded to +-1 bytes, then the Hamming scan as an int8 MFMA product (train slot f, query slot f+1)
     // with the acceptance rule in its epilogue
     const orbm::AcceptArgs aa = {io, io, 1, 0, nnratio, th_low, check_ori, d_match, (int64_t)h->maxKp, h->d_binOf, h->d_hist};
@@ -1373,22 +1519,36 @@ extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low
     } else {
         hipLaunchKernelGGL(orbm::k_expand_desc, dim3((unsigned)(h->xPitch / 4096), B + 1), dim3(256), 0, s, io, 0, 0, r_xdesc(h, set), h->xPitch);
         const int nqb = (h->maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
-        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, s, (const uint8_t*)r_xdesc(h, set), h->xPitch, aa, nqb, B);
+        // few frames (the one-frame-per-call entry): cut the train side into chunks so that the scan fills more than B * nqb CUs
+        int chunks = 1;
+        while (chunks < 8 && (size_t)B * nqb * chunks < 64 && (size_t)B * chunks * 2 <= h->partialSlots) chunks *= 2;
+        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb, chunks), dim3(256), 0, s, (const uint8_t*)r_xdesc(h, set), h->xPitch, aa, nqb, B,
+                           h->d_partial, (int64_t)h->maxKp);
+        fused = chunks > 1;
+        if (fused)  // merge + acceptance + histogram + pruning of a frame in one workgroup
+            hipLaunchKernelGGL(orbm::k_match_accept_prune, dim3(B), dim3(1024), 0, s, aa, chunks, (const uint2*)h->d_partial,
+                               (int64_t)h->maxKp, d_nmatch);
     }
     h->prof.end(s);
-    h->prof.begin(P_MATCH_PRUNE, s);
-    hipLaunchKernelGGL(orbm::k_match_prune, dim3(B), dim3(256), 0, s, io, 1, check_ori, d_match, (int64_t)h->maxKp,
-                       h->d_binOf, h->d_hist, d_nmatch);
-    h->prof.end(s);
-    // last frame of this batch becomes the stream's previous frame: slot 0 of the set the next extraction fills
-    HIPCHK(hipMemcpyAsync(r_kps(h, set ^ 1), r_kps(h, set) + (size_t)B * h->maxKp, (size_t)h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(r_desc(h, set ^ 1), r_desc(h, set) + (size_t)B * h->maxKp * 32, (size_t)h->maxKp * 32, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(r_count(h, set ^ 1), r_count(h, set) + B, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipEventRecord(h->evMatch[set], s));
+    if (!fused) {
+        h->prof.begin(P_MATCH_PRUNE, s);
+        hipLaunchKernelGGL(orbm::k_match_prune, dim3(B), dim3(256), 0, s, io, 1, check_ori, d_match, (int64_t)h->maxKp,
+                           h->d_binOf, h->d_hist, d_nmatch);
+        h->prof.end(s);
+    }
     HIPCHK(hipGetLastError());
-    h->matchPending[set] = true;
-    h->havePrev = true;
+    if (!roll) return ORBX_OK;
+    HIPCHK(hipEventRecord(h->evMatched[set], s));  // the tables are final: the host path's download need not wait for the roll
+    if ((rc = roll_prev_on(h, s, set))) return rc;
     return ORBX_OK;
+}
+
+extern "C" int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low, int check_ori)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    // matching runs on its own stream so that the next batch's pyramid/FAST can start beside it
+    return match_prev_on(h, h->serial ? h->stream : h->stream3, nnratio, th_low, check_ori, true);
 }
 
 extern "C" int orbx_device_matches(orbx_t* h, int32_t** d_match, int32_t** d_nmatch)
@@ -1582,7 +1742,7 @@ extern "C" int orbm_match_bruteforce(orbm_t* h, const uint8_t* qdesc, const floa
         orbm::AcceptArgs am = aa;
         am.tslot0 = 1;
         const int nqb = (nq + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
-        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * nqb), dim3(256), 0, s, (const uint8_t*)h->d_buf[9], xPitch, am, nqb, 1);
+        hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * nqb), dim3(256), 0, s, (const uint8_t*)h->d_buf[9], xPitch, am, nqb, 1, (uint2*)nullptr, (int64_t)0);
     } else {
         hipLaunchKernelGGL(orbm::k_match_best2, dim3((nq + 255) / 256, 1, kMatchChunks), dim3(256), 0, s, q, t, 0, 0, kMatchChunks,
                            (uint2*)h->d_buf[8], (int64_t)nq);

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                                                             int32_t* __restrict__ candCount,
                                                             uint64_t* __restrict__ kept, int32_t* __restrict__ keptCount,
                                                             int32_t* __restrict__ errFlag, int cap, int f0,
-                                                            uint32_t* __restrict__ gscratch, int scratchWords)
+                                                            uint32_t* __restrict__ gscratch, int scratchWords, int l0)
 {
 #ifdef ORBX_DIST_TIMING  // phase timestamps of the level-0 block of frame 0, printed at the end (tools/dist_timing.py)
     __shared__ uint64_t sStamp[96]; __shared__ int sStampId[96]; __shared__ int sNStamp;
@@ -601,8 +601,9 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
 #define STAMP(id) do {} while (0)
 #endif
     extern __shared__ uint32_t smem_lds[];
-    uint32_t* const smem = LDS ? smem_lds : gscratch + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * scratchWords;
-    const int l = blockIdx.x, f = blockIdx.y + f0;
+    // the launch covers levels [l0, l0 + gridDim.x): level 0 may go ahead of the others (it needs no pyramid)
+    const int l = blockIdx.x + l0, f = blockIdx.y + f0;
+    uint32_t* const smem = LDS ? smem_lds : gscratch + (int64_t)(blockIdx.y * g->nlevels + l) * scratchWords;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kDistThreads / 64;
     const LevelGeom& L = g->lv[l];
@@ -1465,6 +1466,56 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
             kp.octave = l;
             kp.class_id = -1;
             outKps[(int64_t)f * g->maxKp + o] = kp;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ small movers of the host path
+// The stream's last frame becomes the previous frame of the next batch: slot `src` of one result set -> slot 0 of the
+// other (one launch instead of three device-to-device copies in front of the download).
+__global__ __launch_bounds__(256) void k_roll_prev(const uint32_t* __restrict__ kpsSrc, const uint32_t* __restrict__ descSrc,
+                                                  const int32_t* __restrict__ countSrc, uint32_t* __restrict__ kpsDst,
+                                                  uint32_t* __restrict__ descDst, int32_t* __restrict__ countDst)
+{
+    const int n = *countSrc;
+    const int t = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+    for (int i = t; i < 7 * n; i += step) kpsDst[i] = kpsSrc[i];
+    for (int i = t; i < 8 * n; i += step) descDst[i] = descSrc[i];
+    if (t == 0) *countDst = n;
+}
+
+// One-frame-per-call entry: the exact n keypoint records, descriptors and match entries of each frame straight into the
+// caller-visible pinned host buffer (device writes over PCIe) -- one launch instead of six copies of ~18 us each.
+struct PackArgs {
+    const uint32_t* kps; const uint32_t* desc; const int32_t* count;   // first frame of the batch (slot 1 of the set)
+    const int32_t* match; const int32_t* nmatch; const int32_t* err;   // match / nmatch may be null
+    uint32_t* hKps; uint32_t* hDesc; int32_t* hN; int32_t* hMatch; int32_t* hNmatch; int32_t* hErr;
+    int32_t* hFlag; int32_t flagValue; int32_t* blocksDone;  // the last block to finish raises the host flag
+    int maxKp;
+};
+__global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
+{
+    const int f = blockIdx.y;
+    const int n = a.count[f];
+    const int t = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+    const int64_t o = (int64_t)f * a.maxKp;
+    for (int i = t; i < 7 * n; i += step) a.hKps[o * 7 + i] = a.kps[o * 7 + i];
+    for (int i = t; i < 8 * n; i += step) a.hDesc[o * 8 + i] = a.desc[o * 8 + i];
+    if (a.match) for (int i = t; i < n; i += step) a.hMatch[o + i] = a.match[o + i];
+    if (t == 0) {
+        a.hN[f] = n;
+        if (a.nmatch) a.hNmatch[f] = a.nmatch[f];
+        if (f == 0) *a.hErr = *a.err;
+    }
+    // every block's writes are performed system-wide before its arrival is counted; the last arrival publishes
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = gridDim.x * gridDim.y;
+        if (atomicAdd(a.blocksDone, 1) == total - 1) {
+            *a.blocksDone = 0;
+            __threadfence_system();
+            __hip_atomic_store(a.hFlag, a.flagValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -28,7 +28,7 @@ int main()
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0));
         for (int i = 0; i < 20; i++)
-            hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, 0, (const uint8_t*)d_x, xPitch, aa, nqb, B);
+            hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, 0, (const uint8_t*)d_x, xPitch, aa, nqb, B, (uint2*)nullptr, (int64_t)0);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("k_match_mfma: %.1f us per launch\n", ms * 1000 / 20);
