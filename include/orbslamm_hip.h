@@ -271,6 +271,17 @@ int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
                               const uint8_t* tdesc, int nt,
                               uint8_t* t_occ, int32_t* assign, int* nmatches);
 
+/* The same with the stereo / RGB-D gate of modes 3 and 4 (src/ORBmatcher.cc:91-96, :1409-1415): a train feature with
+ * t_uright[t] > 0 (Frame::mvuRight) is skipped when |q_ur[q] - t_uright[t]| > radius of the query (q_uvr[3q+2]);
+ * q_ur = MapPoint::mTrackProjXR (mode 3) resp. u - mbf * invzc (mode 4).  Both NULL = the mono call above. */
+int orbm_search_by_projection_stereo(orbm_t* h, const OrbmProjParams* pp,
+                                     const float* q_uvr, const float* q_ur, const int8_t* q_lvl,
+                                     const uint8_t* qdesc, const float* qangle,
+                                     const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                                     const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un,
+                                     const uint8_t* tdesc, const float* t_uright, int nt,
+                                     uint8_t* t_occ, int32_t* assign, int* nmatches);
+
 /* ---- the remaining ORBmatcher entry points on the same primitive ---- */
 
 /* Independent windowed best search, the device part of

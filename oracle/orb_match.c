@@ -244,6 +244,21 @@ int orc_search_by_projection(const OrcProjParams* pp,
                              const uint8_t* tdesc, int nt,
                              uint8_t* t_occ, int32_t* assign)
 {
+    return orc_search_by_projection_stereo(pp, q_uvr, NULL, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, gp, tk, cell_start,
+                                           cell_idx, tdesc, NULL, nt, t_occ, assign);
+}
+
+/* with the stereo gate of ref:91-96 (mode 3: er = |mTrackProjXR - mvuRight|, er > r*scale -> skip) and ref:1409-1415
+ * (mode 4: ur = u - mbf*invzc, er > radius -> skip); q_ur / t_uright NULL = mono */
+int orc_search_by_projection_stereo(const OrcProjParams* pp,
+                             const float* q_uvr, const float* q_ur, const int8_t* q_lvl,
+                             const uint8_t* qdesc, const float* qangle,
+                             const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                             const OrcGridParams* gp, const OrcKeyPoint* tk,
+                             const int32_t* cell_start, const int32_t* cell_idx,
+                             const uint8_t* tdesc, const float* t_uright, int nt,
+                             uint8_t* t_occ, int32_t* assign)
+{
     RotHist rh; rh_init(&rh);
     int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt + 1));
     int nmatches = 0;
@@ -258,6 +273,10 @@ int orc_search_by_projection(const OrcProjParams* pp,
         for (int c = 0; c < nc; c++) {
             const int t = cand[c];
             if (t_occ[t]) continue;
+            if (t_uright && t_uright[t] > 0) {
+                const float er = fabsf(q_ur[q] - t_uright[t]);
+                if (er > r) continue;
+            }
             const int dist = orc_descriptor_distance(qdesc + 32 * (size_t)q, tdesc + 32 * (size_t)t);
             if (dist < best) {
                 best2 = best; best = dist;

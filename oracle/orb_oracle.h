@@ -174,6 +174,15 @@ int  orc_search_by_projection(const OrcProjParams* pp,
                               const uint8_t* tdesc, int nt,
                               uint8_t* t_occ, int32_t* assign);
 
+int  orc_search_by_projection_stereo(const OrcProjParams* pp,
+                              const float* q_uvr, const float* q_ur, const int8_t* q_lvl,
+                              const uint8_t* qdesc, const float* qangle,
+                              const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                              const OrcGridParams* gp, const OrcKeyPoint* t_keys_un,
+                              const int32_t* cell_start, const int32_t* cell_idx,
+                              const uint8_t* tdesc, const float* t_uright, int nt,
+                              uint8_t* t_occ, int32_t* assign);
+
 /* ---- the remaining matchers on the same primitive ---- */
 
 /* Independent windowed best search shared by Fuse (ORBmatcher.cc:827-975, chi2=1),

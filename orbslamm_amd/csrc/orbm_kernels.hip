@@ -700,6 +700,7 @@ struct ProjArgs {
     const float* quvr; const int8_t* qlvl; const uint8_t* qdesc; const float* qang;
     const uint8_t* qvalid; const uint8_t* qobs;
     const uint8_t* tdesc;
+    const float* qur; const float* turight;   // stereo gate of modes 3/4 (null for mono): |q_ur - mvuRight[t]| <= radius
     int32_t nq, nt;
     int32_t* candCnt;      // [nq]   pass 1
     int32_t* candOff;      // [nq+1] after scan
@@ -718,9 +719,17 @@ __global__ void k_proj_candidates(ProjArgs a, int pass)
     if (a.qvalid && !a.qvalid[q]) { if (pass == 0) a.candCnt[q] = 0; return; }
     const float u = a.quvr[3 * q], v = a.quvr[3 * q + 1], r = a.quvr[3 * q + 2];
     const int minL = a.qlvl[2 * q], maxL = a.qlvl[2 * q + 1];
+    // ORBmatcher.cc:91-96 / :1409-1415: a train feature with a right coordinate (mvuRight > 0) must also agree in it.
+    // The test is independent of everything the sequential pass decides, so it is applied here, on both passes alike.
+    const float qur = a.turight ? a.qur[q] : 0.f;
+    auto stereo_ok = [&](int t) {
+        if (!a.turight) return true;
+        const float tr = a.turight[t];
+        return !(tr > 0.f) || !(fabsf(__fsub_rn(qur, tr)) > r);
+    };
     if (pass == 0) {
         int cnt = 0;
-        for_each_in_area(a.grid, a.tkeys, a.cellStart, a.cellIdx, u, v, r, minL, maxL, [&](int) { cnt++; });
+        for_each_in_area(a.grid, a.tkeys, a.cellStart, a.cellIdx, u, v, r, minL, maxL, [&](int t) { if (stereo_ok(t)) cnt++; });
         a.candCnt[q] = cnt;
     } else {
         uint32_t qw[8];
@@ -730,6 +739,7 @@ __global__ void k_proj_candidates(ProjArgs a, int pass)
         int pos = 0;
         const int base = a.candOff[q];
         for_each_in_area(a.grid, a.tkeys, a.cellStart, a.cellIdx, u, v, r, minL, maxL, [&](int t) {
+            if (!stereo_ok(t)) return;
             const int d = hamming256(qw, (const uint32_t*)(a.tdesc + (int64_t)t * 32));
             a.candKey[base + pos] = ((uint32_t)d << 22) | ((uint32_t)(pos & 0x3FFFF) << 4) | (uint32_t)(a.tkeys[t].octave & 15);
             a.candIdx[base + pos] = t;

@@ -1797,7 +1797,7 @@ static int bow_core(orbm_handle* h, const BowSide& q, const uint8_t* qvalid, con
     HIPCHK(hipMemsetAsync(h->d_buf[S_MATCHED], 0, (size_t)nt, s));
     HIPCHK(hipMemsetAsync(h->d_buf[S_MATCH], 0xFF, (size_t)nout * 4, s));
     HIPCHK(hipMemsetAsync(h->d_buf[S_HIST], 0, 34 * 4, s));
-    orbm::BowArgs a;
+    orbm::BowArgs a{};
     a.qdesc = q.d_desc; a.qang = q.d_ang;
     a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
     a.tdesc = t.d_desc; a.tang = t.d_ang;
@@ -1928,7 +1928,7 @@ struct ProjTrain {
 
 static int proj_core(orbm_handle* h, const OrbmProjParams* pp, const float* q_uvr, const int8_t* q_lvl, const uint8_t* qdesc,
                      const float* qangle, const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq, const ProjTrain& tr,
-                     uint8_t* t_occ, int32_t* assign, int* nmatches)
+                     uint8_t* t_occ, int32_t* assign, int* nmatches, const float* q_ur = nullptr, const float* t_uright = nullptr)
 {
     int rc;
     const int nt = tr.nt;
@@ -1943,7 +1943,15 @@ static int proj_core(orbm_handle* h, const OrbmProjParams* pp, const float* q_uv
     if (qvalid) UP(S_QV, qvalid, (size_t)nq);
     if (q_obs_pos) UP(S_QO, q_obs_pos, (size_t)nq);
     UP(S_OCC, t_occ, (size_t)nt); UP(S_ASSIGN, assign, (size_t)nt * 4);
-    orbm::ProjArgs a;
+    enum { S_QUR = 21, S_TUR = 22 };
+    const bool stereo = q_ur && t_uright;
+    if (stereo) {
+        if ((rc = orbm_reserve(h, S_QUR, (size_t)nq * 4)) || (rc = orbm_reserve(h, S_TUR, (size_t)nt * 4))) return rc;
+        UP(S_QUR, q_ur, (size_t)nq * 4); UP(S_TUR, t_uright, (size_t)nt * 4);
+    }
+    orbm::ProjArgs a{};
+    a.qur = stereo ? (const float*)h->d_buf[S_QUR] : nullptr;
+    a.turight = stereo ? (const float*)h->d_buf[S_TUR] : nullptr;
     a.grid = tr.gd;
     a.tkeys = tr.keys;
     a.cellStart = tr.cellStart; a.cellIdx = tr.cellIdx;
@@ -2003,9 +2011,23 @@ extern "C" int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
                                          const uint8_t* tdesc, int nt,
                                          uint8_t* t_occ, int32_t* assign, int* nmatches)
 {
+    return orbm_search_by_projection_stereo(h, pp, q_uvr, nullptr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, grid, t_keys_un,
+                                            tdesc, nullptr, nt, t_occ, assign, nmatches);
+}
+
+extern "C" int orbm_search_by_projection_stereo(orbm_t* h, const OrbmProjParams* pp,
+                                                const float* q_uvr, const float* q_ur, const int8_t* q_lvl,
+                                                const uint8_t* qdesc, const float* qangle,
+                                                const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
+                                                const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un,
+                                                const uint8_t* tdesc, const float* t_uright, int nt,
+                                                uint8_t* t_occ, int32_t* assign, int* nmatches)
+{
     int rc = proj_check(h, pp, q_uvr, q_lvl, qdesc, qangle, nq, nt, t_occ, assign, nmatches);
     if (rc) return rc;
     if (nt && (!t_keys_un || !tdesc)) return fail(ORBX_E_INVALID, "bad argument");
+    if ((q_ur != nullptr) != (t_uright != nullptr)) return fail(ORBX_E_INVALID, "q_ur and t_uright go together");
+    if (q_ur && pp->mode != 3 && pp->mode != 4) return fail(ORBX_E_INVALID, "only modes 3 and 4 have a stereo gate");
     if (nq == 0 || nt == 0) return ORBX_OK;
     ProjTrain tr;
     if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, tr.gd))) return rc;
@@ -2016,7 +2038,7 @@ extern "C" int orbm_search_by_projection(orbm_t* h, const OrbmProjParams* pp,
     tr.cellStart = (const int32_t*)h->d_buf[G_START]; tr.cellIdx = (const int32_t*)h->d_buf[G_IDX];
     tr.desc = (const uint8_t*)h->d_buf[6];
     tr.nt = nt;
-    return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, tr, t_occ, assign, nmatches);
+    return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, tr, t_occ, assign, nmatches, q_ur, t_uright);
 }
 
 // ------------------------------------------------------------------ the Frame's matcher-side state in HBM
@@ -2138,7 +2160,7 @@ extern "C" int orbm_window_best(orbm_t* h, const float* q_uvr, const float* q_ur
     if (qvalid) UP(S_QV, qvalid, (size_t)nq);
     if (t_uright) UP(S_TUR, t_uright, (size_t)nt * 4);
     if (chi2) UP(S_SIG, inv_sigma2, (size_t)nlevels * 4);
-    orbm::WinArgs a;
+    orbm::WinArgs a{};
     a.grid = gd;
     a.tkeys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
     a.cellStart = (const int32_t*)h->d_buf[G_START]; a.cellIdx = (const int32_t*)h->d_buf[G_IDX];
@@ -2175,7 +2197,7 @@ static int init_core(orbm_handle* h, const float* q_xy, float window_size, const
     for (int i = 0; i < 11; i++) if ((rc = orbm_reserve(h, slots[i], sizes[i]))) return rc;
     hipStream_t s = h->stream;
     UP(S_UVR, uvr.data(), (size_t)nq * 12); UP(S_LVL, lvl.data(), (size_t)nq * 2);
-    orbm::ProjArgs a;
+    orbm::ProjArgs a{};
     a.grid = tr.gd;
     a.tkeys = tr.keys;
     a.cellStart = tr.cellStart; a.cellIdx = tr.cellIdx;
@@ -2307,7 +2329,7 @@ extern "C" int orbm_search_for_triangulation(orbm_t* h,
     UP(S_PA, pa.data(), (size_t)npairs * 4); UP(S_PB, pb.data(), (size_t)npairs * 4);
     HIPCHK(hipMemsetAsync(h->d_buf[S_M12], 0xFF, (size_t)n1 * 4, s));
     HIPCHK(hipMemsetAsync(h->d_buf[S_HIST], 0, 34 * 4, s));
-    orbm::TriArgs a;
+    orbm::TriArgs a{};
     a.k1 = (const orbm::KeyDev*)h->d_buf[S_K1]; a.d1 = (const uint8_t*)h->d_buf[S_D1];
     a.skip1 = skip1 ? (const uint8_t*)h->d_buf[S_S1] : nullptr; a.ur1 = uright1 ? (const float*)h->d_buf[S_U1] : nullptr;
     a.k2 = (const orbm::KeyDev*)h->d_buf[S_K2]; a.d2 = (const uint8_t*)h->d_buf[S_D2];

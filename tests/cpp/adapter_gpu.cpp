@@ -39,7 +39,7 @@ int main()
     std::vector<float> ang(n);
     for (int i = 0; i < n; i++) ang[i] = kps[i].angle;
     iORB_SLAM::FlatFeatVec fq = iORB_SLAM::FlatFeatVec::from(fvq), ft = iORB_SLAM::FlatFeatVec::from(fvt);
-    iORB_SLAM::ORBmatcher m(0.75f, true, 0);
+    iORB_SLAM::FlatMatcher m(0.75f, true, 0);
     std::vector<int32_t> match;
     const int nm = m.SearchByBoW(desc.data(), ang.data(), nullptr, n, fq, d2.data(), ang.data(), nullptr, n, ft, true, match);
     std::vector<int32_t> omatch(n);

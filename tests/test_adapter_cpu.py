@@ -23,3 +23,19 @@ def test_cpp_adapter_builds_and_runs(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "adapter ok" in out.stdout and "no CPU fallback" in out.stderr
+
+
+def test_orbmatcher_dropin_template_instantiates(tmp_path):
+    """ORBmatcherT<Frame, KeyFrame, MapPoint> with all eleven reference signatures compiles against mock types that
+    carry the reference's member names (no OpenCV, no GPU needed to build; the run is a -m gpu test)"""
+    from oracle import binding as ob
+    ob.build()
+    exe = str(tmp_path / "dropin")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "matcher_dropin_gpu.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "orbslamm_amd"), "-lorbslamm_hip", "-L", os.path.join(ROOT, "oracle"), "-lorb_oracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "orbslamm_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    syms = subprocess.check_output(["nm", "-C", exe]).decode()
+    for member in ("SearchByProjection", "SearchByBoW", "SearchForInitialization", "SearchForTriangulation", "SearchBySim3", "Fuse"):
+        assert "ORBmatcherT<mock::Frame, mock::KeyFrame, mock::MapPoint>::" + member in syms, member

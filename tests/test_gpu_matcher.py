@@ -254,6 +254,28 @@ def test_cpp_adapters_on_gpu(gpu, tmp_path):
     assert "adapter_gpu ok" in out.stdout
 
 
+def test_orbmatcher_dropin_all_eleven_signatures(gpu, tmp_path):
+    """include/ORBmatcher_hip.hpp: ORBmatcherT<Frame, KeyFrame, MapPoint> -- the reference's eleven ORBmatcher members
+    (ORBmatcher.h:48-83) instantiated on mock objects with the reference's member names, run on the GPU; the flattened
+    arrays each member produced go through the C oracle (identical device results), the write-back into the object
+    graph is replayed on a copy of the world, the projections are recomputed in double (tests/cpp/matcher_dropin_gpu.cpp)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from oracle import binding as ob
+    ob.build()
+    exe = str(tmp_path / "matcher_dropin_gpu")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "matcher_dropin_gpu.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "orbslamm_amd"), "-lorbslamm_hip", "-L", os.path.join(root, "oracle"), "-lorb_oracle",
+                           "-Wl,-rpath," + os.path.join(root, "orbslamm_amd"), "-Wl,-rpath," + os.path.join(root, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    assert "matcher_dropin_gpu ok" in out.stdout
+    assert out.stdout.count("\n") >= 17  # one line per member variant
+
+
 def test_undistort_keypoints_parity(gm, oracle):
     """TUM1.yaml calibration (fx 517.3, fy 516.5, cx 318.6, cy 255.3, k1 0.2624 k2 -0.9531 p1 -0.0054 p2 0.0026 k3 1.1633)"""
     rng = np.random.default_rng(501)
