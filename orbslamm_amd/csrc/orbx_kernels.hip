@@ -360,112 +360,128 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     __syncthreads();
 
     const int dw = cw - 6, dh = ch - 6;  // detection area
-    int th = g->iniTh < 0 ? 0 : (g->iniTh > 255 ? 255 : g->iniTh);
+    const int th1 = g->iniTh < 0 ? 0 : (g->iniTh > 255 ? 255 : g->iniTh);
     const int th2 = g->minTh < 0 ? 0 : (g->minTh > 255 ? 255 : g->minTh);
-    const int tq = min(th, th2);
     constexpr int pos0 = 3 * TSB + 4;  // tile byte offset of detection pixel (0,0)
-
-    // stage 1: list entries are (side << 14 | y << 7 | x), side 1 = bright.  Ballots are taken of
-    // bare compares and combined on the scalar unit (a ballot of a derived bool costs two VALU ops).
-    int nA = 0, nB = 0;
-    for (int xb = 0; xb < dw; xb += 32) {
-        const int x4 = xb + 4 * (lane & 7);
-        uint64_t mX[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) mX[k] = ballot64(x4 + k < dw);
-        for (int y0 = 0; y0 < dh; y0 += 8) {
-            const int y = y0 + (lane >> 3);
-            const bool rowOk = y < dh;
-            const uint64_t mY = ballot64(y < dh);
-            const uint32_t* q = tile + (rowOk ? y : 0) * TSD + (x4 >> 2);
-            const uint32_t N = q[1], C0 = q[3 * TSD], C1 = q[3 * TSD + 1], C2 = q[3 * TSD + 2], S = q[6 * TSD + 1];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int v = (C1 >> (8 * k)) & 0xFF;
-                const int pn = (N >> (8 * k)) & 0xFF, ps = (S >> (8 * k)) & 0xFF;
-                const int pw = k < 3 ? (C0 >> (8 * (k + 1))) & 0xFF : C1 & 0xFF;
-                const int pe = k == 0 ? C1 >> 24 : (C2 >> (8 * (k - 1))) & 0xFF;
-                const int hi = min(max(pn, ps), max(pw, pe));   // bright: hi - v > tq
-                const int lo = max(min(pn, ps), min(pw, pe));   // dark:   v - lo > tq
-                const bool br = hi - v > tq, dk = v - lo > tq;
-                const uint64_t mIn = mX[k] & mY, mBr = ballot64(br), mDk = ballot64(dk);
-                const uint64_t balA = (mBr ^ mDk) & mIn, balB = mBr & mDk & mIn;
-                const bool in = rowOk && x4 + k < dw;
-                const int e = (y << 7) | (x4 + k);
-                if (balA) {
-                    if (in && br != dk) list[nA + lanes_below(balA)] = (uint16_t)(e | (br ? 0x4000 : 0));
-                    nA += __popcll(balA);
-                }
-                if (balB) {
-                    if (in && br && dk) list[listCap - 1 - nB - lanes_below(balB)] = (uint16_t)e;
-                    nB += __popcll(balB);
-                }
-            }
-        }
-    }
-    __syncthreads();
     // every cell owns a fixed segment of the candidate buffer (no atomics, deterministic layout)
     int32_t* myCount = cellCount + (int64_t)f * g->totalCells + bx;
-    if (nA + nB == 0) { if (lane == 0) *myCount = 0; return; }
-
-    // stage 2: exact score on the dense lists; pixels with S > tq (corners at the lower
-    // threshold) are compacted in place: writes land at or below entries already consumed
-    int nC = 0;
-    if (nA + 2 * nB <= listCap) {
-        // one stream of one-sided entries: the A list, then the B list taken once as dark and once as bright (a pixel
-        // is a corner on one side at most, so the two visits never both write).  The in-place compaction cannot reach
-        // the B entries while they are still to be read: nC <= nA + nB <= listCap - nB.
-        const int nV = nA + 2 * nB;
-        for (int i0 = 0; i0 < nV; i0 += 64) {
-            const int i = i0 + lane;
-            const bool act = i < nV;
-            int e = 0;
-            if (act) {
-                if (i < nA) e = list[i];
-                else { const int j = i - nA; e = j < nB ? list[listCap - nB + j] : (list[listCap - nB + (j - nB)] | 0x4000); }
-            }
-            const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
-            const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
-            const bool corner = act && Sx > tq;
-            const uint64_t bal = ballot64(Sx > tq) & tail_mask(nV - i0);
-            if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
-            nC += __popcll(bal);
-        }
-    } else {
-        for (int i0 = 0; i0 < nA; i0 += 64) {
-            const int i = i0 + lane;
-            const bool act = i < nA;
-            const int e = act ? list[i] : 0;
-            const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
-            const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
-            const bool corner = act && Sx > tq;
-            const uint64_t bal = ballot64(Sx > tq) & tail_mask(nA - i0);
-            if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
-            nC += __popcll(bal);
-        }
-        for (int i0 = 0; i0 < nB; i0 += 64) {  // ascending addresses, see above
-            const int i = i0 + lane;
-            const bool act = i < nB;
-            const int e = act ? list[listCap - nB + i] : 0;
-            const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
-            const int Sx = fast_S<TSB>(tb + pos);
-            const bool corner = act && Sx > tq;
-            const uint64_t bal = ballot64(Sx > tq) & tail_mask(nB - i0);
-            if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
-            nC += __popcll(bal);
-        }
-    }
-    __syncthreads();
-    if (nC == 0) { if (lane == 0) *myCount = 0; return; }
-
-    // stage 3: 3x3 non-max suppression on M_t = (S > t ? S-1 : 0), strict >, zero outside the
-    // detection area (the S map is zero there), fused with the emission; if nothing survives at
-    // iniThFAST, retry at minThFAST (:812-816).  A corner has S > t, so "S > every neighbour with
-    // S > t" is simply S > max of the eight neighbours.
     uint64_t* out = cand + (int64_t)f * g->candFrameRecs + L.candOff + c.candOff;
     const int candCap = ((cw - 6 + 1) >> 1) * ((ch - 6 + 1) >> 1);  // NMS bound = segment size
+    // stage-1 rows of a half-wave: even rows in lanes 0..31, odd rows in lanes 32..63 -- with the 12-dword row pitch the
+    // four 8-dword row segments a 32-lane group reads then fall on 32 distinct banks (rows r and r+3 of the plain
+    // lane >> 3 mapping share four)
+    const int rowInIter = 2 * ((lane >> 3) & 3) + (lane >> 5);
+
+    // The reference runs cv::FAST at iniThFAST and, only if that leaves the cell empty, again at minThFAST (:808-816).
+    // Same here: a pass at threshold t needs the exact score S only where S > t (a pixel with S <= t is neither a
+    // corner nor a neighbour that could suppress one: a corner's S exceeds t), so the compass pre-test, the score and
+    // the corner list all work at t -- at t = 20 a third of the pixels that a combined pass at min(20, 7) would score.
+    // Cells without a corner at iniThFAST pay a second pass; on textured frames they are the minority.
     int total = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+#pragma nounroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int th = pass ? th2 : th1;
+        const bool last = pass == 1 || th1 == th2;
+        if (pass) {  // the first pass's scores (all <= ... > th1) go: the map must hold zeros wherever S <= th
+            __syncthreads();
+            uint2* sm64 = (uint2*)smap;
+            for (int i = lane; i < ch * (TSD / 2); i += 64) sm64[i] = make_uint2(0u, 0u);
+            __syncthreads();
+        }
+        // stage 1: list entries are (side << 14 | y << 7 | x), side 1 = bright.  Ballots are taken of
+        // bare compares and combined on the scalar unit (a ballot of a derived bool costs two VALU ops).
+        int nA = 0, nB = 0;
+        for (int xb = 0; xb < dw; xb += 32) {
+            const int x4 = xb + 4 * (lane & 7);
+            uint64_t mX[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) mX[k] = ballot64(x4 + k < dw);
+            for (int y0 = 0; y0 < dh; y0 += 8) {
+                const int y = y0 + rowInIter;
+                const bool rowOk = y < dh;
+                const uint64_t mY = ballot64(y < dh);
+                const uint32_t* q = tile + (rowOk ? y : 0) * TSD + (x4 >> 2);
+                const uint32_t N = q[1], C0 = q[3 * TSD], C1 = q[3 * TSD + 1], C2 = q[3 * TSD + 2], S = q[6 * TSD + 1];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int v = (C1 >> (8 * k)) & 0xFF;
+                    const int pn = (N >> (8 * k)) & 0xFF, ps = (S >> (8 * k)) & 0xFF;
+                    const int pw = k < 3 ? (C0 >> (8 * (k + 1))) & 0xFF : C1 & 0xFF;
+                    const int pe = k == 0 ? C1 >> 24 : (C2 >> (8 * (k - 1))) & 0xFF;
+                    const int hi = min(max(pn, ps), max(pw, pe));   // bright: hi - v > th
+                    const int lo = max(min(pn, ps), min(pw, pe));   // dark:   v - lo > th
+                    const bool br = hi - v > th, dk = v - lo > th;
+                    const uint64_t mIn = mX[k] & mY, mBr = ballot64(br), mDk = ballot64(dk);
+                    const uint64_t balA = (mBr ^ mDk) & mIn, balB = mBr & mDk & mIn;
+                    const bool in = rowOk && x4 + k < dw;
+                    const int e = (y << 7) | (x4 + k);
+                    if (balA) {
+                        if (in && br != dk) list[nA + lanes_below(balA)] = (uint16_t)(e | (br ? 0x4000 : 0));
+                        nA += __popcll(balA);
+                    }
+                    if (balB) {
+                        if (in && br && dk) list[listCap - 1 - nB - lanes_below(balB)] = (uint16_t)e;
+                        nB += __popcll(balB);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (nA + nB == 0) { if (last) break; else continue; }
+
+        // stage 2: exact score on the dense lists; pixels with S > th (the corners of this pass)
+        // are compacted in place: writes land at or below entries already consumed
+        int nC = 0;
+        if (nA + 2 * nB <= listCap) {
+            // one stream of one-sided entries: the A list, then the B list taken once as dark and once as bright (a pixel
+            // is a corner on one side at most, so the two visits never both write).  The in-place compaction cannot reach
+            // the B entries while they are still to be read: nC <= nA + nB <= listCap - nB.
+            const int nV = nA + 2 * nB;
+            for (int i0 = 0; i0 < nV; i0 += 64) {
+                const int i = i0 + lane;
+                const bool act = i < nV;
+                int e = 0;
+                if (act) {
+                    if (i < nA) e = list[i];
+                    else { const int j = i - nA; e = j < nB ? list[listCap - nB + j] : (list[listCap - nB + (j - nB)] | 0x4000); }
+                }
+                const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+                const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
+                const bool corner = act && Sx > th;
+                const uint64_t bal = ballot64(Sx > th) & tail_mask(nV - i0);
+                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
+                nC += __popcll(bal);
+            }
+        } else {
+            for (int i0 = 0; i0 < nA; i0 += 64) {
+                const int i = i0 + lane;
+                const bool act = i < nA;
+                const int e = act ? list[i] : 0;
+                const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+                const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
+                const bool corner = act && Sx > th;
+                const uint64_t bal = ballot64(Sx > th) & tail_mask(nA - i0);
+                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
+                nC += __popcll(bal);
+            }
+            for (int i0 = 0; i0 < nB; i0 += 64) {  // ascending addresses, see above
+                const int i = i0 + lane;
+                const bool act = i < nB;
+                const int e = act ? list[listCap - nB + i] : 0;
+                const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+                const int Sx = fast_S<TSB>(tb + pos);
+                const bool corner = act && Sx > th;
+                const uint64_t bal = ballot64(Sx > th) & tail_mask(nB - i0);
+                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+                nC += __popcll(bal);
+            }
+        }
+        __syncthreads();
+        if (nC == 0) { if (last) break; else continue; }
+
+        // stage 3: 3x3 non-max suppression on M_t = (S > t ? S-1 : 0), strict >, zero outside the
+        // detection area (the S map is zero there), fused with the emission.  A corner has S > t, so
+        // "S > every neighbour with S > t" is simply S > max of the eight neighbours.
         total = 0;
         for (int i0 = 0; i0 < nC; i0 += 64) {
             const int i = i0 + lane;
@@ -487,8 +503,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             }
             total += __popcll(bal);
         }
-        if (total > 0 || th == th2) break;
-        th = th2;
+        if (total > 0 || last) break;
     }
     if (lane == 0) *myCount = total;
 }
