@@ -155,6 +155,14 @@ int orbx_download(orbx_t* h, int frame, OrbxKeyPoint* kps, uint8_t* desc, int ca
  * dst may be NULL to query the size.  blurred!=0 returns the 7x7 Gaussian-smoothed
  * working image the descriptors were sampled from (src/ORBextractor.cc:1085-1086). */
 int orbx_pyramid_level(orbx_t* h, int frame, int level, int blurred, uint8_t* dst, int* w, int* h_);
+/* void Frame::ComputeStereoMatches()   src/Frame.cc:466-638, on the frames the two extractors (left, right: same
+ * device, same shape and parameters -- Tracking's mpORBextractorLeft / mpORBextractorRight) extracted last: row-band
+ * candidates, best descriptor within one octave and the disparity range [-3, mbf/mb], 11-position SAD search on the
+ * keypoint's pyramid level (the consumer of mvImagePyramid, :561,578), parabola sub-pixel fit, median-distance filter.
+ * u_right[cap] = mvuRight, depth[cap] = mvDepth (-1: no match); *n_left = left keypoints. */
+int orbx_compute_stereo_matches(orbx_t* left, orbx_t* right, int frame, float mb, float mbf,
+                                float* u_right, float* depth, int cap, int* n_left);
+
 /* per-stage dump for parity tests: FAST candidates of one level, packed records
  * (see DESIGN.md "candidate record"), unordered; returns count in *n */
 int orbx_level_candidates(orbx_t* h, int frame, int level, uint64_t* dst, int cap, int* n);

@@ -40,7 +40,7 @@ def build(march_native=False, out_dir=None):
     """compile the oracle; returns the path of the .so"""
     out_dir = out_dir or _HERE
     so = os.path.join(out_dir, "liborb_oracle_native.so" if march_native else "liborb_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orb_extract.c", "orb_match.c", "orb_vocab.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb_extract.c", "orb_match.c", "orb_vocab.c", "orb_stereo.c")]
     deps = srcs + [os.path.join(_HERE, f) for f in ("orb_oracle.h", "brief_pattern.inc")]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps):
         return so
@@ -390,6 +390,38 @@ class Vocabulary:
 
 # ---------------------------------------------------------------- oracle/_ref: the reference's own object code
 REF_SO = os.path.join(_HERE, "_ref", "libdbow2_ref.so")
+
+
+class OrcPyramid(C.Structure):
+    _fields_ = [("nlevels", C.c_int), ("data", C.c_void_p * 16), ("w", C.c_int * 16), ("h", C.c_int * 16), ("stride", C.c_int * 16)]
+
+
+def compute_stereo_matches(keysL, descL, keysR, descR, levelsL, levelsR, scale, inv_scale, mb, mbf, L=None):
+    """Frame::ComputeStereoMatches (Frame.cc:466-638); levelsL / levelsR: lists of contiguous uint8 images (the
+    un-blurred pyramid levels).  Returns (mvuRight, mvDepth, accepted before the median filter)."""
+    L = L or lib()
+    keysL = np.ascontiguousarray(keysL); keysR = np.ascontiguousarray(keysR)
+    descL = np.ascontiguousarray(descL, dtype=np.uint8); descR = np.ascontiguousarray(descR, dtype=np.uint8)
+
+    def pyr(levels):
+        p = OrcPyramid()
+        p.nlevels = len(levels)
+        keep = []
+        for i, im in enumerate(levels):
+            im = np.ascontiguousarray(im, dtype=np.uint8)
+            keep.append(im)
+            p.data[i] = im.ctypes.data
+            p.h[i], p.w[i] = im.shape
+            p.stride[i] = im.shape[1]
+        return p, keep
+    pl, k1 = pyr(levelsL)
+    pr, k2 = pyr(levelsR)
+    sc = np.ascontiguousarray(scale, dtype=np.float32); isc = np.ascontiguousarray(inv_scale, dtype=np.float32)
+    ur = np.zeros(max(len(keysL), 1), dtype=np.float32); dp = np.zeros(max(len(keysL), 1), dtype=np.float32)
+    L.orc_compute_stereo_matches.restype = C.c_int
+    n = L.orc_compute_stereo_matches(_p(keysL), _p(descL), len(keysL), _p(keysR), _p(descR), len(keysR), C.byref(pl), C.byref(pr),
+                                     _p(sc), _p(isc), C.c_float(mb), C.c_float(mbf), _p(ur), _p(dp))
+    return ur[:len(keysL)], dp[:len(keysL)], n
 
 
 def build_ref():

@@ -218,6 +218,21 @@ int  orc_search_for_triangulation(const OrcKeyPoint* k1, const uint8_t* d1, cons
                                   const float* sf2, const float* sigma2_2,
                                   int only_stereo, int check_ori, int32_t* matches12);
 
+/* SURVEY.md 8(f) rank 1, last item: Frame::ComputeStereoMatches (src/Frame.cc:466-638), orb_stereo.c.
+ * pyramids: per level a tight or strided 8-bit image (the un-blurred levels of ComputePyramid, no border needed:
+ * the 11 x 21 search window stays inside the level for keypoints >= 16 px from its edge).
+ * returns the number of accepted matches before the median filter. */
+typedef struct {
+    int nlevels;
+    const uint8_t* data[ORC_MAX_LEVELS];
+    int w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS], stride[ORC_MAX_LEVELS];
+} OrcPyramid;
+int  orc_compute_stereo_matches(const OrcKeyPoint* keysL, const uint8_t* descL, int N,
+                                const OrcKeyPoint* keysR, const uint8_t* descR, int Nr,
+                                const OrcPyramid* pyrL, const OrcPyramid* pyrR,
+                                const float* mvScaleFactors, const float* mvInvScaleFactors,
+                                float mb, float mbf, float* mvuRight, float* mvDepth);
+
 /* Frame::UndistortKeyPoints (src/Frame.cc:404-434), OpenCV 3.0 undistortPoints (unpinned) */
 void orc_undistort_keypoints(const OrcKeyPoint* in, int n, const float K[4], const float D[5], OrcKeyPoint* out);
 

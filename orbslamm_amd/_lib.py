@@ -62,7 +62,7 @@ EXPORTS = [
     "orbx_scale_tables", "orbx_features_per_level", "orbx_umax", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch", "orbx_submit_batch", "orbx_collect_view", "orbx_release", "orbx_collect_batch", "orbx_extract_match_batch",
     "orbx_host_alloc_frames", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_device_results", "orbx_download",
-    "orbx_pyramid_level", "orbx_level_candidates", "orbx_sync", "orbx_device_alloc", "orbx_device_free", "orbx_upload", "orbx_match_prev_batch_device",
+    "orbx_pyramid_level", "orbx_compute_stereo_matches", "orbx_level_candidates", "orbx_sync", "orbx_device_alloc", "orbx_device_free", "orbx_upload", "orbx_match_prev_batch_device",
     "orbx_device_matches", "orbx_download_matches", "orbx_reset_stream", "orbx_set_serial", "orbx_profile_enable",
     "orbx_profile_read", "orbx_profile_select", "orbm_create", "orbm_destroy", "orbm_distance_matrix", "orbm_match_bruteforce",
     "orbm_search_by_bow", "orbm_search_by_projection", "orbm_search_by_projection_stereo", "orbm_features_in_area", "orbm_window_best",

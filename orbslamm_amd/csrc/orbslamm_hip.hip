@@ -268,6 +268,7 @@ struct orbx_handle {
     hipEvent_t evOutOfSet[2] = {nullptr, nullptr};         // the download that last read result set s
     CopyPool pool;
     int matchSet = 0;                    // result set the last matching wrote (d_match / d_nmatch half)
+    void* d_stereo = nullptr; size_t stereoBytes = 0;  // orbx_compute_stereo_matches: uRight | depth | SAD | count
     int lastB = 0;
     FrameSrc lastSrc{};
     bool havePrev = false;
@@ -575,6 +576,7 @@ static void free_device(orbx_handle* h)
                     h->d_candCount, h->d_cellCount, h->d_kept, h->d_keptCount, h->d_err, h->d_kps, h->d_desc, h->d_count,
                     h->d_match, h->d_binOf, h->d_hist, h->d_nmatch, h->d_partial, h->d_xdesc};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->d_stereo) (void)hipFree(h->d_stereo);
     h->pool.stop();
     if (h->streamUp) (void)hipStreamSynchronize(h->streamUp);
     if (h->streamDown) (void)hipStreamSynchronize(h->streamDown);
@@ -1420,6 +1422,56 @@ extern "C" int orbx_extract(orbx_t* h, const uint8_t* img, int w, int hh, int st
     if (!img || w < 1 || hh < 1) { if (n_out) *n_out = 0; return ORBX_OK; }  // empty image: silent return (:1046-1047)
     const uint8_t* one[1] = {img};
     return orbx_extract_batch(h, one, 1, w, hh, stride, kps, desc, cap, n_out);
+}
+
+// void Frame::ComputeStereoMatches()   src/Frame.cc:466-638
+extern "C" int orbx_compute_stereo_matches(orbx_t* left, orbx_t* right, int frame, float mb, float mbf,
+                                           float* u_right, float* depth, int cap, int* n_left)
+{
+    int rc = orbx_sync(right);
+    if (rc) return rc;
+    if ((rc = orbx_sync(left))) return rc;  // also leaves the device of `left` current
+    if (left->device != right->device) return fail(ORBX_E_INVALID, "the two extractors live on different devices");
+    if (left->curW == 0 || left->curW != right->curW || left->curH != right->curH || left->nlevels != right->nlevels)
+        return fail(ORBX_E_INVALID, "left and right frames differ in shape or pyramid");
+    if (frame < 0 || frame >= left->lastB || frame >= right->lastB) return fail(ORBX_E_INVALID, "frame %d not in the last batches", frame);
+    if (!(mb > 0.f) || !(mbf > 0.f)) return fail(ORBX_E_INVALID, "stereo baseline (mb, mbf) must be positive");
+    if (left->maxKp >= 65536 || right->maxKp >= 65536) return fail(ORBX_E_UNSUPPORTED, "more than 65535 keypoints per frame");
+    int32_t n = 0;
+    HIPCHK(hipMemcpy(&n, r_count(left, left->curSet) + 1 + frame, sizeof n, hipMemcpyDeviceToHost));
+    if (n_left) *n_left = n;
+    if (n > cap) return fail(ORBX_E_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
+    if (n == 0) return ORBX_OK;
+    // scratch: three arrays of maxKp entries, grown on first use
+    const size_t need = (size_t)left->maxKp * 12 + 64;
+    if (need > left->stereoBytes) {
+        if (left->d_stereo) HIPCHK(hipFree(left->d_stereo));
+        left->d_stereo = nullptr; left->stereoBytes = 0;
+        HIPCHK(hipMalloc(&left->d_stereo, need));
+        left->stereoBytes = need;
+    }
+    StereoArgs a;
+    a.kL = r_kps(left, left->curSet) + (size_t)(frame + 1) * left->maxKp; a.dL = r_desc(left, left->curSet) + (size_t)(frame + 1) * left->maxKp * 32;
+    a.nL = r_count(left, left->curSet) + 1 + frame;
+    a.kR = r_kps(right, right->curSet) + (size_t)(frame + 1) * right->maxKp; a.dR = r_desc(right, right->curSet) + (size_t)(frame + 1) * right->maxKp * 32;
+    a.nR = r_count(right, right->curSet) + 1 + frame;
+    a.gL = left->d_geom; a.gR = right->d_geom;
+    a.srcL = left->lastSrc; a.srcR = right->lastSrc; a.srcL.f0 = a.srcR.f0 = 0;
+    a.fL = a.fR = frame;
+    for (int l = 0; l < ORBX_MAXL; l++) { a.sf[l] = l < left->nlevels ? left->mvScaleFactor[l] : 1.f; a.isf[l] = l < left->nlevels ? left->mvInvScaleFactor[l] : 1.f; }
+    a.mb = mb; a.mbf = mbf;
+    a.uRight = (float*)left->d_stereo; a.depth = a.uRight + left->maxKp; a.sad = (int32_t*)(a.depth + left->maxKp);
+    int32_t* d_nAcc = a.sad + left->maxKp;
+    hipStream_t s = left->stream;
+    hipLaunchKernelGGL(k_stereo_match, dim3((n + 3) / 4), dim3(256), 0, s, a);
+    const size_t lds = (size_t)left->maxKp * 4;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_stereo_median, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_stereo_median, dim3(1), dim3(1024), lds, s, a.nL, (const int32_t*)a.sad, a.uRight, a.depth, d_nAcc);
+    HIPCHK(hipGetLastError());
+    if (u_right) HIPCHK(hipMemcpyAsync(u_right, a.uRight, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (depth) HIPCHK(hipMemcpyAsync(depth, a.depth, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ORBX_OK;
 }
 
 extern "C" int orbx_pyramid_level(orbx_t* h, int frame, int level, int blurred, uint8_t* dst, int* w, int* hh)

@@ -1535,4 +1535,159 @@ __global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
     }
 }
 
+// ------------------------------------------------------------------ Frame::ComputeStereoMatches (Frame.cc:466-638)
+// One wave per left keypoint.  Phase 1: the right keypoints whose row band (:481-490) covers the left keypoint's row,
+// within one octave and inside the disparity range, scanned by the 64 lanes in index order; best = least Hamming
+// distance, lowest index on ties (the reference's row lists hold ascending indices and compare with strict <).
+// Phase 2: the 11-position sliding window of :548-587 -- sum of absolute differences of the two centre-subtracted
+// 11 x 11 patches on the keypoint's pyramid level -- two patch pixels per lane, then the parabola fit on lane 0.
+struct StereoArgs {
+    const OrbxKeyPointDev* kL; const uint8_t* dL; const int32_t* nL;
+    const OrbxKeyPointDev* kR; const uint8_t* dR; const int32_t* nR;
+    const Geom* gL; const Geom* gR;
+    FrameSrc srcL, srcR;
+    int fL, fR;
+    float sf[ORBX_MAXL], isf[ORBX_MAXL];
+    float mb, mbf;
+    float* uRight; float* depth; int32_t* sad;
+};
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int N = *a.nL, Nr = *a.nR;
+    if (iL >= N) return;
+    const OrbxKeyPointDev kp = a.kL[iL];
+    const int levelL = kp.octave;
+    const float vL = kp.y, uL = kp.x;
+    const int nRows = a.gL->lv[0].h;
+    const float maxD = __fdiv_rn(a.mbf, a.mb);
+    const float minU = __fsub_rn(uL, maxD), maxU = __fadd_rn(uL, 3.0f);  // uL - minD, minD = -3
+    float outU = -1.0f, outD = -1.0f;
+    int outSad = -1;
+    const int row = (int)vL;
+    uint32_t key = 0xFFFFFFFFu;
+    if (row >= 0 && row < nRows && !(maxU < 0)) {
+        uint32_t q[8];
+        const uint32_t* qp = (const uint32_t*)(a.dL + (int64_t)iL * 32);
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = qp[i];
+        for (int j = lane; j < Nr; j += 64) {
+            const OrbxKeyPointDev r = a.kR[j];
+            const float rr = __fmul_rn(2.0f, a.sf[r.octave]);
+            int maxr = (int)ceilf(__fadd_rn(r.y, rr)), minr = (int)floorf(__fsub_rn(r.y, rr));
+            minr = max(minr, 0); maxr = min(maxr, nRows - 1);
+            if (row < minr || row > maxr) continue;
+            if (r.octave < levelL - 1 || r.octave > levelL + 1) continue;
+            if (!(r.x >= minU && r.x <= maxU)) continue;
+            const uint32_t* tp = (const uint32_t*)(a.dR + (int64_t)j * 32);
+            int d = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) d += __popc(q[i] ^ tp[i]);
+            if (d < 100) key = min(key, ((uint32_t)d << 16) | (uint32_t)j);  // bestDist starts at TH_HIGH, strict <
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, m));
+    if (key != 0xFFFFFFFFu) {
+        const int bestIdxR = (int)(key & 0xFFFFu);
+        const float uR0 = a.kR[bestIdxR].x;
+        const float scaleFactor = a.isf[levelL];
+        const float scaleduL = roundf(__fmul_rn(kp.x, scaleFactor));
+        const float scaledvL = roundf(__fmul_rn(kp.y, scaleFactor));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, scaleFactor));
+        constexpr int w = 5, L = 5;
+        const int lw = a.gL->lv[levelL].w, lh = a.gL->lv[levelL].h, rw = a.gR->lv[levelL].w, rh = a.gR->lv[levelL].h;
+        const int y0 = (int)__fsub_rn(scaledvL, (float)w), x0 = (int)__fsub_rn(scaleduL, (float)w);
+        bool ok = !(y0 < 0 || y0 + 2 * w + 1 > lh || y0 + 2 * w + 1 > rh || x0 < 0 || x0 + 2 * w + 1 > lw);
+        const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)L), (float)w), endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)L), (float)w), 1.0f);
+        ok = ok && !(iniu < 0 || endu >= (float)rw);
+        const int xr0 = (int)__fsub_rn(__fsub_rn(scaleduR0, (float)L), (float)w);
+        ok = ok && !(xr0 < 0 || (int)endu > rw);
+        if (ok) {
+            int sL, sR;
+            const uint8_t* IL = level_ptr(a.gL, a.srcL, a.fL, levelL, sL) + (int64_t)y0 * sL + x0;
+            const uint8_t* IRb = level_ptr(a.gR, a.srcR, a.fR, levelL, sR) + (int64_t)y0 * sR + xr0;  // column of shift -L
+            const int cL = IL[w * sL + w];
+            // lane owns patch pixels p = lane and lane + 64 (121 in all)
+            int pl[2], off[2];
+            bool has[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int p = lane + 64 * k;
+                has[k] = p < 121;
+                const int yy = has[k] ? p / 11 : 0, xx = has[k] ? p - 11 * (p / 11) : 0;
+                pl[k] = (int)IL[yy * sL + xx] - cL;
+                off[k] = yy * sR + xx;
+            }
+            int bestSad = 0x7FFFFFFF, bestincR = 0;
+            float vD[11];
+#pragma unroll
+            for (int s = 0; s <= 2 * L; s++) {
+                const int cR = IRb[w * sR + w + s];
+                int sad = 0;
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                    if (has[k]) sad += abs(pl[k] - ((int)IRb[off[k] + s] - cR));
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) sad += __shfl_xor(sad, m);
+                vD[s] = (float)sad;
+                if (sad < bestSad) { bestSad = sad; bestincR = s - L; }
+            }
+            if (!(bestincR == -L || bestincR == L)) {
+                float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
+#pragma unroll
+                for (int s = 1; s < 2 * L; s++)
+                    if (s == bestincR + L) { dist1 = vD[s - 1]; dist2 = vD[s]; dist3 = vD[s + 1]; }
+                const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
+                                               __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(a.sf[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestincR), deltaR));
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= 0 && disparity < maxD) {
+                        if (disparity <= 0) { disparity = 0.01f; bestuR = __fsub_rn(uL, 0.01f); }
+                        outD = __fdiv_rn(a.mbf, disparity);
+                        outU = bestuR;
+                        outSad = bestSad;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { a.uRight[iL] = outU; a.depth[iL] = outD; a.sad[iL] = outSad; }
+}
+
+// :626-637: sort the accepted (SAD, index) pairs, take the element at size/2 as median, drop everything at or above
+// 1.5 * 1.4 * median.  One workgroup; the median by rank counting on packed keys SAD << 16 | index.
+__global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restrict__ nL, const int32_t* __restrict__ sad,
+                                                       float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ nAccepted)
+{
+    extern __shared__ uint32_t keys[];
+    __shared__ int sN;
+    __shared__ uint32_t sMedian;
+    const int N = *nL, tid = threadIdx.x;
+    if (tid == 0) sN = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += 1024)
+        if (sad[i] >= 0) keys[atomicAdd(&sN, 1)] = ((uint32_t)sad[i] << 16) | (uint32_t)i;
+    __syncthreads();
+    const int n = sN;
+    if (tid == 0) *nAccepted = n;
+    if (n == 0) return;
+    for (int e = tid; e < n; e += 1024) {
+        const uint32_t k = keys[e];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += keys[j] < k;
+        if (rank == n / 2) sMedian = k;
+    }
+    __syncthreads();
+    const float median = (float)(int)(sMedian >> 16);
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    for (int e = tid; e < n; e += 1024) {
+        const uint32_t k = keys[e];
+        if (!((float)(int)(k >> 16) < thDist)) { uRight[k & 0xFFFFu] = -1.0f; depth[k & 0xFFFFu] = -1.0f; }
+    }
+}
+
 }  // namespace orbx

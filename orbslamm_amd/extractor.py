@@ -241,6 +241,15 @@ class ORBextractor:
         check(self._L.orbx_pyramid_level(self._h, int(frame), int(level), int(blurred), ptr(out), C.byref(w), C.byref(h)))
         return out
 
+    def compute_stereo_matches(self, right, mb, mbf, frame=0):
+        """Frame::ComputeStereoMatches (Frame.cc:466-638) with self as the left extractor: (mvuRight, mvDepth)"""
+        cap = self._cap
+        ur = np.zeros(cap, dtype=np.float32)
+        dp = np.zeros(cap, dtype=np.float32)
+        n = C.c_int(0)
+        check(self._L.orbx_compute_stereo_matches(self._h, right._h, int(frame), C.c_float(mb), C.c_float(mbf), ptr(ur), ptr(dp), cap, C.byref(n)))
+        return ur[:n.value].copy(), dp[:n.value].copy()
+
     def level_sizes(self):
         """(width, height) of every pyramid level of the last extracted shape (ORBextractor.cc:1111-1112)"""
         out = []
