@@ -22,13 +22,45 @@
 
 namespace iORB_SLAM {  // the reference's namespace (ORBextractor.h:29)
 
+class ORBextractor;
+
+// One level of mvImagePyramid as the reference lays it out (ORBextractor.cc:1107-1132): the level's pixels sit inside a
+// buffer with a 19 px (EDGE_THRESHOLD) BORDER_REFLECT_101 frame; data points at pixel (0, 0) of the level, so
+// data[y * step + x] is valid for -19 <= x < cols + 19, -19 <= y < rows + 19 -- what code that indexes the member
+// directly (Frame::ComputeStereoMatches, Frame.cc:561,578) relies on.
+struct PyramidLevel {
+    int rows = 0, cols = 0;
+    size_t step = 0;
+    uint8_t* data = nullptr;
+    std::vector<uint8_t> buf;   // (rows + 38) x (cols + 38)
+#ifdef ORBSLAMM_WITH_OPENCV
+    cv::Mat mat() { return cv::Mat(rows, cols, CV_8UC1, data, step); }
+#endif
+};
+
+// std::vector<cv::Mat> mvImagePyramid (ORBextractor.h:85) as a member that fills itself on first use after each
+// operator() call: the pyramid lives in HBM and only the stereo path ever reads it on the host, so the eight images
+// are not copied back per frame.  mvImagePyramid[l], .size(), and iteration work as on the vector.
+class LazyPyramid {
+public:
+    explicit LazyPyramid(ORBextractor* owner) : owner_(owner) {}
+    size_t size() const;
+    PyramidLevel& operator[](size_t level);
+    void invalidate() { valid_ = false; }
+private:
+    void fill();
+    ORBextractor* owner_;
+    std::vector<PyramidLevel> levels_;
+    bool valid_ = false;
+};
+
 class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
     // same five arguments as the reference; the extra ones size the device buffers
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
-                 int maxWidth = 1920, int maxHeight = 1080, int device = 0)
+                 int maxWidth = 1920, int maxHeight = 1080, int device = 0) : mvImagePyramid(this)
     {
         OrbxParams p = {nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST};
         if (orbx_create(&p, maxWidth, maxHeight, 1, device, &h_) != ORBX_OK)
@@ -39,16 +71,20 @@ public:
         cap_ = orbx_max_keypoints(h_);
         kps_.resize(cap_);
     }
+    orbx_t* handle() { return h_; }
     ~ORBextractor() { orbx_destroy(h_); }
     ORBextractor(const ORBextractor&) = delete;
     ORBextractor& operator=(const ORBextractor&) = delete;
 
-    int GetLevels() { return orbx_levels(h_); }
-    float GetScaleFactor() { return orbx_scale_factor(h_); }
-    std::vector<float> GetScaleFactors() { return mvScaleFactor; }
-    std::vector<float> GetInverseScaleFactors() { return mvInvScaleFactor; }
-    std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
-    std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+    // ORBextractor.h:60-83, the reference's spelling
+    int inline GetLevels() { return orbx_levels(h_); }
+    float inline GetScaleFactor() { return orbx_scale_factor(h_); }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    LazyPyramid mvImagePyramid;   // ORBextractor.h:85
 
 #ifdef ORBSLAMM_WITH_OPENCV
     // void operator()(InputArray image, InputArray mask, vector<KeyPoint>&, OutputArray)  ORBextractor.cc:1043
@@ -66,23 +102,13 @@ public:
             std::fprintf(stderr, "ORBextractor(HIP): %s\n", orbx_last_error());
             n = 0;
         }
+        mvImagePyramid.invalidate();
         _keypoints.clear();
         if (n == 0) { _descriptors.release(); return; }
         _keypoints.resize(n);
         std::memcpy((void*)_keypoints.data(), kps_.data(), (size_t)n * sizeof(OrbxKeyPoint));
         _descriptors.create(n, 32, CV_8U);
         std::memcpy(_descriptors.getMat().data, desc_.data(), (size_t)n * 32);
-        // mvImagePyramid is filled lazily: see pyramidLevel()
-    }
-    // std::vector<cv::Mat> mvImagePyramid (ORBextractor.h:85) is only read by the stereo path;
-    // fetch a level on demand instead of copying 8 images back per frame.
-    cv::Mat pyramidLevel(int level)
-    {
-        int w = 0, hh = 0;
-        orbx_pyramid_level(h_, 0, level, 0, nullptr, &w, &hh);
-        cv::Mat m(hh, w, CV_8UC1);
-        orbx_pyramid_level(h_, 0, level, 0, m.data, &w, &hh);
-        return m;
     }
 #else
     // flat-array form of operator(): image rows `stride` bytes apart
@@ -94,6 +120,7 @@ public:
         int n = 0;
         const int rc = orbx_extract(h_, image, width, height, stride, kps_.data(), desc_.data(), cap_, &n);
         if (rc != ORBX_OK) { std::fprintf(stderr, "ORBextractor(HIP): %s\n", orbx_last_error()); n = 0; }
+        mvImagePyramid.invalidate();
         keypoints.assign(kps_.begin(), kps_.begin() + n);
         descriptors.assign(desc_.begin(), desc_.begin() + (size_t)n * 32);
     }
@@ -116,5 +143,37 @@ protected:
     std::vector<uint8_t> desc_;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
+
+inline size_t LazyPyramid::size() const { return (size_t)orbx_levels(owner_->handle()); }
+inline PyramidLevel& LazyPyramid::operator[](size_t level)
+{
+    if (!valid_) fill();
+    return levels_.at(level);
+}
+inline void LazyPyramid::fill()
+{
+    const int E = 19;  // EDGE_THRESHOLD, ORBextractor.cc:74
+    const int L = orbx_levels(owner_->handle());
+    levels_.resize((size_t)L);
+    for (int l = 0; l < L; l++) {
+        PyramidLevel& P = levels_[(size_t)l];
+        int w = 0, h = 0;
+        if (orbx_pyramid_level(owner_->handle(), 0, l, 0, nullptr, &w, &h) != ORBX_OK)
+            throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
+        P.rows = h; P.cols = w; P.step = (size_t)w + 2 * E;
+        P.buf.assign(P.step * ((size_t)h + 2 * E), 0);
+        P.data = P.buf.data() + (size_t)E * P.step + E;
+        std::vector<uint8_t> tight((size_t)w * h);
+        orbx_pyramid_level(owner_->handle(), 0, l, 0, tight.data(), &w, &h);
+        auto refl = [](int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p; return p; };  // BORDER_REFLECT_101
+        for (int y = -E; y < h + E; y++) {
+            const uint8_t* src = &tight[(size_t)refl(y, h) * w];
+            uint8_t* dst = P.data + (ptrdiff_t)y * (ptrdiff_t)P.step;
+            std::memcpy(dst, src, (size_t)w);
+            for (int x = 1; x <= E; x++) { dst[-x] = src[refl(-x, w)]; dst[w - 1 + x] = src[refl(w - 1 + x, w)]; }
+        }
+    }
+    valid_ = true;
+}
 
 }  // namespace iORB_SLAM

@@ -357,6 +357,13 @@ int orbm_undistort_keypoints(orbm_t* h, const OrbxKeyPoint* keys, int n, const f
  * to the others, -1 for a point without observations. */
 int orbm_distinctive_descriptors(orbm_t* h, const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx);
 
+/* The descriptor text of the map file: `os << pKF->mDescriptors`, `os << pMP->GetDescriptor()`  src/MapSerializer.cc:344-347,
+ * 429-431 (cv::Mat's stream operator, OpenCV 3.0 default formatter: "[%3d, %3d, ...;\n %3d, ...]").  Host-side
+ * formatting of host data; needs no device.  out == NULL queries *len (bytes without the terminating 0). */
+int orbm_descriptors_to_text(const uint8_t* desc, int n, int cols, char* out, size_t cap, size_t* len);
+/* the inverse, for map loaders (desc == NULL counts the rows) */
+int orbm_descriptors_from_text(const char* text, uint8_t* desc, int cap_rows, int cols, int* n_rows);
+
 /* GetFeaturesInArea on the device grid, for tests: out[cap] indices in reference order */
 int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const OrbxKeyPoint* keys_un, int n,
                           float x, float y, float r, int minLevel, int maxLevel,

@@ -1683,6 +1683,66 @@ extern "C" int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset)
     return ORBX_OK;
 }
 
+// ------------------------------------------------------------------ MapSerializer's descriptor text
+// `os << pKF->mDescriptors` / `os << pMP->GetDescriptor()` into an XML attribute (src/MapSerializer.cc:344-347, 429-431):
+// cv::Mat's stream operator with OpenCV 3.0's default formatter -- "[" rows "]", elements "%3d" separated by ", ", rows by
+// ";\n " (restated from the published out.cpp: third-party formatting, unpinned; the reference never reads it back).
+// Host-side string formatting of data that is on the host already: not a compute path, works without a device.
+extern "C" int orbm_descriptors_to_text(const uint8_t* desc, int n, int cols, char* out, size_t cap, size_t* len)
+{
+    if (n < 0 || cols < 0 || (n > 0 && cols > 0 && !desc) || !len) return fail(ORBX_E_INVALID, "bad argument");
+    const size_t need = 2 + (size_t)n * ((size_t)cols * 3 + (cols > 0 ? (size_t)(cols - 1) * 2 : 0)) + (n > 0 ? (size_t)(n - 1) * 3 : 0);
+    *len = need;
+    if (!out) return ORBX_OK;                       // size query
+    if (cap < need + 1) return fail(ORBX_E_CAPACITY, "text needs %zu bytes", need + 1);
+    char* p = out;
+    *p++ = '[';
+    for (int r = 0; r < n; r++) {
+        if (r) { *p++ = ';'; *p++ = '\n'; *p++ = ' '; }
+        for (int c = 0; c < cols; c++) {
+            if (c) { *p++ = ','; *p++ = ' '; }
+            const unsigned v = desc[(size_t)r * cols + c];
+            p[0] = v >= 100 ? (char)('0' + v / 100) : ' ';
+            p[1] = v >= 10 ? (char)('0' + (v / 10) % 10) : ' ';
+            p[2] = (char)('0' + v % 10);
+            p += 3;
+        }
+    }
+    *p++ = ']';
+    *p = 0;
+    return ORBX_OK;
+}
+
+// the inverse (a loader the reference does not have: MultiMapper::InitFromFile never reads descriptors back)
+extern "C" int orbm_descriptors_from_text(const char* text, uint8_t* desc, int cap_rows, int cols, int* n_rows)
+{
+    if (!text || cols < 1 || !n_rows) return fail(ORBX_E_INVALID, "bad argument");
+    const char* p = text;
+    while (*p == ' ' || *p == '\n') p++;
+    if (*p != '[') return fail(ORBX_E_INVALID, "descriptor text does not start with '['");
+    p++;
+    int r = 0, c = 0;
+    bool any = false;
+    for (;;) {
+        while (*p == ' ' || *p == '\n') p++;
+        if (*p == ']') break;
+        if (*p < '0' || *p > '9') return fail(ORBX_E_INVALID, "unexpected character '%c' in descriptor text", *p);
+        unsigned v = 0;
+        while (*p >= '0' && *p <= '9') v = v * 10 + (unsigned)(*p++ - '0');
+        if (v > 255 || c >= cols) return fail(ORBX_E_INVALID, "descriptor text: value or column out of range");
+        if (desc) { if (r >= cap_rows) return fail(ORBX_E_CAPACITY, "more than %d rows", cap_rows); desc[(size_t)r * cols + c] = (uint8_t)v; }
+        any = true;
+        c++;
+        while (*p == ' ') p++;
+        if (*p == ',') p++;
+        else if (*p == ';') { if (c != cols) return fail(ORBX_E_INVALID, "descriptor text: short row"); p++; r++; c = 0; }
+        else if (*p != ']') return fail(ORBX_E_INVALID, "descriptor text: missing separator");
+    }
+    if (any) { if (c != cols) return fail(ORBX_E_INVALID, "descriptor text: short row"); r++; }
+    *n_rows = r;
+    return ORBX_OK;
+}
+
 // ------------------------------------------------------------------ matcher handle
 struct orbm_handle {
     int device = -1;

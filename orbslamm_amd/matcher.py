@@ -267,3 +267,27 @@ class ORBmatcher:
                                             C.c_float(y), C.c_float(r), int(minLevel), int(maxLevel), ptr(out),
                                             out.shape[0], C.byref(n)))
         return out[:n.value].copy()
+
+
+def descriptors_to_text(desc):
+    """MapSerializer's descriptor attribute (src/MapSerializer.cc:344-347, 429-431): `os << cv::Mat` of a CV_8U matrix"""
+    L = lib()
+    d = np.ascontiguousarray(desc, dtype=np.uint8)
+    if d.ndim == 1:
+        d = d[None]
+    n, cols = d.shape
+    ln = C.c_size_t(0)
+    check(L.orbm_descriptors_to_text(ptr(d), n, cols, None, C.c_size_t(0), C.byref(ln)))
+    buf = C.create_string_buffer(ln.value + 1)
+    check(L.orbm_descriptors_to_text(ptr(d), n, cols, buf, C.c_size_t(ln.value + 1), C.byref(ln)))
+    return buf.value.decode()
+
+
+def descriptors_from_text(text, cols=32):
+    L = lib()
+    n = C.c_int(0)
+    t = text.encode()
+    check(L.orbm_descriptors_from_text(t, None, 0, cols, C.byref(n)))
+    out = np.zeros((n.value, cols), dtype=np.uint8)
+    check(L.orbm_descriptors_from_text(t, ptr(out), n.value, cols, C.byref(n)))
+    return out

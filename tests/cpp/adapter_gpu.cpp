@@ -12,6 +12,13 @@
 static int fails = 0;
 #define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
 
+static bool l0_is_frame(iORB_SLAM::ORBextractor& ex, const std::vector<uint8_t>& img, int W, int H)
+{
+    iORB_SLAM::PyramidLevel& P = ex.mvImagePyramid[0];
+    for (int y = 0; y < H; y++) if (std::memcmp(P.data + (size_t)y * P.step, &img[(size_t)y * W], (size_t)W)) return false;
+    return true;
+}
+
 int main()
 {
     const int W = 640, H = 480;
@@ -88,6 +95,31 @@ int main()
         EXPECT(nf == onf && nf > 50);
         EXPECT(std::memcmp(f12.data(), of12.data(), (size_t)n * 4) == 0);
         std::printf("device frames: %d / %d features, %d init matches\n", n, n2, nf);
+    }
+    // mvImagePyramid (ORBextractor.h:85): a public member again, filled on first use after operator(), each level inside
+    // a 19 px BORDER_REFLECT_101 frame like ComputePyramid leaves it (ORBextractor.cc:1107-1132)
+    {
+        std::vector<OrbxKeyPoint> k3; std::vector<uint8_t> d3;
+        ex(img.data(), W, H, W, k3, d3);
+        EXPECT(ex.mvImagePyramid.size() == 8);
+        std::vector<uint8_t> opyr((size_t)W * H * 4);
+        orc_extract(&oex, img.data(), W, H, W, okps.data(), odesc.data(), 2000, opyr.data(), nullptr, nullptr);
+        size_t off = 0;
+        for (int l = 0; l < 8; l++) {
+            iORB_SLAM::PyramidLevel& P = ex.mvImagePyramid[(size_t)l];
+            int lw = 0, lh = 0;
+            orc_level_size(&oex, W, H, l, &lw, &lh);
+            EXPECT(P.cols == lw && P.rows == lh && P.step == (size_t)lw + 38);
+            bool same = true, border = true;
+            for (int y = 0; y < lh && same; y++) same = std::memcmp(P.data + (size_t)y * P.step, &opyr[off + (size_t)y * lw], (size_t)lw) == 0;
+            for (int d = 1; d <= 19; d++) {   // reflect-101: pixel -d mirrors pixel +d, pixel n-1+d mirrors n-1-d
+                border = border && P.data[-d] == P.data[d] && P.data[(ptrdiff_t)(lh - 1 + d) * (ptrdiff_t)P.step + 5] == P.data[(size_t)(lh - 1 - d) * P.step + 5];
+                border = border && P.data[-(ptrdiff_t)d * (ptrdiff_t)P.step - d] == P.data[(size_t)d * P.step + d];
+            }
+            EXPECT(same); EXPECT(border);
+            off += (size_t)lw * lh;
+        }
+        EXPECT(l0_is_frame(ex, img, W, H));
     }
     std::printf(fails ? "adapter_gpu: %d failures\n" : "adapter_gpu ok (%d keypoints, %d BoW matches, %d init matches)\n", fails ? fails : on, nm, ni);
     return fails ? 1 : 0;

@@ -69,3 +69,22 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".h")):
                     txt = open(os.path.join(dp, f), errors="replace").read()
                     assert "oracle" not in txt.lower().replace("no cpu fallback", ""), os.path.join(dp, f)
+
+
+def test_mapserializer_descriptor_text():
+    """`os << pKF->mDescriptors` (src/MapSerializer.cc:344-347): OpenCV 3.0's default cv::Mat formatter for CV_8U --
+    "[" rows "]", "%3d" elements, ", " between elements, ";\\n " between rows.  Host-side formatting: runs without a GPU."""
+    from orbslamm_amd import matcher
+    m = np.array([[1, 20, 255], [0, 7, 100]], dtype=np.uint8)
+    assert matcher.descriptors_to_text(m) == "[  1,  20, 255;\n   0,   7, 100]"
+    assert matcher.descriptors_to_text(np.zeros((0, 32), np.uint8)) == "[]"
+    rng = np.random.default_rng(3)
+    d = rng.integers(0, 256, size=(57, 32), dtype=np.uint8)
+    t = matcher.descriptors_to_text(d)
+    assert t.count("\n") == 56 and t.count(",") == 57 * 31 and len(t) == 2 + 57 * (32 * 3 + 31 * 2) + 56 * 3
+    assert np.array_equal(matcher.descriptors_from_text(t), d)
+    one = matcher.descriptors_to_text(d[5])       # MapPoint::GetDescriptor(): 1 x 32
+    assert one.startswith("[") and "\n" not in one and np.array_equal(matcher.descriptors_from_text(one)[0], d[5])
+    from orbslamm_amd import OrbError
+    with pytest.raises(OrbError):
+        matcher.descriptors_from_text("[1, 2; 3]", cols=2)
