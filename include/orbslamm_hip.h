@@ -210,6 +210,13 @@ int orbx_profile_enable(orbx_t* h, int enable);
 int orbx_profile_select(orbx_t* h, const char* kernel);
 int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset);
 
+/* Diagnostics: which kernels slow each other down when they share the GPU (tools/pair_overlap.py).
+ * Kernel i is launched back to back on one stream while kernel j keeps a second stream busy; co_ms[i * n + j] = time per
+ * launch of i beside j, alone_ms[i] = alone; nb = frames per launch.  Runs on the buffers of the last extracted and
+ * matched batch.  lds_bytes / wg_threads / wgs: workgroup footprint and count of each kernel at that nb. */
+int orbx_debug_pair_overlap(orbx_t* h, int nb, float target_ms, int* n_kernels, const char** names,
+                            float* alone_ms, float* co_ms, int32_t* lds_bytes, int32_t* wg_threads, int32_t* wgs);
+
 /* ---------------------------------------------------------------- matcher
  * replaces class ORBmatcher (include/ORBmatcher.h:37-102).  The object-graph
  * walking (MapPoint flags, mutex-guarded getters, camera projection) stays in the

@@ -524,12 +524,18 @@ static void divide_node(const QNode* p, const OrcCorner* kp, QNode* c[4])
 }
 
 typedef struct { int size; QNode* node; } SizeNode;
+/* Test hook: 0 = the defined tie-break (creation sequence ascending), 1 = the opposite order among equal sizes.  The
+ * reference breaks such ties by heap address (ref:684) -- ANY order can come out of it; tests use the hook to show where
+ * the choice can and cannot change the result (tests/test_oracle_invariants.py). */
+static int g_tie_break_reversed = 0;
+void orc_set_tie_break_reversed(int on) { g_tie_break_reversed = on; }
 static int cmp_sizenode(const void* a, const void* b)
 {
     const SizeNode *x = (const SizeNode*)a, *y = (const SizeNode*)b;
     if (x->size != y->size) return x->size < y->size ? -1 : 1;
     /* reference compares heap pointers here (ref:684); oracle: creation sequence */
-    return x->node->seq < y->node->seq ? -1 : (x->node->seq > y->node->seq ? 1 : 0);
+    const int c = x->node->seq < y->node->seq ? -1 : (x->node->seq > y->node->seq ? 1 : 0);
+    return g_tie_break_reversed ? -c : c;
 }
 
 /* push children of a divided node (ref:621-660 / 694-730); records expandable ones */

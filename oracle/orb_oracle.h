@@ -103,6 +103,9 @@ int  orc_level_candidates(const OrcExtractor* ex, const uint8_t* img, int w, int
 int  orc_distribute(const OrcCorner* in, int n, int minX, int maxX, int minY, int maxY,
                     int N, OrcCorner* out, int cap);
 
+/* test hook: reverse the order among equal-sized quadtree nodes (the reference's order there is a heap-address accident) */
+void orc_set_tie_break_reversed(int on);
+
 /* whole operator(): returns number of keypoints (or <0 on error).  desc is N x 32.
  * If pyr_out != NULL it receives the concatenated (tight, stride = level width)
  * pyramid levels 0..nlevels-1; if cand_counts != NULL it receives the per-level

@@ -1077,6 +1077,14 @@ extern "C" int orbx_sync(orbx_t* h)
     int rc = check_device(h);
     if (rc) return rc;
     if ((rc = sync_all(h))) return rc;
+#ifdef ORBX_FAST_STATS
+    {
+        unsigned long long st[16];
+        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fastStats), sizeof st) == hipSuccess && st[0])
+            fprintf(stderr, "FAST stats: pass0 cells %llu visits %llu corners %llu | pass1 cells %llu visits %llu corners %llu | detection px %llu\n",
+                    st[0], st[1], st[2], st[4], st[5], st[6], st[8]);
+    }
+#endif
     int32_t err = 0;
     HIPCHK(hipMemcpy(&err, h->d_err, sizeof err, hipMemcpyDeviceToHost));
     if (err) {
@@ -1539,20 +1547,9 @@ static int roll_prev_on(orbx_handle* h, hipStream_t s, int set)
     return ORBX_OK;
 }
 
-// the matching of the last extracted batch on stream s; roll = false leaves the roll of the previous-frame slot to the
-// caller (the latency path puts the result kernel in front of it)
-static int match_prev_on(orbx_handle* h, hipStream_t s, float nnratio, int th_low, int check_ori, bool roll)
+// the kernels of the stream matcher for the B frames of result set `set` (no waits, no roll)
+static void match_kernels(orbx_handle* h, hipStream_t s, int set, int B, float nnratio, int th_low, int check_ori)
 {
-    int rc;
-    const int B = h->lastB;
-    if (B < 1) return fail(ORBX_E_INVALID, "no extracted batch to match");
-    const int set = h->curSet;
-    // what this stream does not already follow: the batch's descriptors, the previous batch's roll into slot 0 of this
-    // set, the download that last read this set's tables
-    for (int p = 0; p < h->lastParts; p++)
-        if (!(h->lastParts == 1 && h->prevSplit == 1 && !h->serial && s == h->streamP[0])) HIPCHK(hipStreamWaitEvent(s, h->evPart[p], 0));
-    if (h->matchPending[set ^ 1] && h->matchStream[set ^ 1] != s) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set ^ 1], 0));
-    if (h->evOutOfSet[set] && h->outStream[set] != s) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));
     orbm::MatchIO io = slots_io(h, set);
     int32_t* const d_match = h->d_match + (size_t)set * h->maxB * h->maxKp;  // one table per result set: the host path's
     int32_t* const d_nmatch = h->d_nmatch + (size_t)set * h->maxB;           // download of batch n-1 runs beside batch n
@@ -1588,6 +1585,23 @@ static int match_prev_on(orbx_handle* h, hipStream_t s, float nnratio, int th_lo
                            h->d_binOf, h->d_hist, d_nmatch);
         h->prof.end(s);
     }
+}
+
+// the matching of the last extracted batch on stream s; roll = false leaves the roll of the previous-frame slot to the
+// caller (the latency path puts the result kernel in front of it)
+static int match_prev_on(orbx_handle* h, hipStream_t s, float nnratio, int th_low, int check_ori, bool roll)
+{
+    int rc;
+    const int B = h->lastB;
+    if (B < 1) return fail(ORBX_E_INVALID, "no extracted batch to match");
+    const int set = h->curSet;
+    // what this stream does not already follow: the batch's descriptors, the previous batch's roll into slot 0 of this
+    // set, the download that last read this set's tables
+    for (int p = 0; p < h->lastParts; p++)
+        if (!(h->lastParts == 1 && h->prevSplit == 1 && !h->serial && s == h->streamP[0])) HIPCHK(hipStreamWaitEvent(s, h->evPart[p], 0));
+    if (h->matchPending[set ^ 1] && h->matchStream[set ^ 1] != s) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set ^ 1], 0));
+    if (h->evOutOfSet[set] && h->outStream[set] != s) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));
+    match_kernels(h, s, set, B, nnratio, th_low, check_ori);
     HIPCHK(hipGetLastError());
     if (!roll) return ORBX_OK;
     HIPCHK(hipEventRecord(h->evMatched[set], s));  // the tables are final: the host path's download need not wait for the roll
@@ -1681,6 +1695,78 @@ extern "C" int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset)
         if (reset) { h->prof.ms[i] = 0; h->prof.launches[i] = 0; }
     }
     return ORBX_OK;
+}
+
+// ------------------------------------------------------------------ co-run experiment (tools/pair_overlap.py)
+// Kernel i repeated on one stream while kernel j runs on another for at least three times as long: the per-launch time of
+// i beside j against i alone.  Works on the buffers of the last extracted + matched batch (every stage is idempotent on
+// its inputs).  PMC counters cannot do this: rocprofv3 serialises dispatches while it collects them.
+extern "C" int orbx_debug_pair_overlap(orbx_t* h, int nb, float target_ms, int* n_kernels, const char** names,
+                                       float* alone_ms, float* co_ms, int32_t* lds_bytes, int32_t* wg_threads, int32_t* wgs)
+{
+    int rc = orbx_sync(h);
+    if (rc) return rc;
+    if (h->lastB < 1 || nb < 1 || nb > h->lastB) return fail(ORBX_E_INVALID, "run a batch of at least %d frames first", nb);
+    constexpr int K = 6;
+    static const char* kNames[K] = {"k_pyramid", "k_fast", "k_distribute", "k_blur", "k_orient_desc", "k_match_mfma"};
+    if (n_kernels) *n_kernels = K;
+    const Geom& g = h->geom;
+    FrameSrc src = h->lastSrc; src.f0 = 0;
+    Launcher L{h, src, nb};
+    const int set = h->curSet, cellsL0 = g.lv[0].nCells;
+    auto launch = [&](int k, hipStream_t s) {
+        switch (k) {
+        case 0: (void)L.pyramid(s); break;
+        case 1: L.fast(s, 0, cellsL0); L.fast(s, cellsL0, g.totalCells - cellsL0); break;
+        case 2: L.dist(s, 0, g.nlevels); break;
+        case 3: L.blur(s); break;
+        case 4: (void)L.desc(s, set); break;
+        default: match_kernels(h, s, set, nb, 0.7f, 50, 1); break;
+        }
+    };
+    if (lds_bytes && wg_threads && wgs) {
+        const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
+        const size_t fl = (size_t)2 * (h->tileRows * h->tileStrideDw + 4) * 4 + (size_t)h->fastListCap * 2;
+        const int nqb = (h->maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
+        const int32_t l[K] = {(int32_t)pl, (int32_t)fl, (int32_t)(dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel) + 18284), 13464, 31104, 24576};
+        const int32_t t[K] = {256, 64, kDistThreads, 256, 256, 256};
+        const int32_t w[K] = {h->pyrBlocks * nb, g.totalCells * nb, g.nlevels * nb, h->blurTiles.base[g.nlevels] * nb, h->kpBlocksTotal * nb, nqb * nb};
+        for (int k = 0; k < K; k++) { lds_bytes[k] = l[k]; wg_threads[k] = t[k]; wgs[k] = w[k]; }
+    }
+    for (int k = 0; k < K; k++) if (names) names[k] = kNames[k];
+    hipStream_t sa = h->streamP[0], sb = h->streamP[1];
+    hipEvent_t e0, e1, eGo;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreateWithFlags(&eGo, hipEventDisableTiming));
+    auto timed = [&](int i, int j, int ni, int nj, float& ms) -> int {  // j < 0: alone
+        HIPCHK(hipEventRecord(eGo, h->stream));
+        HIPCHK(hipStreamWaitEvent(sa, eGo, 0));
+        if (j >= 0) { HIPCHK(hipStreamWaitEvent(sb, eGo, 0)); for (int r = 0; r < nj / 4; r++) launch(j, sb); }  // a head start
+        HIPCHK(hipEventRecord(e0, sa));
+        for (int r = 0; r < ni; r++) { launch(i, sa); if (j >= 0) for (int q = 0; q * ni < nj - nj / 4 && q < 8; q++) launch(j, sb); }
+        HIPCHK(hipEventRecord(e1, sa));
+        HIPCHK(hipStreamSynchronize(sa)); HIPCHK(hipStreamSynchronize(sb));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        ms = t / ni;
+        return ORBX_OK;
+    };
+    float alone[K];
+    for (int i = 0; i < K; i++) {
+        float t;
+        if ((rc = timed(i, -1, 4, 0, t))) return rc;                  // warm
+        if ((rc = timed(i, -1, 20, 0, t))) return rc;
+        alone[i] = t;
+        if (alone_ms) alone_ms[i] = t;
+    }
+    for (int i = 0; i < K; i++)
+        for (int j = 0; j < K; j++) {
+            const int ni = std::max(4, (int)(target_ms / alone[i]));
+            const int nj = std::max(8, (int)(4.f * ni * alone[i] / alone[j]));   // j's stream stays busy ~4x as long as i's alone time
+            float t;
+            if ((rc = timed(i, j, ni, nj, t))) return rc;
+            if (co_ms) co_ms[i * K + j] = t;
+        }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eGo);
+    return orbx_sync(h);
 }
 
 // ------------------------------------------------------------------ MapSerializer's descriptor text

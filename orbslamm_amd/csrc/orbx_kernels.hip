@@ -306,6 +306,9 @@ __device__ __forceinline__ int lanes_below(uint64_t bal)
 
 // Tile layout: ROI pixel (rx, ry) at byte ry*TSB + rx + 1, so detection pixel (x, y) = ROI (x+3, y+3)
 // sits at (y+3)*TSB + x + 4 and groups of four detection pixels are dword aligned.
+#ifdef ORBX_FAST_STATS
+__device__ unsigned long long g_fastStats[16];  // per pass: cells, stage-2 visits, corners; [8] detection pixels
+#endif
 template <int TSB>
 __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const Cell* __restrict__ cells,
                                             FrameSrc src, uint64_t* __restrict__ cand,
@@ -427,6 +430,9 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             }
         }
         __syncthreads();
+#ifdef ORBX_FAST_STATS
+        if (lane == 0) { atomicAdd(&g_fastStats[0 + 4 * pass], 1ull); atomicAdd(&g_fastStats[1 + 4 * pass], (unsigned long long)(nA + 2 * nB)); atomicAdd(&g_fastStats[8], (unsigned long long)(dw * dh)); }
+#endif
         if (nA + nB == 0) { if (last) break; else continue; }
 
         // stage 2: exact score on the dense lists; pixels with S > th (the corners of this pass)
@@ -477,6 +483,9 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             }
         }
         __syncthreads();
+#ifdef ORBX_FAST_STATS
+        if (lane == 0) atomicAdd(&g_fastStats[2 + 4 * pass], (unsigned long long)nC);
+#endif
         if (nC == 0) { if (last) break; else continue; }
 
         // stage 3: 3x3 non-max suppression on M_t = (S > t ? S-1 : 0), strict >, zero outside the

@@ -300,6 +300,51 @@ def test_two_handles_on_two_threads(gpu, oracle):
             assert_same(oex(frames[i][t]), *out[i][t])
 
 
+def test_one_handle_per_device_in_one_process(gpu, oracle):
+    """one host thread + one handle per GPU inside ONE process (MultipleRobotsScenario's one tracking thread
+    per robot, mono_kitti.cc:80-101).  With >= 2 visible devices: stream s on device s, each checked against the oracle
+    (extract + match vs previous frame).  A 1-GPU box cannot exercise device != 0: the test then says so and checks the
+    same layout with both handles on device 0."""
+    import threading
+    from orbslamm_amd import ORBextractor
+    ndev = gpu
+    if ndev < 2:
+        print("NOTE: only %d HIP device visible -- the two handles share device 0; device selection is NOT exercised here" % ndev)
+    w, h, nf = 640, 480, 1000
+    streams = [frames_for(w, h, 4, stream=20 + s) for s in range(2)]
+    res = [None, None]
+    errs = []
+
+    def robot(s):
+        try:
+            ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=4, device=s % ndev)
+            assert ex.device == s % ndev
+            d = ex.upload_frames(streams[s])
+            ex.extract_batch_device(*d)
+            ex.match_prev_batch_device(0.7, 50, True)
+            res[s] = [(ex.download(f), ex.download_matches(f)) for f in range(4)]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=robot, args=(s,)) for s in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    for s in range(2):
+        prev = None
+        for f in range(4):
+            ref = oex(streams[s][f])
+            (kps, desc), (m, nm) = res[s][f]
+            assert_same(ref, kps, desc)
+            if prev is not None:
+                rm, rn = oracle.match_bruteforce(ref["desc"], ref["kps"]["angle"], prev["desc"], prev["kps"]["angle"], 0.7, 50, True)
+                assert nm == rn and np.array_equal(m[:len(kps)], rm)
+            prev = ref
+    with pytest.raises(Exception):
+        ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, device=ndev)   # one past the last device
+
+
 def test_errors_do_not_poison_the_handle(gpu, oracle):
     from orbslamm_amd import OrbError
     gex = gpu_extractor(500, 320, 240, 2)
