@@ -356,9 +356,10 @@ def run_rank(args):
             torch.cuda.synchronize()
 
     import gc
-    for _ in range(args.warmup):
-        step()
-    sync()
+    # Everything that is not a step happens BEFORE the warm-up (collector, profiler events, result arrays), so that the
+    # W warm-up steps run straight into the barrier-bracketed timed region: an idle GPU drops its clocks within
+    # milliseconds and takes tens of milliseconds of load to bring them back -- with 8192 profiler events created between
+    # warm-up and timing a 20-step run (10 ms) read 122 k frames/s where the steady state is 133 k.
     gc.collect()
     gc.disable()  # no collector pause inside the timed region (the host only enqueues, ~0.15 ms per step)
     if not args.no_profile:
@@ -367,8 +368,26 @@ def run_rank(args):
         # (and those of one step in SAMPLE: ~1 %)
         ex.profile_select(DOMINANT)
         ex.profile_enable(True)
-        ex.profile_read(reset=True)
         state["sample"] = True
+    # Pool validation (untimed, before the W warm-up steps): every resident batch goes through the pipeline once, the
+    # device error flag is read (a scratch overflow on any batch would otherwise surface in the timed region) and each
+    # batch must yield keypoints.  It also leaves the stream with a previous frame and both result sets in use.  Stated
+    # openly because it matters for short runs: a step is 0.5 ms, so the driver's W = 5 is 2.4 ms of load, not enough for
+    # the GPU to reach its steady clocks (20 timed steps read 124 k frames/s after 5 warm-up steps alone, 134 k after 50;
+    # tools/short_run.sh) -- with this pass in front the warm-up starts on a GPU that has 8 ms of load behind it.
+    for p in range(pool):
+        step()
+    sync()   # orbx_sync returns the device error flag
+    state["n"] = 0
+    kp_check, _ = ex.download(B - 1)
+    if len(kp_check) == 0:
+        sys.stderr.write("bench.py: the pool's last batch yields no keypoints\n")
+        return 3
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        ex.profile_read(reset=True)  # drops the validation's and the warm-up's spans; synchronises, like the sync() below
+        state["i"] = 0
     dt = streams.timed_region(step, args.steps, sync, world)
     state["sample"] = False
     prof = ex.profile_read(reset=True) if not args.no_profile else {}
@@ -414,7 +433,8 @@ def run_rank(args):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config,
                        "frames_per_step_per_gpu": B, "streams": world, "parallelism": "1 independent stream per GPU",
-                       "resident_pool_frames_per_gpu": pool * B, "resident_pool_mb_per_gpu": pool * B * STRIDE * H / 1e6},
+                       "resident_pool_frames_per_gpu": pool * B, "resident_pool_mb_per_gpu": pool * B * STRIDE * H / 1e6,
+                       "pool_validation_steps_before_warmup": pool},
             "keypoints_last_frame": [int(g[1]) for g in gathered],
             "matches_last_frame": [int(g[2]) for g in gathered],
         }

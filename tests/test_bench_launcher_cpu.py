@@ -37,7 +37,7 @@ def _check_record(out, tmp_path):
     dumps = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
     for r, d in enumerate(dumps):
         assert d["rank"] == r and d["device"] == r and d["world"] == 2  # one process per GPU, rank r on GPU r
-        assert d["steps"] == 2 + 6 and len(d["uploads"]) == 3          # warmup + EXACTLY the timed steps; the pool
+        assert d["steps"] == 3 + 2 + 6 and len(d["uploads"]) == 3      # pool validation + warmup + EXACTLY the timed steps
     assert dumps[0]["uploads"] != dumps[1]["uploads"]                    # rank r feeds camera stream r, not a shared one
     return rec
 
