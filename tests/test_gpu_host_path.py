@@ -143,3 +143,44 @@ def test_host_and_device_paths_interleave(gpu, oracle):
     kps, desc, n, m, nm = ex.extract_match_host(fr[4:6], copy=True)
     for f in range(2):
         _check(ref[4 + f], kps[f], desc[f], int(n[f]), m[f], int(nm[f]))
+
+
+def test_soak_random_tickets(gpu, oracle):
+    """40 tickets of random sizes (1..8 frames, so latency-mode and throughput-mode calls alternate inside one stream),
+    pageable and pinned sources mixed, up to three in flight, collected as views or copies: every frame and every match
+    table equals the oracle's -- the hazards of the three-deep pipeline (result sets, match tables, staging slots, the
+    previous-frame slot) under an irregular schedule"""
+    from orbslamm_amd import ORBextractor
+    w, h, nf = 640, 480, 1000
+    rng = np.random.default_rng(77)
+    sizes = [int(rng.integers(1, 9)) for _ in range(40)]
+    fr = frames_for(w, h, sum(sizes), stream=6)
+    ref = _oracle_stream(oracle, fr, nf)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=8, device=0)
+    pins = [ex.alloc_pinned_frames(8, w, h) for _ in range(3)]
+    tickets, got, o = [], [], 0
+    for i, b in enumerate(sizes):
+        chunk = fr[o:o + b]
+        if rng.integers(0, 2):
+            p = pins[i % 3]
+            p.array[:b, :, :w] = chunk
+            src = [p.array[f, :, :w] for f in range(b)] if rng.integers(0, 2) else None
+            if src is None:   # the pinned buffer itself (device layout), first b frames
+                from orbslamm_amd.extractor import PinnedFrames
+                src = PinnedFrames(p.owner, p.ptr, b, w, h, p.stride, p.pitch)
+        else:
+            src = np.ascontiguousarray(chunk)
+        tickets.append((ex.submit_host(src), b))
+        o += b
+        while len(tickets) == 3 or (tickets and rng.integers(0, 3) == 0):
+            t, bb = tickets.pop(0)
+            got.append((ex.collect_host(t, view=False), bb))
+    while tickets:
+        t, bb = tickets.pop(0)
+        got.append((ex.collect_host(t, view=False), bb))
+    o = 0
+    for (kps, desc, n, m, nm), b in got:
+        for f in range(b):
+            _check(ref[o + f], kps[f], desc[f], int(n[f]), m[f], int(nm[f]))
+        o += b
+    assert o == sum(sizes)
