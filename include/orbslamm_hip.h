@@ -402,6 +402,16 @@ int orbm_frame_compute_bow(orbm_frame_t* f, orbv_t* voc, int levelsup, uint32_t*
 int orbm_search_by_bow_frames(orbm_t* h, orbm_frame_t* q, const uint8_t* qvalid, orbm_frame_t* t, const uint8_t* tvalid,
                               float nnratio, int check_ori, int out_by_train, int32_t* match, int* nmatches);
 
+/* orbm_window_best with a device-resident frame as train side (the KeyFrame of Fuse / Fuse(Scw) / SearchBySim3; mono) */
+int orbm_window_best_frame(orbm_t* h, const float* q_uvr, const int8_t* q_pred, const uint8_t* qdesc, const uint8_t* qvalid, int nq,
+                           orbm_frame_t* train, const float* inv_sigma2, int nlevels, int chi2,
+                           int32_t* best_idx, int32_t* best_dist);
+/* orbm_search_for_triangulation between two device-resident frames that ran orbm_frame_compute_bow (mono);
+ * skip1 / skip2 (host): the feature already has a MapPoint */
+int orbm_search_for_triangulation_frames(orbm_t* h, orbm_frame_t* f1, const uint8_t* skip1, orbm_frame_t* f2, const uint8_t* skip2,
+                                         const float F12[9], float ex, float ey, const float* sf2, const float* sigma2_2, int nlevels,
+                                         int check_ori, int32_t* matches12, int* nmatches);
+
 /* orbm_search_for_initialization between two device-resident frames (F1 = the initial frame, F2 = the current one);
  * q_xy = vbPrevMatched (host, F1 size), matches12: F1 size */
 int orbm_search_for_initialization_frames(orbm_t* h, const float* q_xy, float window_size, orbm_frame_t* f1, orbm_frame_t* f2,

@@ -2331,41 +2331,28 @@ extern "C" int orbm_search_by_projection_frame(orbm_t* h, const OrbmProjParams* 
     return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, tr, t_occ, assign, nmatches);
 }
 
-// ------------------------------------------------------------------ SURVEY 8(f).1 entry points
-extern "C" int orbm_window_best(orbm_t* h, const float* q_uvr, const float* q_ur, const int8_t* q_pred,
-                                const uint8_t* qdesc, const uint8_t* qvalid, int nq,
-                                const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc,
-                                const float* t_uright, int nt, const float* inv_sigma2, int nlevels, int chi2,
-                                int32_t* best_idx, int32_t* best_dist)
+// train side of a windowed best search, resident in HBM
+static int window_core(orbm_handle* h, const float* q_uvr, const float* q_ur, const int8_t* q_pred, const uint8_t* qdesc,
+                       const uint8_t* qvalid, int nq, const ProjTrain& tr, const float* d_turight, const float* inv_sigma2,
+                       int nlevels, int chi2, int32_t* best_idx, int32_t* best_dist)
 {
-    int rc = orbm_check(h);
-    if (rc) return rc;
-    if (nq < 0 || nt < 0 || (nq && (!q_uvr || !q_pred || !qdesc || !best_idx || !best_dist)) || (nt && (!t_keys_un || !tdesc)))
-        return fail(ORBX_E_INVALID, "bad argument");
-    if (chi2 && (!inv_sigma2 || nlevels < 1 || nlevels > 16)) return fail(ORBX_E_INVALID, "inv_sigma2 required for the chi-square test");
-    if (chi2 && t_uright && !q_ur) return fail(ORBX_E_INVALID, "q_ur required with t_uright");
-    for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
-    if (nq == 0 || nt == 0) return ORBX_OK;
-    orbm::GridDev gd;
-    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, gd))) return rc;
+    int rc;
     enum { S_UVR, S_UR, S_PRED, S_QD, S_QV, S_TD, S_TUR, S_SIG, S_BI, S_BD };
-    const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 4, (size_t)nq, (size_t)nq * 32, (size_t)nq, (size_t)nt * 32,
-                            (size_t)nt * 4, 64, (size_t)nq * 4, (size_t)nq * 4};
-    for (int i = 0; i < 10; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 4, (size_t)nq, (size_t)nq * 32, (size_t)nq, 16, 16, 64, (size_t)nq * 4, (size_t)nq * 4};
+    for (int i = 0; i < 10; i++) if (i != S_TD && i != S_TUR && (rc = orbm_reserve(h, i, sizes[i]))) return rc;
     hipStream_t s = h->stream;
-    UP(S_UVR, q_uvr, (size_t)nq * 12); UP(S_PRED, q_pred, (size_t)nq); UP(S_QD, qdesc, (size_t)nq * 32); UP(S_TD, tdesc, (size_t)nt * 32);
+    UP(S_UVR, q_uvr, (size_t)nq * 12); UP(S_PRED, q_pred, (size_t)nq); UP(S_QD, qdesc, (size_t)nq * 32);
     if (q_ur) UP(S_UR, q_ur, (size_t)nq * 4);
     if (qvalid) UP(S_QV, qvalid, (size_t)nq);
-    if (t_uright) UP(S_TUR, t_uright, (size_t)nt * 4);
     if (chi2) UP(S_SIG, inv_sigma2, (size_t)nlevels * 4);
     orbm::WinArgs a{};
-    a.grid = gd;
-    a.tkeys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
-    a.cellStart = (const int32_t*)h->d_buf[G_START]; a.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    a.grid = tr.gd;
+    a.tkeys = tr.keys;
+    a.cellStart = tr.cellStart; a.cellIdx = tr.cellIdx;
     a.quvr = (const float*)h->d_buf[S_UVR]; a.qur = q_ur ? (const float*)h->d_buf[S_UR] : nullptr;
     a.qpred = (const int8_t*)h->d_buf[S_PRED]; a.qdesc = (const uint8_t*)h->d_buf[S_QD];
     a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
-    a.tdesc = (const uint8_t*)h->d_buf[S_TD]; a.turight = t_uright ? (const float*)h->d_buf[S_TUR] : nullptr;
+    a.tdesc = tr.desc; a.turight = d_turight;
     a.invSigma2 = (const float*)h->d_buf[S_SIG];
     a.nq = nq; a.chi2 = chi2;
     a.bestIdx = (int32_t*)h->d_buf[S_BI]; a.bestDist = (int32_t*)h->d_buf[S_BD];
@@ -2375,6 +2362,57 @@ extern "C" int orbm_window_best(orbm_t* h, const float* q_uvr, const float* q_ur
     HIPCHK(hipMemcpyAsync(best_dist, a.bestDist, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return ORBX_OK;
+}
+
+static int window_check(orbm_handle* h, const float* q_uvr, const float* q_ur, const int8_t* q_pred, const uint8_t* qdesc, int nq, int nt,
+                        const float* t_uright, const float* inv_sigma2, int nlevels, int chi2, int32_t* best_idx, int32_t* best_dist)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (nq < 0 || nt < 0 || (nq && (!q_uvr || !q_pred || !qdesc || !best_idx || !best_dist))) return fail(ORBX_E_INVALID, "bad argument");
+    if (chi2 && (!inv_sigma2 || nlevels < 1 || nlevels > 16)) return fail(ORBX_E_INVALID, "inv_sigma2 required for the chi-square test");
+    if (chi2 && t_uright && !q_ur) return fail(ORBX_E_INVALID, "q_ur required with t_uright");
+    for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------ SURVEY 8(f).1 entry points
+extern "C" int orbm_window_best(orbm_t* h, const float* q_uvr, const float* q_ur, const int8_t* q_pred,
+                                const uint8_t* qdesc, const uint8_t* qvalid, int nq,
+                                const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc,
+                                const float* t_uright, int nt, const float* inv_sigma2, int nlevels, int chi2,
+                                int32_t* best_idx, int32_t* best_dist)
+{
+    int rc = window_check(h, q_uvr, q_ur, q_pred, qdesc, nq, nt, t_uright, inv_sigma2, nlevels, chi2, best_idx, best_dist);
+    if (rc) return rc;
+    if (nt && (!t_keys_un || !tdesc)) return fail(ORBX_E_INVALID, "bad argument");
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    ProjTrain tr;
+    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, tr.gd))) return rc;
+    enum { S_TD = 5, S_TUR = 6 };
+    if ((rc = orbm_reserve(h, S_TD, (size_t)nt * 32)) || (rc = orbm_reserve(h, S_TUR, (size_t)nt * 4))) return rc;
+    hipStream_t s = h->stream;
+    UP(S_TD, tdesc, (size_t)nt * 32);
+    if (t_uright) UP(S_TUR, t_uright, (size_t)nt * 4);
+    tr.keys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
+    tr.cellStart = (const int32_t*)h->d_buf[G_START]; tr.cellIdx = (const int32_t*)h->d_buf[G_IDX];
+    tr.desc = (const uint8_t*)h->d_buf[S_TD];
+    tr.nt = nt;
+    return window_core(h, q_uvr, q_ur, q_pred, qdesc, qvalid, nq, tr, t_uright ? (const float*)h->d_buf[S_TUR] : nullptr, inv_sigma2,
+                       nlevels, chi2, best_idx, best_dist);
+}
+
+// the same with a device-resident frame as train side (the KeyFrame of Fuse / SearchBySim3; mono: no right coordinates)
+extern "C" int orbm_window_best_frame(orbm_t* h, const float* q_uvr, const int8_t* q_pred, const uint8_t* qdesc, const uint8_t* qvalid, int nq,
+                                      orbm_frame_t* train, const float* inv_sigma2, int nlevels, int chi2,
+                                      int32_t* best_idx, int32_t* best_dist)
+{
+    if (!train || train->owner != h) return fail(ORBX_E_INVALID, "frame does not belong to this matcher handle");
+    int rc = window_check(h, q_uvr, nullptr, q_pred, qdesc, nq, train->n, nullptr, inv_sigma2, nlevels, chi2, best_idx, best_dist);
+    if (rc) return rc;
+    if (nq == 0 || train->n == 0) return ORBX_OK;
+    ProjTrain tr = {train->gd, train->d_keysUn, train->d_start, train->d_idx, train->d_desc, train->n};
+    return window_core(h, q_uvr, nullptr, q_pred, qdesc, qvalid, nq, tr, nullptr, inv_sigma2, nlevels, chi2, best_idx, best_dist);
 }
 
 // query side (F1) of SearchForInitialization resident in HBM: descriptors, angles, "octave 0" flags
@@ -2478,6 +2516,64 @@ extern "C" int orbm_search_for_initialization_frames(orbm_t* h, const float* q_x
     return init_core(h, q_xy, window_size, f1->d_desc, f1->d_ang, (const uint8_t*)h->d_buf[4], nq, tr, nnratio, check_ori, matches12, nmatches);
 }
 
+// one side of SearchForTriangulation resident in HBM (node ids on the host for the lock-step walk)
+struct TriSide {
+    const orbm::KeyDev* keys; const uint8_t* desc; int n;
+    const int32_t* d_start; const int32_t* d_idx; const uint32_t* node_id; int n_nodes;
+    const uint8_t* skip; const float* uright;   // host arrays (uploaded here), may be null
+};
+
+static int tri_core(orbm_handle* h, const TriSide& A, const TriSide& B, const float F12[9], float ex, float ey, const float* sf2,
+                    const float* sigma2_2, int nlevels, int only_stereo, int check_ori, int32_t* matches12, int* nmatches)
+{
+    int rc;
+    const int n1 = A.n, n2 = B.n;
+    std::vector<int32_t> pa, pb;
+    {
+        int a = 0, b = 0;
+        while (a < A.n_nodes && b < B.n_nodes) {
+            if (A.node_id[a] == B.node_id[b]) { pa.push_back(a); pb.push_back(b); a++; b++; }
+            else if (A.node_id[a] < B.node_id[b]) a++;
+            else b++;
+        }
+    }
+    const int npairs = (int)pa.size();
+    if (npairs == 0) return ORBX_OK;
+    enum { S_S1 = 2, S_U1 = 3, S_S2 = 6, S_U2 = 7, S_PA = 12, S_PB = 13, S_M12 = 14, S_BIN = 15, S_HIST = 23 };
+    const int slots[] = {S_S1, S_U1, S_S2, S_U2, S_PA, S_PB, S_M12, S_BIN, S_HIST};
+    const size_t sizes[] = {(size_t)n1, (size_t)n1 * 4, (size_t)n2, (size_t)n2 * 4, (size_t)npairs * 4, (size_t)npairs * 4, (size_t)n1 * 4, (size_t)n1, 34 * 4};
+    for (int i = 0; i < 9; i++) if ((rc = orbm_reserve(h, slots[i], sizes[i]))) return rc;
+    hipStream_t s = h->stream;
+    if (A.skip) UP(S_S1, A.skip, (size_t)n1);
+    if (B.skip) UP(S_S2, B.skip, (size_t)n2);
+    if (A.uright) UP(S_U1, A.uright, (size_t)n1 * 4);
+    if (B.uright) UP(S_U2, B.uright, (size_t)n2 * 4);
+    UP(S_PA, pa.data(), (size_t)npairs * 4); UP(S_PB, pb.data(), (size_t)npairs * 4);
+    HIPCHK(hipMemsetAsync(h->d_buf[S_M12], 0xFF, (size_t)n1 * 4, s));
+    HIPCHK(hipMemsetAsync(h->d_buf[S_HIST], 0, 34 * 4, s));
+    orbm::TriArgs a{};
+    a.k1 = A.keys; a.d1 = A.desc;
+    a.skip1 = A.skip ? (const uint8_t*)h->d_buf[S_S1] : nullptr; a.ur1 = A.uright ? (const float*)h->d_buf[S_U1] : nullptr;
+    a.k2 = B.keys; a.d2 = B.desc;
+    a.skip2 = B.skip ? (const uint8_t*)h->d_buf[S_S2] : nullptr; a.ur2 = B.uright ? (const float*)h->d_buf[S_U2] : nullptr;
+    a.start1 = A.d_start; a.idx1 = A.d_idx; a.start2 = B.d_start; a.idx2 = B.d_idx;
+    a.pairA = (const int32_t*)h->d_buf[S_PA]; a.pairB = (const int32_t*)h->d_buf[S_PB];
+    for (int i = 0; i < 9; i++) a.F[i] = F12[i];
+    a.ex = ex; a.ey = ey;
+    for (int i = 0; i < 16; i++) { a.sf2[i] = i < nlevels ? sf2[i] : 0.f; a.sigma2[i] = i < nlevels ? sigma2_2[i] : 0.f; }
+    a.onlyStereo = only_stereo; a.checkOri = check_ori;
+    a.m12 = (int32_t*)h->d_buf[S_M12]; a.binOf = (uint8_t*)h->d_buf[S_BIN]; a.hist = (int32_t*)h->d_buf[S_HIST];
+    hipLaunchKernelGGL(orbm::k_triangulation_pairs, dim3(npairs), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(orbm::k_prune_flat, dim3(1), dim3(256), 0, s, a.m12, n1, check_ori, (const uint8_t*)a.binOf, a.hist, a.hist + 32);
+    HIPCHK(hipGetLastError());
+    int32_t nm = 0;
+    HIPCHK(hipMemcpyAsync(matches12, a.m12, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&nm, a.hist + 32, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nmatches) *nmatches = nm;
+    return ORBX_OK;
+}
+
 extern "C" int orbm_search_for_triangulation(orbm_t* h,
                                              const OrbxKeyPoint* k1, const uint8_t* d1, const uint8_t* skip1, const float* uright1, int n1,
                                              const OrbmFeatVec* fv1,
@@ -2494,61 +2590,43 @@ extern "C" int orbm_search_for_triangulation(orbm_t* h,
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (nmatches) *nmatches = 0;
     if (n1 == 0 || n2 == 0) return ORBX_OK;
-    std::vector<int32_t> pa, pb;
-    {
-        int a = 0, b = 0;
-        while (a < fv1->n_nodes && b < fv2->n_nodes) {
-            if (fv1->node_id[a] == fv2->node_id[b]) { pa.push_back(a); pb.push_back(b); a++; b++; }
-            else if (fv1->node_id[a] < fv2->node_id[b]) a++;
-            else b++;
-        }
-    }
-    const int npairs = (int)pa.size();
-    if (npairs == 0) return ORBX_OK;
     const int ni1 = fv1->start[fv1->n_nodes], ni2 = fv2->start[fv2->n_nodes];
     for (int i = 0; i < ni1; i++) if (fv1->idx[i] < 0 || fv1->idx[i] >= n1) return fail(ORBX_E_INVALID, "feature index out of range");
     for (int i = 0; i < ni2; i++) if (fv2->idx[i] < 0 || fv2->idx[i] >= n2) return fail(ORBX_E_INVALID, "feature index out of range");
-    enum { S_K1, S_D1, S_S1, S_U1, S_K2, S_D2, S_S2, S_U2, S_ST1, S_I1, S_ST2, S_I2, S_PA, S_PB, S_M12, S_BIN, S_HIST };
-    const size_t sizes[] = {(size_t)n1 * 28, (size_t)n1 * 32, (size_t)n1, (size_t)n1 * 4, (size_t)n2 * 28, (size_t)n2 * 32, (size_t)n2,
-                            (size_t)n2 * 4, (size_t)(fv1->n_nodes + 1) * 4, (size_t)std::max(ni1, 1) * 4,
-                            (size_t)(fv2->n_nodes + 1) * 4, (size_t)std::max(ni2, 1) * 4, (size_t)npairs * 4, (size_t)npairs * 4,
-                            (size_t)n1 * 4, (size_t)n1, 34 * 4};
-    for (int i = 0; i < 17; i++) if ((rc = orbm_reserve(h, i, sizes[i]))) return rc;
+    enum { S_K1 = 0, S_D1 = 1, S_K2 = 4, S_D2 = 5, S_ST1 = 8, S_I1 = 9, S_ST2 = 10, S_I2 = 11 };
+    const int slots[] = {S_K1, S_D1, S_K2, S_D2, S_ST1, S_I1, S_ST2, S_I2};
+    const size_t sizes[] = {(size_t)n1 * 28, (size_t)n1 * 32, (size_t)n2 * 28, (size_t)n2 * 32, (size_t)(fv1->n_nodes + 1) * 4,
+                            (size_t)std::max(ni1, 1) * 4, (size_t)(fv2->n_nodes + 1) * 4, (size_t)std::max(ni2, 1) * 4};
+    for (int i = 0; i < 8; i++) if ((rc = orbm_reserve(h, slots[i], sizes[i]))) return rc;
     hipStream_t s = h->stream;
     UP(S_K1, k1, (size_t)n1 * 28); UP(S_D1, d1, (size_t)n1 * 32); UP(S_K2, k2, (size_t)n2 * 28); UP(S_D2, d2, (size_t)n2 * 32);
-    if (skip1) UP(S_S1, skip1, (size_t)n1);
-    if (skip2) UP(S_S2, skip2, (size_t)n2);
-    if (uright1) UP(S_U1, uright1, (size_t)n1 * 4);
-    if (uright2) UP(S_U2, uright2, (size_t)n2 * 4);
     UP(S_ST1, fv1->start, (size_t)(fv1->n_nodes + 1) * 4);
     if (ni1) UP(S_I1, fv1->idx, (size_t)ni1 * 4);
     UP(S_ST2, fv2->start, (size_t)(fv2->n_nodes + 1) * 4);
     if (ni2) UP(S_I2, fv2->idx, (size_t)ni2 * 4);
-    UP(S_PA, pa.data(), (size_t)npairs * 4); UP(S_PB, pb.data(), (size_t)npairs * 4);
-    HIPCHK(hipMemsetAsync(h->d_buf[S_M12], 0xFF, (size_t)n1 * 4, s));
-    HIPCHK(hipMemsetAsync(h->d_buf[S_HIST], 0, 34 * 4, s));
-    orbm::TriArgs a{};
-    a.k1 = (const orbm::KeyDev*)h->d_buf[S_K1]; a.d1 = (const uint8_t*)h->d_buf[S_D1];
-    a.skip1 = skip1 ? (const uint8_t*)h->d_buf[S_S1] : nullptr; a.ur1 = uright1 ? (const float*)h->d_buf[S_U1] : nullptr;
-    a.k2 = (const orbm::KeyDev*)h->d_buf[S_K2]; a.d2 = (const uint8_t*)h->d_buf[S_D2];
-    a.skip2 = skip2 ? (const uint8_t*)h->d_buf[S_S2] : nullptr; a.ur2 = uright2 ? (const float*)h->d_buf[S_U2] : nullptr;
-    a.start1 = (const int32_t*)h->d_buf[S_ST1]; a.idx1 = (const int32_t*)h->d_buf[S_I1];
-    a.start2 = (const int32_t*)h->d_buf[S_ST2]; a.idx2 = (const int32_t*)h->d_buf[S_I2];
-    a.pairA = (const int32_t*)h->d_buf[S_PA]; a.pairB = (const int32_t*)h->d_buf[S_PB];
-    for (int i = 0; i < 9; i++) a.F[i] = F12[i];
-    a.ex = ex; a.ey = ey;
-    for (int i = 0; i < 16; i++) { a.sf2[i] = i < nlevels ? sf2[i] : 0.f; a.sigma2[i] = i < nlevels ? sigma2_2[i] : 0.f; }
-    a.onlyStereo = only_stereo; a.checkOri = check_ori;
-    a.m12 = (int32_t*)h->d_buf[S_M12]; a.binOf = (uint8_t*)h->d_buf[S_BIN]; a.hist = (int32_t*)h->d_buf[S_HIST];
-    hipLaunchKernelGGL(orbm::k_triangulation_pairs, dim3(npairs), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(orbm::k_prune_flat, dim3(1), dim3(256), 0, s, a.m12, n1, check_ori, (const uint8_t*)a.binOf, a.hist, a.hist + 32);
-    HIPCHK(hipGetLastError());
-    int32_t nm = 0;
-    HIPCHK(hipMemcpyAsync(matches12, a.m12, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&nm, a.hist + 32, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (nmatches) *nmatches = nm;
-    return ORBX_OK;
+    const TriSide A = {(const orbm::KeyDev*)h->d_buf[S_K1], (const uint8_t*)h->d_buf[S_D1], n1, (const int32_t*)h->d_buf[S_ST1],
+                       (const int32_t*)h->d_buf[S_I1], fv1->node_id, fv1->n_nodes, skip1, uright1};
+    const TriSide B = {(const orbm::KeyDev*)h->d_buf[S_K2], (const uint8_t*)h->d_buf[S_D2], n2, (const int32_t*)h->d_buf[S_ST2],
+                       (const int32_t*)h->d_buf[S_I2], fv2->node_id, fv2->n_nodes, skip2, uright2};
+    return tri_core(h, A, B, F12, ex, ey, sf2, sigma2_2, nlevels, only_stereo, check_ori, matches12, nmatches);
+}
+
+// SearchForTriangulation between two device-resident frames that ran orbm_frame_compute_bow (mono: no right coordinates)
+extern "C" int orbm_search_for_triangulation_frames(orbm_t* h, orbm_frame_t* f1, const uint8_t* skip1, orbm_frame_t* f2, const uint8_t* skip2,
+                                                    const float F12[9], float ex, float ey, const float* sf2, const float* sigma2_2, int nlevels,
+                                                    int check_ori, int32_t* matches12, int* nmatches)
+{
+    int rc = orbm_check(h);
+    if (rc) return rc;
+    if (!f1 || !f2 || f1->owner != h || f2->owner != h) return fail(ORBX_E_INVALID, "frames do not belong to this matcher handle");
+    if (!f1->hasBow || !f2->hasBow) return fail(ORBX_E_INVALID, "orbm_frame_compute_bow has not run on both frames");
+    if (!F12 || !sf2 || !sigma2_2 || nlevels < 1 || nlevels > 16 || (f1->n && !matches12)) return fail(ORBX_E_INVALID, "bad argument");
+    for (int i = 0; i < f1->n; i++) matches12[i] = -1;
+    if (nmatches) *nmatches = 0;
+    if (f1->n == 0 || f2->n == 0 || f1->fvNodes == 0 || f2->fvNodes == 0) return ORBX_OK;
+    const TriSide A = {f1->d_keysUn, f1->d_desc, f1->n, f1->d_fvStart, f1->d_fvIdx, f1->fvNode.data(), f1->fvNodes, skip1, nullptr};
+    const TriSide B = {f2->d_keysUn, f2->d_desc, f2->n, f2->d_fvStart, f2->d_fvIdx, f2->fvNode.data(), f2->fvNodes, skip2, nullptr};
+    return tri_core(h, A, B, F12, ex, ey, sf2, sigma2_2, nlevels, 0, check_ori, matches12, nmatches);
 }
 #undef UP
 

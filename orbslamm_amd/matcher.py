@@ -178,6 +178,34 @@ class ORBmatcher:
                                                       ptr(qv), ptr(qo), q_uvr.shape[0], frame, ptr(t_occ), ptr(assign), C.byref(n)))
         return assign, t_occ, n.value
 
+    def window_best_frame(self, q_uvr, q_pred, qdesc, qvalid, frame, inv_sigma2=None, chi2=False):
+        """orbm_window_best with a device-resident frame as train side (the KeyFrame of Fuse / SearchBySim3)"""
+        q_uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
+        q_pred = np.ascontiguousarray(q_pred, dtype=np.int8)
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.uint8)
+        qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+        sig = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, dtype=np.float32)
+        nq = q_uvr.shape[0]
+        bi = np.full(max(nq, 1), -1, np.int32)
+        bd = np.full(max(nq, 1), 256, np.int32)
+        check(self._L.orbm_window_best_frame(self._h, ptr(q_uvr), ptr(q_pred), ptr(qdesc), ptr(qv), nq, frame, ptr(sig),
+                                             0 if sig is None else sig.shape[0], int(bool(chi2)), ptr(bi), ptr(bd)))
+        return bi[:nq], bd[:nq]
+
+    def SearchForTriangulationFrames(self, f1, skip1, f2, skip2, F12, ex, ey, sf2, sigma2_2):
+        """SearchForTriangulation between two device-resident frames that ran frame_compute_bow"""
+        s1 = None if skip1 is None else np.ascontiguousarray(skip1, dtype=np.uint8)
+        s2 = None if skip2 is None else np.ascontiguousarray(skip2, dtype=np.uint8)
+        F = np.ascontiguousarray(F12, dtype=np.float32).reshape(9)
+        sf2 = np.ascontiguousarray(sf2, dtype=np.float32)
+        sg2 = np.ascontiguousarray(sigma2_2, dtype=np.float32)
+        n1 = self._L.orbm_frame_size(f1)
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._L.orbm_search_for_triangulation_frames(self._h, f1, ptr(s1), f2, ptr(s2), ptr(F), C.c_float(ex), C.c_float(ey),
+                                                           ptr(sf2), ptr(sg2), sf2.shape[0], int(self.mbCheckOrientation), ptr(m12), C.byref(n)))
+        return m12[:n1], n.value
+
     # ---- SURVEY.md 8(f) rank 1
     def window_best(self, q_uvr, q_pred, qdesc, qvalid, grid, t_keys_un, tdesc, inv_sigma2=None, chi2=False,
                     q_ur=None, t_uright=None):

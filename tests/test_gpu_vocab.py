@@ -98,5 +98,29 @@ def test_tracking_front_end_stays_in_hbm(gpu, oracle):
         gi, gni = m.SearchForInitializationFrames(q_xy, 100.0, frames[0], frames[1])
         wi, wni = oracle.search_for_initialization(q_xy, 100.0, k0, d0, gp, k1, start, idx, d1, ratio, ori)
         assert gni == wni and np.array_equal(gi, wi) and wni > 30
+        # SearchForTriangulation between the two device frames (ORBmatcher.cc:659): descriptors, keys and FeatureVectors
+        # stay in HBM, only the "already has a MapPoint" flags and the fundamental matrix come from the host.
+        # F12 of a pure sideways translation: epipolar lines are the rows, the epipole lies at infinity
+        sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+        F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=np.float32)
+        s1 = (rng.uniform(size=len(k0)) < 0.3).astype(np.uint8)
+        s2 = (rng.uniform(size=len(k1)) < 0.3).astype(np.uint8)
+        gt, gnt = m.SearchForTriangulationFrames(frames[0], s1, frames[1], s2, F12, 1.0e6, 240.0, sf, sf * sf)
+        wt, wnt = oracle.search_for_triangulation(k0, d0, s1, fvs[0], k1, d1, s2, fvs[1], F12, 1.0e6, 240.0, sf, sf * sf, False, ori)
+        assert gnt == wnt and np.array_equal(gt, wt) and wnt > 20
+        # the windowed best search of Fuse / SearchBySim3 with the device frame as train side
+        nq = 600
+        pick = rng.integers(0, len(k1), nq)
+        uvr = np.stack([k1["x"][pick] + rng.uniform(-2, 2, nq), k1["y"][pick] + rng.uniform(-2, 2, nq),
+                        3.0 * sf[np.clip(k1["octave"][pick], 0, 7)]], axis=1).astype(np.float32)
+        pred = np.clip(k1["octave"][pick] + rng.integers(0, 2, nq), 0, 7).astype(np.int8)
+        qd = d1[pick].copy()
+        flip = rng.integers(0, 32, nq)
+        qd[np.arange(nq), flip] ^= np.uint8(5)
+        inv = (1.0 / (sf * sf)).astype(np.float32)
+        for chi2 in (False, True):
+            bi, bd = m.window_best_frame(uvr, pred, qd, None, frames[1], inv, chi2)
+            wi_, wd_ = oracle.window_best(uvr, pred, qd, None, gp, k1, start, idx, d1, inv, chi2)
+            assert np.array_equal(bi, wi_) and np.array_equal(bd, wd_) and (wi_ >= 0).sum() > 300
         for F in frames:
             m.frame_destroy(F)
