@@ -173,14 +173,12 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
             const int yy0 = tid / cols, gx = gxb + tid - yy0 * cols;
             if (yy0 < dr) {
                 int sx[4], a0[4], a1[4];
-                bool interp[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint2 xt = sxt[4 * gx + i];
                     sx[i] = (int)(xt.x & 0xFFFF) - pnx0;
                     a0[i] = (int16_t)(xt.x >> 16);
                     a1[i] = (int16_t)(xt.y & 0xFFFF);
-                    interp[i] = (xt.y >> 16) != 0;
                 }
                 const int dx = c.nx0 + 4 * gx;
                 const bool ownX = dx >= c.ox0 && dx < c.ox1;
@@ -193,15 +191,12 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
                     uint32_t packed = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
+                        // columns past xmax (cv::resize's `D[dx] = S[sx] * ONE` tail) carry a0 = 2048, a1 = 0 in the table,
+                        // so the two-tap form is exact there too (the second tap may read the tile's padding: times zero) --
+                        // no per-pixel branch, all sixteen LDS reads of the row in flight together
                         const int s00 = ldsb[o0 + sx[i]], s10 = ldsb[o1 + sx[i]];
-                        int r0, r1;
-                        if (interp[i]) {
-                            r0 = s00 * a0[i] + ldsb[o0 + sx[i] + 1] * a1[i];
-                            r1 = s10 * a0[i] + ldsb[o1 + sx[i] + 1] * a1[i];
-                        } else {
-                            r0 = s00 * 2048;
-                            r1 = s10 * 2048;
-                        }
+                        const int r0 = s00 * a0[i] + ldsb[o0 + sx[i] + 1] * a1[i];
+                        const int r1 = s10 * a0[i] + ldsb[o1 + sx[i] + 1] * a1[i];
                         const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
                         packed |= (uint32_t)(v & 0xFF) << (8 * i);
                     }
@@ -1216,9 +1211,13 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         r4[2] = dot(O[4], K3, dot(O[3], K2, dot(O[2], K1, dot(O[1], K0, 1u << 15))));
         r4[3] = dot(P[5], K3, dot(P[4], K2, dot(P[3], K1, dot(P[2], K0, 1u << 15))));
         if (rq + 8 * k < nrows) {
-            uint32_t pk = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) pk |= min(r4[i] >> 16, 255u) << (8 * i);
+            // (sum + 2^15) >> 16, saturated (the sum can reach 257 * 257 * 255): the four high halves through
+            // v_sat_pk_u8_i16, two per instruction, instead of shift + min + shift-or per pixel
+            const uint32_t h01 = __builtin_amdgcn_perm(r4[1], r4[0], 0x07060302u), h23 = __builtin_amdgcn_perm(r4[3], r4[2], 0x07060302u);
+            uint32_t p01, p23;
+            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p01) : "v"(h01));
+            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p23) : "v"(h23));
+            const uint32_t pk = (p01 & 0xFFFFu) | (p23 << 16);
             *(uint32_t*)(D + (int64_t)(8 * k) * L.blurStride) = pk;
         }
     }
