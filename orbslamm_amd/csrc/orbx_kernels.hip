@@ -1100,6 +1100,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
     int stride;
     const uint8_t* S = level_ptr(g, src, f, l, stride);
     const int tid = threadIdx.x;
+    bool patchCols = false;
 
     // (TH+6)*IN_DW = 1216 dwords, 5 per thread (rows tid/32 + 8k of dword column tid%32), all loads issued
     // before the first LDS store.  Tiles that touch no image border (block-uniform test) skip the reflection.
@@ -1112,6 +1113,20 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
             const uint8_t* p = S + (int64_t)(ty0 - 3 + r0) * stride + x0;
 #pragma unroll
             for (int k = 0; k < PER; k++) regs[k] = *(const uint32_t*)(p + (int64_t)min(8 * k, TH + 5 - r0) * stride);
+        } else if (w >= 12 && h >= 12) {
+            // Border tile, the usual case (every tile of the small levels, a third of level 0): rows are reflected in the
+            // load (one reflection covers a 3 px halo), columns are loaded as clamped aligned dwords and the few halo
+            // bytes that lie outside the image are patched IN LDS below -- round 1 reflected them byte by byte in the
+            // load, which every wave of a left/right border tile paid with ~290 instructions (all eight waves hold a
+            // lane of dword column 0 and 31).
+            const int xs = min(max(x0, 0), (w - 1) & ~3);   // valid aligned address for every lane
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int yy = ty0 + min(r0 + 8 * k, TH + 5) - 3;
+                const int sy = min(max(yy < 0 ? -yy : (yy >= h ? 2 * h - 2 - yy : yy), 0), h - 1);
+                regs[k] = *(const uint32_t*)(S + (int64_t)sy * stride + xs);
+            }
+            patchCols = true;
         } else {
             const bool edge = !(x0 >= 0 && x0 + 3 < w);
             const int xs = min(max(x0, 0), (w - 1) & ~3);   // valid aligned address for every lane
@@ -1136,6 +1151,21 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
             if (r0 + 8 * k < TH + 6) in[(r0 + 8 * k) * IN_STRIDE + c] = regs[k];
     }
     __syncthreads();
+    if (patchCols && (tx0 == 0 || tx0 + TW + 4 > w)) {  // block-uniform
+        uint8_t* const inb = (uint8_t*)in;
+        if (tx0 == 0 && tid < TH + 6) {
+            // x = -4 .. -1 (dword column 0) mirror x = 4 .. 1 (BORDER_REFLECT_101)
+            const uint32_t d1 = in[tid * IN_STRIDE + 1], d2 = in[tid * IN_STRIDE + 2];
+            in[tid * IN_STRIDE] = __builtin_amdgcn_perm(d2, d1, 0x01020304u);  // d2.b0, d1.b3, d1.b2, d1.b1
+        }
+        if (tx0 + TW + 4 > w && tid >= 64 && tid < 64 + 4 * (TH + 6)) {
+            // x = w + k mirrors x = w - 2 - k; only the three columns right of the image are ever read
+            const int r = (tid - 64) >> 2, k = (tid - 64) & 3;
+            const int bd = w + k - (tx0 - 4), bs = w - 2 - k - (tx0 - 4);
+            if (bd < 4 * IN_DW && bs >= 0) inb[r * IN_STRIDE * 4 + bd] = inb[r * IN_STRIDE * 4 + bs];
+        }
+        __syncthreads();
+    }
 
     // vertical pass: thread = (dword column c, group of 4 output rows); rows 4rg .. 4rg+9 of the input tile
     {
