@@ -232,6 +232,7 @@ struct orbx_handle {
     hipEvent_t evMatched[2] = {nullptr, nullptr};  // the batch's match tables are final (recorded before the roll of the previous frame)
     size_t partialSlots = 0;                  // (frame, chunk) slots of d_partial
     bool matchPopcount = false;               // ORBX_MATCH_POPCOUNT=1: xor/popcount scan instead of the int8 MFMA scan
+    bool blurMfma = false;                    // ORBX_BLUR_MFMA=1: the Gaussian as int8 products on the matrix cores (k_blur_mfma) instead of k_blur
     // device buffers (sized for maxW x maxH x maxB at create)
     Geom* d_geom = nullptr;
     Cell* d_cells = nullptr; size_t cellsCap = 0;
@@ -616,6 +617,8 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     h->device = device;
     { const char* e = getenv("ORBX_SERIAL"); h->serial = e && e[0] == '1'; }
     { const char* e = getenv("ORBX_MATCH_POPCOUNT"); h->matchPopcount = e && e[0] == '1'; }
+    // the matrix-core form of the Gaussian (k_blur_mfma): same bytes, faster alone, slower beside k_match_mfma
+    { const char* e = getenv("ORBX_BLUR_MFMA"); h->blurMfma = e && e[0] == '1'; }
     { const char* e = getenv("ORBX_SPLIT"); if (e && e[0] >= '1' && e[0] <= '4') h->nsplit = e[0] - '0'; }
     h->maxW = max_w; h->maxH = max_h; h->maxB = max_batch;
     if (device < 0) { *out = h; return ORBX_OK; }  // host-only handle: tables and geometry queries
@@ -915,7 +918,10 @@ struct Launcher {
     void blur(hipStream_t s) const
     {
         h->prof.begin(P_BLUR, s);
-        hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[h->geom.nlevels], xcd_grid_y(nb)), dim3(256), 0, s, h->d_geom, src, h->blurTiles, nb);
+        if (h->blurMfma)
+            hipLaunchKernelGGL(k_blur_mfma, dim3(h->blurTiles.base[h->geom.nlevels], xcd_grid_y(nb)), dim3(256), 0, s, h->d_geom, src, h->blurTiles, nb);
+        else
+            hipLaunchKernelGGL(k_blur, dim3(h->blurTiles.base[h->geom.nlevels], xcd_grid_y(nb)), dim3(256), 0, s, h->d_geom, src, h->blurTiles, nb);
         h->prof.end(s);
     }
     // The output slots of `set` were read by the matching two batches back and by its download (host path); a wait is

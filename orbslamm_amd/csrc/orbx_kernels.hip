@@ -1070,40 +1070,21 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// 120x32 output tile per 256-thread block.  Global traffic is aligned dwords (byte
-// path only where a dword straddles the image border); every thread owns 4 adjacent
-// pixels in both passes, so LDS is read as b32/b64 and the result leaves as one dword.
+// 120x32 output tile per 256-thread block; input 128 x 38 (4 px / 3 rows of halo, dword aligned) in LDS.
 constexpr int kBlurTW = 120, kBlurTH = 32;
 
-// 7x7 Gaussian as two exact integer passes on the dot-product units.  The separable sum has no intermediate
-// rounding, so the pass order is free: the VERTICAL pass runs first, on bytes (v_dot4_u32_u8 over 4x4 byte
-// transposes of the input dwords; row sums <= 257*255 fit 16 bits), the horizontal pass then works on the
-// 16-bit sums, whose horizontally adjacent pairs are naturally packed for v_dot2_u32_u16.
-// Tile: 120 x 32 outputs; input 128 x 38 (4 px / 3 rows of halo, dword aligned).
-__global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt, int nframes)
+// Input tile of k_blur / k_blur_mfma: (TH+6) rows x 32 dwords at a pitch of IN_STRIDE dwords, every dword XORed with XORV on the way
+// in.  Global traffic is aligned dwords, all loads issued before the first LDS store.  Ends with the tile complete and
+// the workgroup synchronised.
+template <int IN_STRIDE, uint32_t XORV>
+__device__ __forceinline__ void blur_load_tile(uint32_t* __restrict__ in, const uint8_t* __restrict__ S, int stride, int w, int h,
+                                               int tx0, int ty0, int tid)
 {
     constexpr int TW = kBlurTW, TH = kBlurTH;
     constexpr int IN_DW = (TW + 8) / 4;       // 32 dwords per input row (4 px margin each side)
-    constexpr int IN_STRIDE = IN_DW + 1;      // 33
-    constexpr int VS_STRIDE = IN_DW * 2 + 2;  // 66 dwords of u16 pairs per row, even for b64 access
-    __shared__ uint32_t in[(TH + 6) * IN_STRIDE];
-    __shared__ uint32_t vs[TH * VS_STRIDE];
-    int bx, fr;
-    if (!xcd_block_frame(nframes, bx, fr)) return;
-    const int f = fr + src.f0;
-    int l = 0;
-    while (l + 1 < g->nlevels && bx >= bt.base[l + 1]) l++;
-    const int tIdx = bx - bt.base[l];
-    const int tx0 = (tIdx % bt.tilesX[l]) * TW, ty0 = (tIdx / bt.tilesX[l]) * TH;
-    const LevelGeom& L = g->lv[l];
-    const int w = L.w, h = L.h;
-    int stride;
-    const uint8_t* S = level_ptr(g, src, f, l, stride);
-    const int tid = threadIdx.x;
     bool patchCols = false;
-
-    // (TH+6)*IN_DW = 1216 dwords, 5 per thread (rows tid/32 + 8k of dword column tid%32), all loads issued
-    // before the first LDS store.  Tiles that touch no image border (block-uniform test) skip the reflection.
+    // (TH+6)*IN_DW = 1216 dwords, 5 per thread (rows tid/32 + 8k of dword column tid%32).  Tiles that touch no image
+    // border (block-uniform test) skip the reflection.
     {
         constexpr int PER = (TH + 6 + 7) / 8;
         const int c = tid & 31, r0 = tid >> 5;
@@ -1148,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         }
 #pragma unroll
         for (int k = 0; k < PER; k++)
-            if (r0 + 8 * k < TH + 6) in[(r0 + 8 * k) * IN_STRIDE + c] = regs[k];
+            if (r0 + 8 * k < TH + 6) in[(r0 + 8 * k) * IN_STRIDE + c] = regs[k] ^ XORV;
     }
     __syncthreads();
     if (patchCols && (tx0 == 0 || tx0 + TW + 4 > w)) {  // block-uniform
@@ -1166,6 +1147,35 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
         }
         __syncthreads();
     }
+}
+
+// 7x7 Gaussian as two exact integer passes on the dot-product units.  The separable sum has no intermediate
+// rounding, so the pass order is free: the VERTICAL pass runs first, on bytes (v_dot4_u32_u8 over 4x4 byte
+// transposes of the input dwords; row sums <= 257*255 fit 16 bits), the horizontal pass then works on the
+// 16-bit sums, whose horizontally adjacent pairs are naturally packed for v_dot2_u32_u16.  Every thread owns 4 adjacent
+// pixels in both passes, so LDS is read as b32/b64 and the result leaves as one dword.
+__global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt, int nframes)
+{
+    constexpr int TW = kBlurTW, TH = kBlurTH;
+    constexpr int IN_DW = (TW + 8) / 4;       // 32 dwords per input row (4 px margin each side)
+    constexpr int IN_STRIDE = IN_DW + 1;      // 33
+    constexpr int VS_STRIDE = IN_DW * 2 + 2;  // 66 dwords of u16 pairs per row, even for b64 access
+    __shared__ uint32_t in[(TH + 6) * IN_STRIDE];
+    __shared__ uint32_t vs[TH * VS_STRIDE];
+    int bx, fr;
+    if (!xcd_block_frame(nframes, bx, fr)) return;
+    const int f = fr + src.f0;
+    int l = 0;
+    while (l + 1 < g->nlevels && bx >= bt.base[l + 1]) l++;
+    const int tIdx = bx - bt.base[l];
+    const int tx0 = (tIdx % bt.tilesX[l]) * TW, ty0 = (tIdx / bt.tilesX[l]) * TH;
+    const LevelGeom& L = g->lv[l];
+    const int w = L.w, h = L.h;
+    int stride;
+    const uint8_t* S = level_ptr(g, src, f, l, stride);
+    const int tid = threadIdx.x;
+
+    blur_load_tile<IN_STRIDE, 0u>(in, S, stride, w, h, tx0, ty0, tid);
 
     // vertical pass: thread = (dword column c, group of 4 output rows); rows 4rg .. 4rg+9 of the input tile
     {
@@ -1251,6 +1261,128 @@ __global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameS
             *(uint32_t*)(D + (int64_t)(8 * k) * L.blurStride) = pk;
         }
     }
+}
+
+// The four constant matrix-core operands of k_blur_mfma, one 16-byte fragment per lane each (lane = index + 32 * half, byte
+// b of half h = contraction slot (h, b)):
+//   [0], [1]  horizontal taps, B side: output column n of a 32-column strip reads strip columns n+1 .. n+7 (the tile
+//             starts 4 px left of the outputs); slot (h, b) = strip column 16h + b of the first / second 32 columns
+//   [2], [3]  vertical taps, A side: output row m reads tile rows m .. m+6; slot (h, b = 4g + j) = the tile row
+//             8g + 4h + j that accumulator element 4g + j of the horizontal product holds in that lane half
+struct BlurOps { uint32_t v[4][64][4]; };
+constexpr BlurOps make_blur_ops()
+{
+    constexpr int W[7] = {18, 34, 49, 55, 49, 34, 18};
+    BlurOps o{};
+    for (int op = 0; op < 4; op++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int i = lane & 31, hh = lane >> 5;
+            for (int b = 0; b < 16; b++) {
+                int t = 0;
+                if (op < 2) t = (32 * op + 16 * hh + b) - (i + 1);
+                else t = (32 * (op - 2) + 8 * (b >> 2) + 4 * hh + (b & 3)) - i;
+                const uint32_t val = (t >= 0 && t <= 6) ? (uint32_t)W[t] : 0u;
+                o.v[op][lane][b >> 2] |= val << (8 * (b & 3));
+            }
+        }
+    return o;
+}
+__device__ const BlurOps kBlurOps = make_blur_ops();
+
+// 7x7 Gaussian as two exact integer matrix products on the matrix cores (v_mfma_i32_32x32x32_i8): the pipeline these
+// kernels run in is bound by VALU issue while the matrix pipe idles, and a separable filter is a
+// pair of banded-matrix products, out = Kv . (X . Kh).  Every wave owns a 32-column strip of the tile:
+//   H = X . Kh   A = 16-byte row fragments of the tile straight from LDS (pixels - 128, signed bytes; done by the
+//                loader's XOR), B = the constant tap matrix; accumulator preset to 128, so G = sum - 128*257 + 128 lies
+//                in [-32768, 32767] and splits exactly into a signed high byte and a signed low byte (G.b0 ^ 0x80);
+//   out = Kv . H the accumulator layout of H (lane = column, element = row) IS the B-side layout of the second product,
+//                contraction over rows: four v_perm per four values pack the two byte planes, no transposition, no LDS;
+//                A = the constant tap matrix; high and low planes accumulate apart (the weights would not fit a byte
+//                scaled by 256), joined by one v_lshl_add; the presets carry the 128*257 offsets and the 2^15 rounding.
+// Tile rows 32 .. 37 (the lower halo) are a second, mostly empty 32-row product on both sides.  Results leave as
+// bytes into an LDS tile (ds_write_b8_d16_hi takes bits 16 .. 23 of the saturated sum) and are stored as row dwords.
+__global__ __launch_bounds__(256, 2) void k_blur_mfma(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt, int nframes)
+{
+    constexpr int TW = kBlurTW, TH = kBlurTH;
+    constexpr int IN_STRIDE = 36;             // dwords: 144-byte rows keep the 16-byte fragment reads conflict free
+    constexpr int OUT_STRIDE = 33;            // dwords per output row (128 bytes + 4)
+    typedef int b4i __attribute__((ext_vector_type(4)));
+    typedef int b16i __attribute__((ext_vector_type(16)));
+    __shared__ __attribute__((aligned(16))) uint32_t in[(TH + 6) * IN_STRIDE + 8];
+    __shared__ uint32_t outT[TH * OUT_STRIDE];
+    int bx, fr;
+    if (!xcd_block_frame(nframes, bx, fr)) return;
+    const int f = fr + src.f0;
+    int l = 0;
+    while (l + 1 < g->nlevels && bx >= bt.base[l + 1]) l++;
+    const int tIdx = bx - bt.base[l];
+    const int tx0 = (tIdx % bt.tilesX[l]) * TW, ty0 = (tIdx / bt.tilesX[l]) * TH;
+    const LevelGeom& L = g->lv[l];
+    const int w = L.w, h = L.h;
+    int stride;
+    const uint8_t* S = level_ptr(g, src, f, l, stride);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, hh = lane >> 5, m = lane & 31;
+    const b4i* ops = (const b4i*)kBlurOps.v;
+    const b4i hB0 = ops[lane], hB1 = ops[64 + lane], vA0 = ops[128 + lane], vA1 = ops[192 + lane];
+
+    blur_load_tile<IN_STRIDE, 0x80808080u>(in, S, stride, w, h, tx0, ty0, tid);
+
+    if (tx0 + 32 * wave < w) {  // strips right of the image have nothing to add (wave-uniform)
+        const uint8_t* inb = (const uint8_t*)in + 32 * wave + 16 * hh;
+        b16i G0, G1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) G0[r] = G1[r] = 128;
+        {
+            const b4i a0 = *(const b4i*)(inb + m * (IN_STRIDE * 4)), a1 = *(const b4i*)(inb + m * (IN_STRIDE * 4) + 32);
+            G0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, hB0, G0, 0, 0, 0);
+            G0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, hB1, G0, 0, 0, 0);
+        }
+        {
+            const int m1 = min(32 + m, TH + 5);
+            const b4i a0 = *(const b4i*)(inb + m1 * (IN_STRIDE * 4)), a1 = *(const b4i*)(inb + m1 * (IN_STRIDE * 4) + 32);
+            G1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, hB0, G1, 0, 0, 0);
+            G1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, hB1, G1, 0, 0, 0);
+        }
+        b4i lo0, hi0, lo1 = {0, 0, 0, 0}, hi1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const uint32_t t0 = __builtin_amdgcn_perm((uint32_t)G0[4 * gq + 1], (uint32_t)G0[4 * gq], 0x05010400u);
+            const uint32_t t1 = __builtin_amdgcn_perm((uint32_t)G0[4 * gq + 3], (uint32_t)G0[4 * gq + 2], 0x05010400u);
+            lo0[gq] = (int)(__builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u);
+            hi0[gq] = (int)__builtin_amdgcn_perm(t1, t0, 0x07060302u);
+        }
+        {   // tile rows 32 .. 37 sit in elements 0 .. 3 of the second product; the taps of every other slot are zero
+            const uint32_t t0 = __builtin_amdgcn_perm((uint32_t)G1[1], (uint32_t)G1[0], 0x05010400u);
+            const uint32_t t1 = __builtin_amdgcn_perm((uint32_t)G1[3], (uint32_t)G1[2], 0x05010400u);
+            lo1[0] = (int)(__builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u);
+            hi1[0] = (int)__builtin_amdgcn_perm(t1, t0, 0x07060302u);
+        }
+        b16i aHi, aLo;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { aHi[r] = 0; aLo[r] = 257 * 32896 + 32768; }
+        aHi = __builtin_amdgcn_mfma_i32_32x32x32_i8(vA0, hi0, aHi, 0, 0, 0);
+        aHi = __builtin_amdgcn_mfma_i32_32x32x32_i8(vA1, hi1, aHi, 0, 0, 0);
+        aLo = __builtin_amdgcn_mfma_i32_32x32x32_i8(vA0, lo0, aLo, 0, 0, 0);
+        aLo = __builtin_amdgcn_mfma_i32_32x32x32_i8(vA1, lo1, aLo, 0, 0, 0);
+        uint8_t* ob = (uint8_t*)outT + (4 * hh) * (OUT_STRIDE * 4) + 32 * wave + m;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            // (sum + 2^15) >> 16, saturated (the sum can reach 257 * 257 * 255)
+            const uint32_t v = min((uint32_t)((aHi[r] << 8) + aLo[r]), 0xFFFFFFu);
+            ob[((r & 3) + 8 * (r >> 2)) * (OUT_STRIDE * 4)] = (uint8_t)(v >> 16);
+        }
+    }
+    __syncthreads();
+
+    const int cq = tid & 31, rq = tid >> 5;
+    const int x = tx0 + 4 * cq;
+    if (cq >= TW / 4 || x >= w) return;
+    uint8_t* D = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)(ty0 + rq) * L.blurStride + x;
+    const int nrows = min(TH, h - ty0);
+#pragma unroll
+    for (int k = 0; k < TH / 8; k++)
+        if (rq + 8 * k < nrows) *(uint32_t*)(D + (int64_t)(8 * k) * L.blurStride) = outT[(rq + 8 * k) * OUT_STRIDE + cq];
 }
 
 // ------------------------------------------------------------------ orientation + rBRIEF + pack

@@ -207,6 +207,34 @@ def test_matrix_core_scan_equals_popcount_scan(gpu, monkeypatch):
     assert sum(n for _, n in out[0]) > 5000
 
 
+def test_matrix_core_blur_equals_dot_product_blur(gpu, oracle, monkeypatch):
+    """the Gaussian's two forms -- v_dot4/v_dot2 on the vector units (default) and the pair of banded int8 products on
+    the matrix cores (ORBX_BLUR_MFMA=1) -- give the oracle's bytes: blurred levels and the records built on them,
+    on shapes with interior tiles, border tiles on every side, and levels smaller than one tile"""
+    monkeypatch.setenv("ORBX_BLUR_MFMA", "1")
+    for w, h, nf in ((1241, 376, 2000), (640, 480, 1000), (401, 263, 700), (97, 81, 200)):
+        fr = frames_for(w, h, 2, stream=5)
+        gex = gpu_extractor(nf, w, h, B=2)
+        kps, desc = gex.extract_batch(fr)
+        oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+        for f in range(2):
+            assert_same(oex(fr[f]), kps[f], desc[f])
+    # saturation: a white frame blurs to (257 * 257 * 255 + 2^15) >> 16 = 257 -> 255; the blurred levels themselves
+    w, h = 640, 480
+    img = np.full((h, w), 255, np.uint8)
+    img[100:200, 150:400] = 0
+    gex = gpu_extractor(500, w, h)
+    gex(img)
+    oex = oracle.Extractor(500, 1.2, 8, 20, 7)
+    ref = oex(img, want_pyramid=True)
+    off = 0
+    for lvl in range(8):
+        lw, lh = oex.level_size(w, h, lvl)
+        rl = ref["pyramid"][off:off + lw * lh].reshape(lh, lw)
+        off += lw * lh
+        assert np.array_equal(gex.pyramid_level(0, lvl, blurred=True), oracle.gaussian7(rl)), "level %d" % lvl
+
+
 def test_saddle_texture_exercises_two_sided_fast_path(gpu, oracle):
     """a periodic saddle texture: a quarter of all pixels pass FAST's compass pre-test on BOTH sides (brighter N/S,
     darker E/W), more than the one-sided stream can take twice -- k_fast falls back to its two-sided scorer"""
