@@ -689,7 +689,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_cellCount, B * h->cellsCap * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_kept, h->keptCapFrame * B * sizeof(uint64_t)));
     CRT(hipMalloc(&h->d_keptCount, B * ORBX_MAXL * sizeof(int32_t)));
-    CRT(hipMalloc(&h->d_err, 2 * sizeof(int32_t)));  // [0] error flags, [1] block counter of k_pack_host
+    CRT(hipMalloc(&h->d_err, 4 * sizeof(int32_t)));  // [0] error flags, [1] block counter of k_pack_host, [2] scratch word (stream warm-up)
     CRT(hipMalloc(&h->d_kps, 2 * (B + 1) * h->maxKp * sizeof(OrbxKeyPointDev)));
     CRT(hipMalloc(&h->d_desc, 2 * (B + 1) * (size_t)h->maxKp * 32));
     CRT(hipMalloc(&h->d_count, 2 * (B + 1) * sizeof(int32_t)));
@@ -702,7 +702,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     h->xPitch = (int64_t)align_up(h->maxKp, orbm::kMfmaRowsPerBlock) * 256;
     CRT(hipMalloc(&h->d_xdesc, 2 * (B + 1) * (size_t)h->xPitch));
     CRT(hipMemset(h->d_xdesc, 0, 2 * (B + 1) * (size_t)h->xPitch));
-    CRT(hipMemset(h->d_err, 0, 2 * sizeof(int32_t)));
+    CRT(hipMemset(h->d_err, 0, 4 * sizeof(int32_t)));
     CRT(hipMemset(h->d_count, 0, 2 * (B + 1) * sizeof(int32_t)));
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
     CRT(hipMemset(h->d_nmatch, 0, 2 * B * sizeof(int32_t)));
@@ -1169,8 +1169,20 @@ static int ensure_slots(orbx_handle* h)
     h->outOffDesc = o; o += B * (size_t)h->maxKp * 32;
     h->outOffMatch = o; o += B * (size_t)h->maxKp * 4;
     h->outBytes = o;
-    HIPCHK(hipStreamCreateWithFlags(&h->streamUp, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->streamDown, hipStreamNonBlocking));
+    // The two copy streams are the process's fifth and sixth: the runtime deals its (four) hardware queues out again and
+    // they would share one with a compute stream -- the download's wait for the matcher then sits in front of the next
+    // batch's first kernels in that queue and the three tickets run one after the other (46 k frames/s through the host
+    // entries where the frames alone allow 120 k).  A stream created with a CU mask gets a hardware queue of its own;
+    // the mask is all CUs.  (GPU_MAX_HW_QUEUES=6 does the same from outside: 46 k -> 65 k in bench.py's host_path.)
+    {
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDeviceProperties(&pr, h->device));
+        std::vector<uint32_t> mask((pr.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
+        HIPCHK(hipExtStreamCreateWithCUMask(&h->streamUp, (uint32_t)mask.size(), mask.data()));
+        HIPCHK(hipExtStreamCreateWithCUMask(&h->streamDown, (uint32_t)mask.size(), mask.data()));
+        // (the queue itself is made at the stream's first use, tens of milliseconds: here, not in the first batch)
+        for (hipStream_t st : {h->streamUp, h->streamDown}) { HIPCHK(hipMemsetAsync(h->d_err + 2, 0, 4, st)); HIPCHK(hipStreamSynchronize(st)); }
+    }
     for (auto& sl : h->slot) {
         HIPCHK(hipHostMalloc(&sl.h_in, h->imgFrameBytes * B));
         HIPCHK(hipHostMalloc(&sl.h_out, h->outBytes));
@@ -1321,15 +1333,19 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
         if ((rc = join_parts(h, dn))) return rc;
         if (match && (rc = orbx_match_prev_batch_device(h, opts->nnratio, opts->th_low, opts->check_ori))) return rc;
         if (match) HIPCHK(hipStreamWaitEvent(dn, h->evMatched[set], 0));
+        // One kernel writes the exact n keypoints / descriptors / match entries of every frame into the pinned buffer.
+        // (Six device-to-host copies of full-capacity slots went through the runtime's blit path with ~110 us between
+        // consecutive copies: 0.55 ms per 64-frame batch, as long as the upload.  No flag here: the consumer waits for evOut.)
+        PackArgs pa;
+        pa.kps = (const uint32_t*)(r_kps(h, set) + h->maxKp); pa.desc = (const uint32_t*)(r_desc(h, set) + (size_t)h->maxKp * 32);
+        pa.count = r_count(h, set) + 1; pa.match = match ? dm : nullptr; pa.nmatch = match ? dnm : nullptr; pa.err = h->d_err;
+        pa.hKps = (uint32_t*)(sl.h_out + h->outOffKp); pa.hDesc = (uint32_t*)(sl.h_out + h->outOffDesc);
+        pa.hN = (int32_t*)(sl.h_out + h->outOffN); pa.hMatch = (int32_t*)(sl.h_out + h->outOffMatch);
+        pa.hNmatch = (int32_t*)(sl.h_out + h->outOffNm); pa.hErr = (int32_t*)sl.h_out; pa.maxKp = h->maxKp;
+        pa.hFlag = nullptr; pa.flagValue = 0; pa.blocksDone = nullptr;  // the consumer waits for evOut: the kernel's end publishes
         h->prof.begin(P_D2H, dn);
-        HIPCHK(hipMemcpyAsync(sl.h_out, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, dn));
-        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffN, r_count(h, set) + 1, B * sizeof(int32_t), hipMemcpyDeviceToHost, dn));
-        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffKp, r_kps(h, set) + h->maxKp, (size_t)B * h->maxKp * sizeof(OrbxKeyPointDev), hipMemcpyDeviceToHost, dn));
-        HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffDesc, r_desc(h, set) + (size_t)h->maxKp * 32, (size_t)B * h->maxKp * 32, hipMemcpyDeviceToHost, dn));
-        if (match) {
-            HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffNm, dnm, B * sizeof(int32_t), hipMemcpyDeviceToHost, dn));
-            HIPCHK(hipMemcpyAsync(sl.h_out + h->outOffMatch, dm, (size_t)B * h->maxKp * 4, hipMemcpyDeviceToHost, dn));
-        }
+        // two workgroups per frame: the kernel is bound by the link (8 MB at ~45 GB/s), more waves only sit on the CUs
+        hipLaunchKernelGGL(k_pack_host, dim3(2, B), dim3(256), 0, dn, pa);
         h->prof.end(dn);
         HIPCHK(hipEventRecord(sl.evOut, dn));
         outS = dn;

@@ -1684,14 +1684,28 @@ __global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
     const int n = a.count[f];
     const int t = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
     const int64_t o = (int64_t)f * a.maxKp;
-    for (int i = t; i < 7 * n; i += step) a.hKps[o * 7 + i] = a.kps[o * 7 + i];
-    for (int i = t; i < 8 * n; i += step) a.hDesc[o * 8 + i] = a.desc[o * 8 + i];
-    if (a.match) for (int i = t; i < n; i += step) a.hMatch[o + i] = a.match[o + i];
+    // 16 bytes per lane where the frame's slot is 16-byte aligned (maxKp a multiple of 4): a wave instruction then writes
+    // a contiguous KiB towards the host
+    auto copy_words = [&](uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int nw) {
+        int i0 = 0;
+        if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+            const int n4 = nw >> 2;
+            for (int i = t; i < n4; i += step) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+            i0 = n4 << 2;
+        }
+        for (int i = i0 + t; i < nw; i += step) dst[i] = src[i];
+    };
+    copy_words(a.hKps + o * 7, a.kps + o * 7, 7 * n);
+    copy_words(a.hDesc + o * 8, a.desc + o * 8, 8 * n);
+    if (a.match) copy_words((uint32_t*)a.hMatch + o, (const uint32_t*)a.match + o, n);
     if (t == 0) {
         a.hN[f] = n;
         if (a.nmatch) a.hNmatch[f] = a.nmatch[f];
         if (f == 0) *a.hErr = *a.err;
     }
+    // Without a flag the consumer waits for the kernel's completion event, and the end of the kernel publishes: no
+    // system-scope fence, no arrival count.
+    if (!a.hFlag) return;
     // every block's writes are performed system-wide before its arrival is counted; the last arrival publishes
     __threadfence_system();
     __syncthreads();
