@@ -265,7 +265,8 @@ struct orbx_handle {
     bool slotsReady = false;
     int nextTicket = 0;
     size_t outOffN = 0, outOffNm = 0, outOffKp = 0, outOffDesc = 0, outOffMatch = 0, outBytes = 0;
-    hipStream_t streamUp = nullptr, streamDown = nullptr;  // copies only (SDMA): never a kernel
+    hipStream_t streamUp = nullptr, streamDown = nullptr;  // upload / results of a batch submitted while nothing else is in flight
+    hipStream_t streamUpQ = nullptr, streamDownQ = nullptr;  // the same for a batch submitted behind others: hardware queues of their own
     hipEvent_t evOutOfSet[2] = {nullptr, nullptr};         // the download that last read result set s
     CopyPool pool;
     int matchSet = 0;                    // result set the last matching wrote (d_match / d_nmatch half)
@@ -579,8 +580,7 @@ static void free_device(orbx_handle* h)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->d_stereo) (void)hipFree(h->d_stereo);
     h->pool.stop();
-    if (h->streamUp) (void)hipStreamSynchronize(h->streamUp);
-    if (h->streamDown) (void)hipStreamSynchronize(h->streamDown);
+    for (hipStream_t st : {h->streamUp, h->streamDown, h->streamUpQ, h->streamDownQ}) if (st) (void)hipStreamSynchronize(st);
     for (auto& sl : h->slot) {
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
@@ -588,8 +588,7 @@ static void free_device(orbx_handle* h)
         if (sl.evUp) (void)hipEventDestroy(sl.evUp);
         if (sl.evOut) (void)hipEventDestroy(sl.evOut);
     }
-    if (h->streamUp) (void)hipStreamDestroy(h->streamUp);
-    if (h->streamDown) (void)hipStreamDestroy(h->streamDown);
+    for (hipStream_t st : {h->streamUp, h->streamDown, h->streamUpQ, h->streamDownQ}) if (st) (void)hipStreamDestroy(st);
     for (int i = 0; i < orbx_handle::kMaxSplit; i++) {
         if (h->evPyr[i]) (void)hipEventDestroy(h->evPyr[i]);
         if (h->evBlur[i]) (void)hipEventDestroy(h->evBlur[i]);
@@ -768,8 +767,7 @@ static int sync_all(orbx_handle* h)
         if (h->streamB[i]) HIPCHK(hipStreamSynchronize(h->streamB[i]));
     }
     HIPCHK(hipStreamSynchronize(h->stream3));
-    if (h->streamUp) HIPCHK(hipStreamSynchronize(h->streamUp));
-    if (h->streamDown) HIPCHK(hipStreamSynchronize(h->streamDown));
+    for (hipStream_t st : {h->streamUp, h->streamDown, h->streamUpQ, h->streamDownQ}) if (st) HIPCHK(hipStreamSynchronize(st));
     h->matchPending[0] = h->matchPending[1] = false;
     h->evOutOfSet[0] = h->evOutOfSet[1] = nullptr;
     return ORBX_OK;
@@ -1169,19 +1167,24 @@ static int ensure_slots(orbx_handle* h)
     h->outOffDesc = o; o += B * (size_t)h->maxKp * 32;
     h->outOffMatch = o; o += B * (size_t)h->maxKp * 4;
     h->outBytes = o;
-    // The two copy streams are the process's fifth and sixth: the runtime deals its (four) hardware queues out again and
-    // they would share one with a compute stream -- the download's wait for the matcher then sits in front of the next
-    // batch's first kernels in that queue and the three tickets run one after the other (46 k frames/s through the host
-    // entries where the frames alone allow 120 k).  A stream created with a CU mask gets a hardware queue of its own;
-    // the mask is all CUs.  (GPU_MAX_HW_QUEUES=6 does the same from outside: 46 k -> 65 k in bench.py's host_path.)
+    // Copy streams.  They are the process's fifth and later streams: the runtime deals its (four) hardware queues out
+    // again and they share one with a compute stream.  For a batch submitted while others are in flight that is ruinous
+    // -- the wait of the results for the matcher then sits in front of the next batch's first kernels in that queue and
+    // the three tickets run one after the other (46 k frames/s where the frames alone allow 120 k).  A stream created
+    // with a CU mask (here: all CUs) gets a hardware queue of its own: 46 k -> 69-74 k; but every hand-over through
+    // such a queue costs ~0.1 ms, which a lone batch (nothing to overlap with) pays for nothing: B = 8 per call
+    // 0.67 -> 0.97 ms.  Hence two pairs; orbx_submit_batch picks by whether another ticket is in flight.
+    // (GPU_MAX_HW_QUEUES=6 set from outside gives the plain pair queues of their own as well.)
     {
+        HIPCHK(hipStreamCreateWithFlags(&h->streamUp, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&h->streamDown, hipStreamNonBlocking));
         hipDeviceProp_t pr;
         HIPCHK(hipGetDeviceProperties(&pr, h->device));
         std::vector<uint32_t> mask((pr.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
-        HIPCHK(hipExtStreamCreateWithCUMask(&h->streamUp, (uint32_t)mask.size(), mask.data()));
-        HIPCHK(hipExtStreamCreateWithCUMask(&h->streamDown, (uint32_t)mask.size(), mask.data()));
-        // (the queue itself is made at the stream's first use, tens of milliseconds: here, not in the first batch)
-        for (hipStream_t st : {h->streamUp, h->streamDown}) { HIPCHK(hipMemsetAsync(h->d_err + 2, 0, 4, st)); HIPCHK(hipStreamSynchronize(st)); }
+        HIPCHK(hipExtStreamCreateWithCUMask(&h->streamUpQ, (uint32_t)mask.size(), mask.data()));
+        HIPCHK(hipExtStreamCreateWithCUMask(&h->streamDownQ, (uint32_t)mask.size(), mask.data()));
+        // (a queue is made at its stream's first use, tens of milliseconds: here, not in the first batch)
+        for (hipStream_t st : {h->streamUp, h->streamDown, h->streamUpQ, h->streamDownQ}) { HIPCHK(hipMemsetAsync(h->d_err + 2, 0, 4, st)); HIPCHK(hipStreamSynchronize(st)); }
     }
     for (auto& sl : h->slot) {
         HIPCHK(hipHostMalloc(&sl.h_in, h->imgFrameBytes * B));
@@ -1270,7 +1273,9 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
     // writes the pinned host buffer (k_pack_host) instead of six copies.  Larger batches are the throughput mode: copy
     // streams of their own, so that the DMA of neighbouring batches runs beside the kernels.
     const bool lat = B <= 2 && !h->serial;
-    hipStream_t up = lat ? h->streamP[0] : h->streamUp;  // latency mode: the stream of the pyramid, the chain's first kernel
+    bool behind = false;  // another ticket is in flight: this batch's copies must not share a hardware queue with kernels
+    for (const HostSlot& o : h->slot) behind |= o.state == 1;
+    hipStream_t up = lat ? h->streamP[0] : (behind ? h->streamUpQ : h->streamUp);  // latency mode: the stream of the pyramid, the chain's first kernel
     h->prof.begin(P_H2D, up);
     const bool pinned = is_pinned(imgs[0]);
     bool contiguous = true;  // frames back to back at a constant pitch of whole rows
@@ -1329,7 +1334,7 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
         if (match && (rc = roll_prev_on(h, ps, set))) return rc;
     } else {
         // download behind the batch's kernels on the second copy stream: full-capacity slots, one pass, no host sync
-        hipStream_t dn = h->streamDown;
+        hipStream_t dn = behind ? h->streamDownQ : h->streamDown;
         if ((rc = join_parts(h, dn))) return rc;
         if (match && (rc = orbx_match_prev_batch_device(h, opts->nnratio, opts->th_low, opts->check_ori))) return rc;
         if (match) HIPCHK(hipStreamWaitEvent(dn, h->evMatched[set], 0));
