@@ -685,7 +685,14 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // cy = the y decisions at bit 1 (the y descent is the same under every root).  Two small LDS tables built per
     // block (one descent per column and per row instead of one per key) turn a key's code into two byte-pair reads.
     constexpr int kLutX = 2048, kLutY = 1280;
-    __shared__ uint16_t lutx[kLutX], luty[kLutY];
+    constexpr int kFirstCap = 1024;
+    // one block of scratch: the two code tables and the search table of the counting sort, dead once the keys are
+    // scattered -- the list construction below reuses it for its scan
+    __shared__ uint32_t sortScratch[(kLutX + kLutY + kFirstCap + 2) / 2];
+    static_assert(sizeof(sortScratch) >= 1368 * 4, "the list construction scans up to 1368 flags here");
+    uint16_t* const lutx = (uint16_t*)sortScratch;
+    uint16_t* const luty = lutx + kLutX;
+    uint16_t* const firstCell = luty + kLutY;
     const bool useLut = L.winW <= kLutX && L.winH <= kLutY;
     auto code_x = [&](int x) {
         int r = (int)__fdiv_rn((float)x, hX);
@@ -725,8 +732,6 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     constexpr int KPT = 16;
     // two-level search: firstCell[k] = cell of flat position 64k (one full search per 64 positions), then a key only
     // searches the few cells its 64-block spans -- the search is LDS-issue bound (8 of the block's 70 us went here)
-    constexpr int kFirstCap = 1024;
-    __shared__ uint16_t firstCell[kFirstCap + 1];
     __shared__ int sSpan;
     const int nblk = (n + 63) >> 6;
     const bool twoLevel = nblk <= kFirstCap && nCells <= 65535;
@@ -805,32 +810,89 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         tree_sums_and_starts();
         for (int base = 0; base < n; base += kChunk) { uint64_t key[KPT]; uint32_t code[KPT]; load_chunk(base, key, code); scatter_chunk(base, key, code); }
     }
-    for (int i = tid; i < nIni; i += kDistThreads) { ord[i] = hst[i]; tA[i] = hst[i]; }  // root counts
+    // ---- the list after the first r rounds, built in one step.  As long as every node with more than one key is
+    // divided (main mode) the list is a function of the histogram alone: a bin of depth d is a node iff it holds a key
+    // and its parent held more than one; the list after round r is C_r ++ leaves(C_{r-1}) ++ ... ++ leaves(C_0), where
+    // C_d are the depth-d nodes and leaves(.) those left with one key (never divided again, :594-600), and the order
+    // inside C_d follows from push_front: groups in reverse processing order, n4..n1 inside a group (:621-660), i.e.
+    // ascending in T_d = (-T_{d-1}, -q_d), T_0 = root index -- the path code with every other base-4 digit
+    // complemented.  The loop conditions (:669-673) after each of those rounds need only the three tallies per depth.
+    // So: tally, find the first round r* after which the reference stops or turns careful (or the histogram ends),
+    // one scan over the concatenated (depth, complemented code) sequence = every node's list position.  Replaces r*
+    // rounds of ~5 us (a dozen barriers each) by one of ~3.
+    __shared__ int sTal[6][3];         // per depth: nodes, nodes with one key, nodes with more
+    uint32_t* const sq = sortScratch;
+    if (tid < 18) (&sTal[0][0])[tid] = 0;
     __syncthreads();
-    block_excl_scan(tA, nIni, wtmp);  // tA = root starts
-    // non-empty roots in order 0..nIni-1 (:572-585)
-    for (int i = tid; i < nIni; i += kDistThreads) tB[i] = ord[i] > 0 ? 1u : 0u;
+    auto depth_of = [&](int idx, int& code) { int d = 0; while (d < D && idx >= hoff(d + 1)) d++; code = idx - hoff(d); return d; };
+    auto is_node = [&](int d, int code, uint32_t cnt) { return cnt >= 1 && (d == 0 || hst[hoff(d - 1) + (code >> 2)] > 1); };
+    for (int idx = tid; idx < hTotal; idx += kDistThreads) {
+        int code;
+        const int d = depth_of(idx, code);
+        const uint32_t cnt = hst[idx];
+        if (is_node(d, code, cnt)) { atomicAdd(&sTal[d][0], 1); atomicAdd(&sTal[d][cnt == 1 ? 1 : 2], 1); }
+    }
     __syncthreads();
-    // tB flags -> positions (keep counts in ord, starts in tA)
-    for (int i = tid; i < nIni; i += kDistThreads) ord2[i] = tB[i];
-    __syncthreads();
-    int m = (int)block_excl_scan(ord2, nIni, wtmp);
-    int cur = 0;
-    for (int i = tid; i < nIni; i += kDistThreads) {
-        if (tB[i]) {
-            const int pos = ord2[i];
-            nbB[cur * cap + pos] = make_short4((short)(int)__fmul_rn(hX, (float)i), (short)(int)__fmul_rn(hX, (float)(i + 1)), 0, (short)L.winH);
-            nsB[cur * cap + pos] = tA[i];
-            ncB[cur * cap + pos] = ord[i] | (1u << 31);  // keys are in buffer 1
-            nkB[cur * cap + pos] = (uint32_t)i;          // depth 0, path code = root index
+    int rstar = 0;
+    bool careful = false, finished = false;
+    if (sTal[0][2] > 0) {  // the first round always runs in main mode
+        int mPrev = sTal[0][0], leaves = 0;
+        for (int r = 1; r <= D; r++) {
+            leaves += sTal[r - 1][1];
+            const int mr = sTal[r][0] + leaves, nx = sTal[r][2];
+            rstar = r;
+            if (mr >= N || mr == mPrev) { finished = true; break; }   // :669 / :733
+            if (mr + 3 * nx > N) { careful = true; break; }          // :673
+            if (nx == 0) break;                                       // nothing left to divide: the loop below ends at once
+            mPrev = mr;
         }
+    }
+    // sequence: depth r* (all its nodes), then depths r*-1 .. 0 (their one-key nodes), each in T order
+    auto seq_index = [&](int d, int code) {
+        int base = 0;
+        for (int j = rstar; j > d; j--) base += nIni << (2 * j);
+        const int low = (1 << (2 * d)) - 1;
+        const int root = code >> (2 * d);
+        return base + ((((d & 1) ? nIni - 1 - root : root) << (2 * d)) | ((code & low) ^ (0x333 & low)));
+    };
+    const int seqLen = hoff(rstar) + (nIni << (2 * rstar));
+    for (int i = tid; i < seqLen; i += kDistThreads) sq[i] = 0;
+    __syncthreads();
+    for (int idx = tid; idx < seqLen; idx += kDistThreads) {
+        int code;
+        const int d = depth_of(idx, code);
+        const uint32_t cnt = hst[idx];
+        if (is_node(d, code, cnt) && (d == rstar || cnt == 1)) sq[seq_index(d, code)] = 1;
+    }
+    __syncthreads();
+    int m = (int)block_excl_scan(sq, seqLen, wtmp);
+    int cur = 0;
+    if (m > cap) { if (tid == 0) atomicOr(errFlag, 2); return; }  // cannot happen (size <= max(N + 2, 4 * nIni)); guard anyway
+    for (int idx = tid; idx < seqLen; idx += kDistThreads) {
+        int code;
+        const int d = depth_of(idx, code);
+        const uint32_t cnt = hst[idx];
+        if (!(is_node(d, code, cnt) && (d == rstar || cnt == 1))) continue;
+        const int pos = (int)sq[seq_index(d, code)];
+        const int root = code >> (2 * d);
+        int x0 = (short)(int)__fmul_rn(hX, (float)root), x1 = (short)(int)__fmul_rn(hX, (float)(root + 1)), y0 = 0, y1 = (short)L.winH;
+        for (int t = 1; t <= d; t++) {
+            const int q = (code >> (2 * (d - t))) & 3;
+            const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);  // :483-484
+            if (q & 1) x0 = xm; else x1 = xm;
+            if (q & 2) y0 = ym; else y1 = ym;
+        }
+        const int b0 = code << (2 * (D - d));  // the node's first leaf bin; hfill holds bin ENDS after the scatter
+        nbB[cur * cap + pos] = make_short4((short)x0, (short)x1, (short)y0, (short)y1);
+        nsB[cur * cap + pos] = hfill[b0] - hst[hoff(D) + b0];
+        ncB[cur * cap + pos] = cnt | (1u << 31);  // keys are in buffer 1
+        nkB[cur * cap + pos] = ((uint32_t)d << 24) | (uint32_t)code;
     }
     __syncthreads();
 
     STAMP(2);
-    // ---- rounds
-    bool careful = false;
-    for (int iter = 0; iter < 64; iter++) {
+    // ---- rounds (the ones the histogram could not decide)
+    for (int iter = 0; iter < 64 && !finished; iter++) {
         const int prevSize = m;
         // E = nodes with more than one key, in list order
         for (int i = tid; i < m; i += kDistThreads) tA[i] = (ncB[cur * cap + i] & 0x7FFFFFFFu) > 1 ? 1u : 0u;
