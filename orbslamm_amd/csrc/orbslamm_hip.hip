@@ -1181,8 +1181,15 @@ static int ensure_slots(orbx_handle* h)
         hipDeviceProp_t pr;
         HIPCHK(hipGetDeviceProperties(&pr, h->device));
         std::vector<uint32_t> mask((pr.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
-        HIPCHK(hipExtStreamCreateWithCUMask(&h->streamUpQ, (uint32_t)mask.size(), mask.data()));
-        HIPCHK(hipExtStreamCreateWithCUMask(&h->streamDownQ, (uint32_t)mask.size(), mask.data()));
+        // (a runtime that refuses the mask leaves the pipelined batches on plain streams: slower, not wrong)
+        if (hipExtStreamCreateWithCUMask(&h->streamUpQ, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&h->streamUpQ, hipStreamNonBlocking));
+        }
+        if (hipExtStreamCreateWithCUMask(&h->streamDownQ, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&h->streamDownQ, hipStreamNonBlocking));
+        }
         // (a queue is made at its stream's first use, tens of milliseconds: here, not in the first batch)
         for (hipStream_t st : {h->streamUp, h->streamDown, h->streamUpQ, h->streamDownQ}) { HIPCHK(hipMemsetAsync(h->d_err + 2, 0, 4, st)); HIPCHK(hipStreamSynchronize(st)); }
     }
