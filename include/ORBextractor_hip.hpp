@@ -17,6 +17,7 @@
 #include "orbslamm_hip.h"
 
 #ifdef ORBSLAMM_WITH_OPENCV
+#include <cassert>
 #include <opencv/cv.h>
 #endif
 

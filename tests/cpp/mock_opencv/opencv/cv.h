@@ -1,0 +1,61 @@
+// Test infrastructure: the handful of cv:: names include/ORBextractor_hip.hpp touches under -DORBSLAMM_WITH_OPENCV
+// (cv::Mat, cv::InputArray, cv::OutputArray, cv::KeyPoint, CV_8U / CV_8UC1), so that the reference-signature
+// operator() of the drop-in class is compiled and run where OpenCV is absent.  Plain data holders with OpenCV's member
+// names and cv::KeyPoint's 28-byte layout; nothing here computes anything.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#define CV_8U 0
+#define CV_8UC1 0
+
+namespace cv {
+
+struct Point2f { float x, y; };
+struct KeyPoint { Point2f pt; float size, angle, response; int octave, class_id; };
+
+class Mat {
+public:
+    int rows = 0, cols = 0;
+    size_t step = 0;
+    unsigned char* data = nullptr;
+    Mat() {}
+    Mat(int r, int c, int /*type*/, void* d, size_t s) : rows(r), cols(c), step(s), data((unsigned char*)d) {}
+    void create(int r, int c, int /*type*/)
+    {
+        rows = r; cols = c; step = (size_t)c;
+        own_.reset(new std::vector<unsigned char>((size_t)r * c));
+        data = own_->data();
+    }
+    void release() { rows = cols = 0; step = 0; data = nullptr; own_.reset(); }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    int type() const { return CV_8UC1; }
+private:
+    std::shared_ptr<std::vector<unsigned char> > own_;
+};
+
+class _InputArray {
+public:
+    _InputArray() {}
+    _InputArray(const Mat& m) : m_(&m) {}
+    bool empty() const { return !m_ || m_->empty(); }
+    Mat getMat() const { return m_ ? *m_ : Mat(); }
+private:
+    const Mat* m_ = nullptr;
+};
+typedef const _InputArray& InputArray;
+
+class _OutputArray {
+public:
+    _OutputArray(Mat& m) : m_(&m) {}
+    void create(int r, int c, int t) const { m_->create(r, c, t); }
+    void release() const { m_->release(); }
+    Mat getMat() const { return *m_; }
+private:
+    Mat* m_;
+};
+typedef const _OutputArray& OutputArray;
+
+}  // namespace cv

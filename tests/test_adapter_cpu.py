@@ -39,3 +39,20 @@ def test_orbmatcher_dropin_template_instantiates(tmp_path):
     syms = subprocess.check_output(["nm", "-C", exe]).decode()
     for member in ("SearchByProjection", "SearchByBoW", "SearchForInitialization", "SearchForTriangulation", "SearchBySim3", "Fuse"):
         assert "ORBmatcherT<mock::Frame, mock::KeyFrame, mock::MapPoint>::" + member in syms, member
+
+
+def test_extractor_dropin_reference_signature_compiles(tmp_path):
+    """the -DORBSLAMM_WITH_OPENCV branch of include/ORBextractor_hip.hpp -- the reference's operator()(InputArray,
+    InputArray, vector<KeyPoint>&, OutputArray) -- builds against the data-holder cv:: types of tests/cpp/mock_opencv
+    (no OpenCV in this image; the run is a -m gpu test)"""
+    from oracle import binding as ob
+    ob.build()
+    exe = str(tmp_path / "adapter_cv")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-DORBSLAMM_WITH_OPENCV", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "tests", "cpp", "mock_opencv"),
+                           os.path.join(ROOT, "tests", "cpp", "adapter_cv_gpu.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "orbslamm_amd"), "-lorbslamm_hip", "-L", os.path.join(ROOT, "oracle"), "-lorb_oracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "orbslamm_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    syms = subprocess.check_output(["nm", "-C", exe]).decode()
+    assert "iORB_SLAM::ORBextractor::operator()(cv::_InputArray const&, cv::_InputArray const&, std::vector<cv::KeyPoint" in syms

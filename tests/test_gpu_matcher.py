@@ -254,6 +254,28 @@ def test_cpp_adapters_on_gpu(gpu, tmp_path):
     assert "adapter_gpu ok" in out.stdout
 
 
+def test_extractor_dropin_reference_signature(gpu, tmp_path):
+    """include/ORBextractor_hip.hpp under -DORBSLAMM_WITH_OPENCV: the reference's own operator() signature
+    (InputArray, InputArray, vector<KeyPoint>&, OutputArray; include/ORBextractor.h:57-58) compiled against the
+    data-holder cv:: types of tests/cpp/mock_opencv and called the way Frame::ExtractORB calls it (Frame.cc:247-253),
+    keypoint records and descriptor rows against the C oracle; empty and featureless images (:1046-1047, :1064-1065)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from oracle import binding as ob
+    ob.build()
+    exe = str(tmp_path / "adapter_cv_gpu")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-DORBSLAMM_WITH_OPENCV", "-I", os.path.join(root, "include"),
+                           "-I", os.path.join(root, "tests", "cpp", "mock_opencv"),
+                           os.path.join(root, "tests", "cpp", "adapter_cv_gpu.cpp"), "-o", exe,
+                           "-L", os.path.join(root, "orbslamm_amd"), "-lorbslamm_hip", "-L", os.path.join(root, "oracle"), "-lorb_oracle",
+                           "-Wl,-rpath," + os.path.join(root, "orbslamm_amd"), "-Wl,-rpath," + os.path.join(root, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapter_cv_gpu ok" in out.stdout
+
+
 def test_orbmatcher_dropin_all_eleven_signatures(gpu, tmp_path):
     """include/ORBmatcher_hip.hpp: ORBmatcherT<Frame, KeyFrame, MapPoint> -- the reference's eleven ORBmatcher members
     (ORBmatcher.h:48-83) instantiated on mock objects with the reference's member names, run on the GPU; the flattened
