@@ -275,6 +275,25 @@ def host_path(ex, cfg, frames, seconds=1.5):
         dt = time.perf_counter() - t0
         out.update(pipelined_fps=n / dt, pipelined_what="orbx_submit_batch / orbx_collect_batch, depth 3, B=%d host frames per ticket, results on the host" % B,
                    pcie_gbs=n / dt * (W * H + 0.0) / 1e9)
+        # the same from pinned frames in the device layout (orbx_host_alloc_frames), results read in place (orbx_collect_view)
+        if hasattr(ex, "alloc_pinned_frames"):
+            pins = [ex.alloc_pinned_frames(B, W, H) for _ in range(3)]
+            for pf in pins:
+                pf.fill(batch)
+            ex.reset_stream()
+            n = 0
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                tickets.append(ex.submit_host(pins[(n // B) % 3]))
+                if len(tickets) > 2:
+                    ex.collect_host(tickets.pop(0), view=True)
+                n += B
+            while tickets:
+                ex.collect_host(tickets.pop(0), view=True)
+            dt = time.perf_counter() - t0
+            out.update(pipelined_pinned_fps=n / dt, pipelined_pinned_what="the same from pinned frames in the device layout (orbx_host_alloc_frames), results read in place (orbx_collect_view)")
+            for pf in pins:
+                pf.free()
     return out
 
 
