@@ -981,14 +981,21 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     // Sub-batch p owns stream streamP[p] across calls: it follows its own previous work (its frames' scratch
     // buffers) and the upload, nothing else -- the next batch's pyramid of sub-batch 0 starts while this batch's
     // sub-batch 1 is still in its quadtree.  Consumers join through evPart (join_parts).
-    if (evUploaded) HIPCHK(hipStreamWaitEvent(sIn, evUploaded, 0));  // host path, throughput mode: the frames arrive on the copy stream
-    // evStart = "the frames are there" for the streams that did not carry them.  A device-resident call has nothing to
-    // announce (the caller's frames are complete, every hazard on the scratch buffers is ordered by the sub-batch chains
-    // below), and an event recorded on the host-facing stream would sit behind the previous step's blur: the next
-    // pyramid then waits for a kernel it does not depend on.
+    // evFrames = "the frames are there", for the streams that did not carry them: the upload's own event (host path,
+    // throughput mode: the frames arrive on a copy stream) or one recorded behind the upload on the stream that did
+    // (latency mode).  A device-resident call has nothing to announce (the caller's frames are complete, every hazard
+    // on the scratch buffers is ordered by the sub-batch chains below).  Never an event recorded on the host-facing
+    // stream: it would sit behind the previous step's blur, and the next pyramid would wait for a kernel it does not
+    // depend on.
     const bool devCall = !evUploaded && sIn == s0;
-    const bool announce = !h->serial && !devCall;
-    if (announce) HIPCHK(hipEventRecord(h->evStart, sIn));
+    hipEvent_t evFrames = nullptr;
+    if (evUploaded) {
+        HIPCHK(hipStreamWaitEvent(sIn, evUploaded, 0));
+        evFrames = evUploaded;
+    } else if (!h->serial && !devCall) {
+        HIPCHK(hipEventRecord(h->evStart, sIn));
+        evFrames = h->evStart;
+    }
     // A frame's scratch (pyramid and blur levels, candidate segments, kept records) is ordered between two calls by
     // the stream of the sub-batch that owns the frame.  When the batch size -- and with it the frame -> sub-batch
     // map -- changes between two calls that the caller did not separate by a sync, a frame can change hands: its new
@@ -1008,8 +1015,8 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     if (lat) {
         hipStream_t sm = h->streamP[0], sa = s0;
         Launcher L{h, src, B};
-        if (announce && sIn != sm) HIPCHK(hipStreamWaitEvent(sm, h->evStart, 0));
-        if (announce && sIn != sa) HIPCHK(hipStreamWaitEvent(sa, h->evStart, 0));
+        if (evFrames && sIn != sm) HIPCHK(hipStreamWaitEvent(sm, evFrames, 0));
+        if (evFrames && sIn != sa) HIPCHK(hipStreamWaitEvent(sa, evFrames, 0));
         // aux: level 0 needs no pyramid.  (The previous call's quadtree and descriptors, which read what these two
         // overwrite, ran on `sm` in front of the upload / evStart that `sa` has just been made to follow.)
         if (sIn == sa && h->partEverRan[0]) HIPCHK(hipStreamWaitEvent(sa, h->evPart[0], 0));
@@ -1031,8 +1038,8 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
             if (nb <= 0) continue;
             hipStream_t s = h->serial ? s0 : h->streamP[part];
             hipStream_t s2 = h->serial ? s : s0;  // blur: see orbx_create on the choice of streams
-            if (announce) HIPCHK(hipStreamWaitEvent(s, h->evStart, 0));
-            if (announce && sIn != s0 && part == 0) HIPCHK(hipStreamWaitEvent(s0, h->evStart, 0));
+            if (evFrames && !h->serial) HIPCHK(hipStreamWaitEvent(s, evFrames, 0));
+            if (evFrames && !h->serial && sIn != s0 && part == 0) HIPCHK(hipStreamWaitEvent(s0, evFrames, 0));
             src.f0 = f0;
             Launcher L{h, src, nb};
             // FAST of level 0 needs no pyramid: on the blur stream it runs beside the (latency-bound) pyramid kernel.
