@@ -273,7 +273,7 @@ def host_path(ex, cfg, frames, seconds=1.5):
         while tickets:
             ex.collect_host(tickets.pop(0))
         dt = time.perf_counter() - t0
-        out.update(pipelined_fps=n / dt, pipelined_what="orbx_submit_batch / orbx_collect_batch, depth 3, B=%d host frames per ticket, results on the host" % B,
+        out.update(pipelined_fps=n / dt, pipelined_what="orbx_submit_batch / orbx_collect_view + orbx_release, depth 3, B=%d pageable host frames per ticket, results in the pinned host buffer" % B,
                    pcie_gbs=n / dt * (W * H + 0.0) / 1e9)
         # the same from pinned frames in the device layout (orbx_host_alloc_frames), results read in place (orbx_collect_view)
         if hasattr(ex, "alloc_pinned_frames"):

@@ -182,7 +182,7 @@ struct HostSlot {
     uint8_t* h_in = nullptr;    // pinned staging for pageable caller frames
     uint8_t* d_in = nullptr;    // the batch's frames in HBM (rows 64-byte aligned)
     uint8_t* h_out = nullptr;   // pinned results: [err | n[B] | nmatch[B] | kps[B][maxKp] | desc[B][maxKp][32] | match[B][maxKp]]
-    hipEvent_t evUp = nullptr, evOut = nullptr;
+    hipEvent_t evUp[4] = {nullptr, nullptr, nullptr, nullptr}, evOut = nullptr;  // evUp[p]: the frames of sub-batch p are in HBM
     int state = 0;              // 0 free, 1 in flight, 2 collected (a view is out)
     bool lat = false;           // results written by k_pack_host: h_out[1] holds ticket + 1 once they are all there
     int ticket = -1, B = 0;
@@ -585,7 +585,7 @@ static void free_device(orbx_handle* h)
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         if (sl.d_in) (void)hipFree(sl.d_in);
-        if (sl.evUp) (void)hipEventDestroy(sl.evUp);
+        for (hipEvent_t& e : sl.evUp) if (e) (void)hipEventDestroy(e);
         if (sl.evOut) (void)hipEventDestroy(sl.evOut);
     }
     for (hipStream_t st : {h->streamUp, h->streamDown, h->streamUpQ, h->streamDownQ}) if (st) (void)hipStreamDestroy(st);
@@ -962,7 +962,7 @@ struct Launcher {
 // sIn = the stream on which the frames become available (nullptr: the host-facing stream, where the device-resident
 // entry has always taken them from).
 static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int hh, int stride, size_t pitch,
-                       hipEvent_t evUploaded = nullptr, hipStream_t sIn = nullptr)
+                       const hipEvent_t* evUploaded = nullptr, hipStream_t sIn = nullptr)
 {
     int rc = configure_shape(h, w, hh);
     if (rc) return rc;
@@ -990,8 +990,7 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
     const bool devCall = !evUploaded && sIn == s0;
     hipEvent_t evFrames = nullptr;
     if (evUploaded) {
-        HIPCHK(hipStreamWaitEvent(sIn, evUploaded, 0));
-        evFrames = evUploaded;
+        // per sub-batch, below
     } else if (!h->serial && !devCall) {
         HIPCHK(hipEventRecord(h->evStart, sIn));
         evFrames = h->evStart;
@@ -1038,6 +1037,10 @@ static int run_extract(orbx_handle* h, const uint8_t* d_imgs, int B, int w, int 
             if (nb <= 0) continue;
             hipStream_t s = h->serial ? s0 : h->streamP[part];
             hipStream_t s2 = h->serial ? s : s0;  // blur: see orbx_create on the choice of streams
+            if (evUploaded) {  // host path, throughput mode: this sub-batch's frames arrive on a copy stream
+                HIPCHK(hipStreamWaitEvent(s, evUploaded[part], 0));
+                if (s2 != s) HIPCHK(hipStreamWaitEvent(s2, evUploaded[part], 0));
+            }
             if (evFrames && !h->serial) HIPCHK(hipStreamWaitEvent(s, evFrames, 0));
             if (evFrames && !h->serial && sIn != s0 && part == 0) HIPCHK(hipStreamWaitEvent(s0, evFrames, 0));
             src.f0 = f0;
@@ -1208,7 +1211,7 @@ static int ensure_slots(orbx_handle* h)
         HIPCHK(hipHostMalloc(&sl.h_in, h->imgFrameBytes * B));
         HIPCHK(hipHostMalloc(&sl.h_out, h->outBytes));
         HIPCHK(hipMalloc(&sl.d_in, h->imgFrameBytes * B));
-        HIPCHK(hipEventCreateWithFlags(&sl.evUp, hipEventDisableTiming));
+        for (hipEvent_t& e : sl.evUp) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
     }
     const unsigned hc = std::thread::hardware_concurrency();
@@ -1298,32 +1301,40 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
     const bool pinned = is_pinned(imgs[0]);
     bool contiguous = true;  // frames back to back at a constant pitch of whole rows
     for (int f = 1; f < B && contiguous; f++) contiguous = imgs[f] == imgs[0] + (size_t)f * stride * hh;
-    if (pinned && contiguous && stride == dstride) {
-        // frames from orbx_host_alloc_frames: already in the device layout, the DMA reads the caller's memory
-        HIPCHK(hipMemcpyAsync(sl.d_in, imgs[0], dpitch * B, hipMemcpyHostToDevice, up));
-    } else if (pinned && contiguous) {
-        HIPCHK(hipMemcpy2DAsync(sl.d_in, dstride, imgs[0], stride, w, (size_t)hh * B, hipMemcpyHostToDevice, up));
-    } else if (pinned) {
-        for (int f = 0; f < B; f++) {
-            if (f && !is_pinned(imgs[f])) return fail(ORBX_E_INVALID, "frame %d is pageable, frame 0 pinned: one kind per batch", f);
-            HIPCHK(hipMemcpy2DAsync(sl.d_in + f * dpitch, dstride, imgs[f], stride, w, hh, hipMemcpyHostToDevice, up));
+    if (pinned) for (int f = 1; f < B; f++) if (!is_pinned(imgs[f])) return fail(ORBX_E_INVALID, "frame %d is pageable, frame 0 pinned: one kind per batch", f);
+    // Throughput mode uploads the batch in the parts run_extract cuts it into (same frame ranges), an event behind each:
+    // sub-batch 0's kernels start when its half is there, and for pageable frames the staging of part p + 1 (host
+    // threads) runs beside the DMA of part p.  Latency mode: one part, no event (the frames ride on the kernels' stream).
+    const int nparts = lat || h->serial ? 1 : std::min(h->nsplit, B);
+    for (int part = 0; part < nparts; part++) {
+        const int F0 = (int)((int64_t)B * part / nparts), F1 = (int)((int64_t)B * (part + 1) / nparts), nb = F1 - F0;
+        if (nb <= 0) continue;
+        uint8_t* const dst = sl.d_in + (size_t)F0 * dpitch;
+        if (pinned && contiguous && stride == dstride) {
+            // frames from orbx_host_alloc_frames: already in the device layout, the DMA reads the caller's memory
+            HIPCHK(hipMemcpyAsync(dst, imgs[F0], dpitch * nb, hipMemcpyHostToDevice, up));
+        } else if (pinned && contiguous) {
+            HIPCHK(hipMemcpy2DAsync(dst, dstride, imgs[F0], stride, w, (size_t)hh * nb, hipMemcpyHostToDevice, up));
+        } else if (pinned) {
+            for (int f = F0; f < F1; f++)
+                HIPCHK(hipMemcpy2DAsync(sl.d_in + f * dpitch, dstride, imgs[f], stride, w, hh, hipMemcpyHostToDevice, up));
+        } else {
+            // pageable frames: row-band jobs over the copy threads into the pinned staging, one DMA for the part
+            // (one 1241x376 frame: 34 us on one core -- 376 row copies -- against ~15 us over four)
+            const int bands = 4, jobs = nb * bands;
+            uint8_t* const hin = sl.h_in;
+            h->pool.run(jobs, [=](int j) {
+                const int f = F0 + j / bands, c = j % bands;
+                const int y0 = (int)((int64_t)hh * c / bands), y1 = (int)((int64_t)hh * (c + 1) / bands);
+                for (int y = y0; y < y1; y++) memcpy(hin + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
+            });
+            // (one DMA also in the latency mode: four band DMAs sent off by the workers as they finish were slower --
+            // a copy of this size is mostly its fixed cost, ~7 of 16 us)
+            HIPCHK(hipMemcpyAsync(dst, sl.h_in + (size_t)F0 * dpitch, dpitch * nb, hipMemcpyHostToDevice, up));
         }
-    } else {
-        // pageable frames: row-band jobs over the copy threads into the pinned staging, one DMA for the batch
-        // (one 1241x376 frame: 34 us on one core -- 376 row copies -- against ~15 us over four)
-        const int bands = 4, jobs = B * bands;
-        uint8_t* const hin = sl.h_in;
-        h->pool.run(jobs, [=](int j) {
-            const int f = j / bands, c = j - f * bands;
-            const int y0 = (int)((int64_t)hh * c / bands), y1 = (int)((int64_t)hh * (c + 1) / bands);
-            for (int y = y0; y < y1; y++) memcpy(hin + f * dpitch + (size_t)y * dstride, imgs[f] + (size_t)y * stride, (size_t)w);
-        });
-        // (one DMA also in the latency mode: four band DMAs sent off by the workers as they finish were slower --
-        // a copy of this size is mostly its fixed cost, ~7 of 16 us)
-        HIPCHK(hipMemcpyAsync(sl.d_in, sl.h_in, dpitch * B, hipMemcpyHostToDevice, up));
+        if (!lat) HIPCHK(hipEventRecord(sl.evUp[part], up));
     }
     h->prof.end(up);
-    if (!lat) HIPCHK(hipEventRecord(sl.evUp, up));
 
     if ((rc = run_extract(h, sl.d_in, B, w, hh, dstride, dpitch, lat ? nullptr : sl.evUp, lat ? up : nullptr))) return rc;
     const bool match = opts && opts->match_prev;
