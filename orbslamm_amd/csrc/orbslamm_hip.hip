@@ -442,7 +442,7 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
     // the level-0 launch (a third of the cells, all of one size) gets its own, smaller LDS footprint: more waves per CU
     out.tileRows0 = maxRoiH0;
     out.fastListCap0 = ((maxRoiW0 - 6) * (maxRoiH0 - 6) + 63) / 64 * 64;
-    out.nodeCap = align_up(nodeCap, 4);  // k_distribute reads its u32 arrays as uint4
+    out.nodeCap = align_up(std::max(nodeCap, 360), 4);  // k_distribute reads its u32 arrays as uint4, and parks its sort scratch (3201 words) in 9 * cap of them
 
     // cv::resize INTER_LINEAR coefficient tables, levels >= 1
     for (int l = 0; l < g.nlevels; l++) { out.xoff[l] = out.yoff[l] = 0; }

@@ -670,7 +670,11 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // the histogram over 4, 16, ... bins are the child counts of every node of depth < D: the first D
     // rounds below replay the list logic on those counts and move no key at all.
     __shared__ uint32_t hst[1368];   // levels 0..D of the histogram, level d at hoff(d) = nIni * (4^d - 1) / 3
-    __shared__ uint32_t hfill[1024]; // scatter cursors of the leaf bins
+    // The scratch of the counting sort -- scatter cursors of the leaf bins, the two code tables, the search table -- lives
+    // in the part of the node-list carve-up that only the rounds use (cc .. proc, 9 * cap words; the host keeps
+    // cap >= 360 for that): the workgroup's LDS footprint decides how soon it is placed beside the other kernels, and
+    // the pipeline loses 2.2 % per 16 KB of it (section 5 of DESIGN.md).
+    uint32_t* const hfill = smem + 8 * cap;   // [1024]
     const int nIni = L.nIni;
     const float hX = L.hX;
     if (nIni > 1024) { if (tid == 0) atomicOr(errFlag, 2); return; }
@@ -686,10 +690,11 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // block (one descent per column and per row instead of one per key) turn a key's code into two byte-pair reads.
     constexpr int kLutX = 2048, kLutY = 1280;
     constexpr int kFirstCap = 1024;
-    // one block of scratch: the two code tables and the search table of the counting sort, dead once the keys are
-    // scattered -- the list construction below reuses it for its scan
-    __shared__ uint32_t sortScratch[(kLutX + kLutY + kFirstCap + 2) / 2];
-    static_assert(sizeof(sortScratch) >= 1368 * 4, "the list construction scans up to 1368 flags here");
+    // the two code tables and the search table of the counting sort are dead once the keys are scattered -- the list
+    // construction below reuses their words for its scan
+    uint32_t* const sortScratch = hfill + 1024;   // [(kLutX + kLutY + kFirstCap + 2) / 2]
+    static_assert((kLutX + kLutY + kFirstCap + 2) / 2 >= 1368, "the list construction scans up to 1368 flags here");
+    static_assert(1024 + (kLutX + kLutY + kFirstCap + 2) / 2 <= 9 * 360, "host: nodeCap >= 360");
     uint16_t* const lutx = (uint16_t*)sortScratch;
     uint16_t* const luty = lutx + kLutX;
     uint16_t* const firstCell = luty + kLutY;
