@@ -542,16 +542,29 @@ static int build_geometry(const orbx_handle* h, int w, int h0, HostGeom& out)
                     cx0 &= ~3;  // dword-aligned tile origin
                     R[l] = PyrRange{(int16_t)ox0, (int16_t)ox1, (int16_t)oy0, (int16_t)oy1,
                                     (int16_t)cx0, (int16_t)cx1, (int16_t)cy0, (int16_t)cy1};
-                    nx0 = cx0; nx1 = cx1; ny0 = cy0; ny1 = cy1;
                     if (cx1 > cx0 && cy1 > cy0) {
                         const int rowBytes = (cx1 - cx0 + 3) & ~3;
-                        const int words = rowBytes / 4 * (cy1 - cy0) + 4;
+                        int rows = cy1 - cy0;
+                        if (l == 0 && ny1 > ny0) {
+                            // the kernel stages level 0 in kPyrStrips strips: the rows the strip's level-1 rows read
+                            // (same split as k_pyramid: rows [chh * s / n, chh * (s + 1) / n) of level 1's computed range)
+                            const short4* yt = &out.tabs[out.yoff[1]];
+                            const int chh1 = ny1 - ny0;
+                            rows = 0;
+                            for (int sidx = 0; sidx < kPyrStrips; sidx++) {
+                                const int ya = (int)((int64_t)chh1 * sidx / kPyrStrips), yb = (int)((int64_t)chh1 * (sidx + 1) / kPyrStrips);
+                                if (yb > ya) rows = std::max(rows, std::min<int>(yt[ny0 + yb - 1].y + 1, cy1) - (int)yt[ny0 + ya].x);
+                            }
+                        }
+                        const int words = rowBytes / 4 * rows + 4;
                         if (l & 1) maxB = std::max(maxB, words); else maxA = std::max(maxA, words);
                         if (l > 0) tabCap = std::max(tabCap, std::max(rowBytes, cy1 - cy0));
                     }
+                    nx0 = cx0; nx1 = cx1; ny0 = cy0; ny1 = cy1;
                 }
             }
         out.pyrBufA = maxA; out.pyrBufB = maxB; out.pyrTabCap = (tabCap + 3) & ~3;
+        if (getenv("ORBX_DEBUG_GEOM")) fprintf(stderr, "pyramid: %d blocks, bufA %d B, bufB %d B, tabs %d B\n", out.pyrBlocks, maxA * 4, maxB * 4, out.pyrTabCap * 16);
         const size_t pl = ((size_t)maxA + maxB) * 4 + (size_t)out.pyrTabCap * 16;
         out.pyrFused = pl <= 64 * 1024 || (refine == 3 && pl <= 156 * 1024);
     }

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void k_resize_level(const Geom* __restrict__ g
 // will read (ranges are chained top-down on the host, PyrRange), keeps the tile in LDS
 // (ping-pong) and writes only the owned pixels to HBM.  The level-0 source tile is
 // staged with aligned dword loads.  Same fixed-point arithmetic as k_resize.
+constexpr int kPyrStrips = 2;   // level-0 tile of k_pyramid: strips per block (host sizing and kernel)
 struct PyrRange {
     int16_t ox0, ox1, oy0, oy1;   // owned output range at this level (exclusive ends)
     int16_t nx0, nx1, ny0, ny1;   // computed range (owned + halo needed by the next level)
@@ -123,24 +124,67 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     const PyrRange* R = ranges + (int64_t)blockIdx.x * nl;
     const int tid = threadIdx.x;
 
-    // level-0 tile: aligned dword loads (ranges have 4-aligned x origins)
+    // Level 0 is the caller's frame: its tile (the largest, 22 KB of the 41 KB this kernel used to hold -- exactly a
+    // quarter of a CU's LDS, so that a workgroup could only be placed on a CU where FAST cells had drained 40 KB) is
+    // staged in kPyrStrips horizontal strips, each loaded right before the level-1 rows that read it.
     PyrRange p = R[0];
     int pstride = 0;
-    if (p.nx1 > p.nx0 && p.ny1 > p.ny0) {
-        int stride0;
+    const bool have0 = p.nx1 > p.nx0 && p.ny1 > p.ny0;
+    int stride0 = 0;
+    const uint8_t* S0 = nullptr;
+    int ndw0 = 0;
+    if (have0) {
         const uint8_t* S = level_ptr(g, src, f, 0, stride0);
-        const int ndw = (p.nx1 - p.nx0 + 3) >> 2, rows = p.ny1 - p.ny0;
-        pstride = ndw * 4;
-        const uint8_t* S0 = S + (int64_t)p.ny0 * stride0 + p.nx0;
-        // 8 loads per thread in flight
-        const int total = rows * ndw;
+        ndw0 = (p.nx1 - p.nx0 + 3) >> 2;
+        pstride = ndw0 * 4;
+        S0 = S + p.nx0;
+    }
+    // rows [r0, r1) of level 0 into buffer A: aligned dword loads (ranges have 4-aligned x origins).  A strip of up to
+    // 4096 dwords travels through 16 registers per thread: fetched (loads issued) before the previous strip's rows are
+    // computed, committed to LDS after -- only the first strip's latency is exposed.  Larger strips load in place.
+    constexpr int kStripRegs = 16;
+    uint32_t sreg[kStripRegs];
+    auto strip_rows = [&](int strip, int chh1, const uint2* yt, int& r0, int& r1) {  // level-0 rows read by the strip's level-1 rows
+        const int ya = (int)((int64_t)chh1 * strip / kPyrStrips), yb = (int)((int64_t)chh1 * (strip + 1) / kPyrStrips);
+        r0 = r1 = 0;
+        if (yb > ya) { r0 = (int16_t)(yt[ya].x & 0xFFFF); r1 = min((int)(int16_t)(yt[yb - 1].x >> 16) + 1, (int)p.ny1); }
+    };
+    // element k * 256 + tid of a strip is (row, dword column); stepping by 256 elements without a division per load
+    const int q256 = have0 ? 256 / ndw0 : 0, m256 = have0 ? 256 - q256 * ndw0 : 0;
+    const int rowT = have0 ? tid / ndw0 : 0, colT = have0 ? tid - rowT * ndw0 : 0;
+    auto fetch0 = [&](int r0, int r1) {
+        const int total = (r1 - r0) * ndw0;
+        if (total <= 0 || total > 256 * kStripRegs) return;
+        const uint8_t* Sr = S0 + (int64_t)r0 * stride0;
+        int r = rowT, c = colT;
+#pragma unroll
+        for (int k = 0; k < kStripRegs; k++) {
+            if (k * 256 < total) {   // uniform
+                if (k * 256 + tid < total) sreg[k] = *(const uint32_t*)(Sr + (int64_t)r * stride0 + 4 * c);
+                r += q256; c += m256;
+                if (c >= ndw0) { c -= ndw0; r++; }
+            }
+        }
+    };
+    auto commit0 = [&](int r0, int r1) {
+        const int total = (r1 - r0) * ndw0;
+        if (total <= 0) return;
+        if (total <= 256 * kStripRegs) {
+#pragma unroll
+            for (int k = 0; k < kStripRegs; k++) {
+                const int i = k * 256 + tid;
+                if (i < total) plds[i] = sreg[k];
+            }
+            return;
+        }
+        const uint8_t* Sr = S0 + (int64_t)r0 * stride0;
         for (int i0 = 0; i0 < total; i0 += 256 * 8) {
             uint32_t regs[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int i = min(i0 + k * 256 + tid, total - 1);
-                const int r = i / ndw, c = i - r * ndw;
-                regs[k] = *(const uint32_t*)(S0 + (int64_t)r * stride0 + 4 * c);
+                const int r = i / ndw0, c = i - r * ndw0;
+                regs[k] = *(const uint32_t*)(Sr + (int64_t)r * stride0 + 4 * c);
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -148,7 +192,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
                 if (i < total) plds[i] = regs[k];
             }
         }
-    }
+    };
     for (int l = 1; l < nl; l++) {
         const PyrRange c = R[l];
         const int cw = c.nx1 - c.nx0, chh = c.ny1 - c.ny0;
@@ -164,7 +208,23 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
         for (int i = tid; i < chh; i += 256) syt[i] = gy_tab[c.ny0 + i];
         __syncthreads();  // also orders the previous level's tile writes before the reads below
         const int offP = offBuf[(l - 1) & 1], offC = offBuf[l & 1];
-        if (gpr > 0) {
+        const bool strips = l == 1 && have0 && chh > 0;
+        const int nstrips = strips ? kPyrStrips : 1;
+        if (strips) { int r0, r1; strip_rows(0, chh, syt, r0, r1); fetch0(r0, r1); }
+        for (int strip = 0; strip < nstrips; strip++) {
+        // rows [ya, yb) of this level; for level 1 they read the level-0 rows [prow0, ..) of the strip committed just now
+        const int ya = strips ? (int)((int64_t)chh * strip / nstrips) : 0, yb = strips ? (int)((int64_t)chh * (strip + 1) / nstrips) : chh;
+        int prow0 = pny0;
+        if (strips) {
+            int r0, r1;
+            strip_rows(strip, chh, syt, r0, r1);
+            prow0 = r0;
+            if (strip) __syncthreads();   // the previous strip's rows are read
+            commit0(r0, r1);
+            __syncthreads();
+            if (strip + 1 < nstrips) { int q0, q1; strip_rows(strip + 1, chh, syt, q0, q1); fetch0(q0, q1); }
+        }
+        if (gpr > 0 && yb > ya) {
             // thread = (dword group gx, row lane): the four x-coefficient entries of the group are unpacked once
             // and reused down the rows the thread owns (rows yy0, yy0 + dr, ...)
           for (int gxb = 0; gxb < gpr; gxb += 256) {  // one pass unless the tile is wider than 1024 px
@@ -182,12 +242,12 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
                 }
                 const int dx = c.nx0 + 4 * gx;
                 const bool ownX = dx >= c.ox0 && dx < c.ox1;
-                for (int yy = yy0; yy < chh; yy += dr) {
+                for (int yy = ya + yy0; yy < yb; yy += dr) {
                     const uint2 yt = syt[yy];
                     const int sy0 = (int16_t)(yt.x & 0xFFFF), sy1 = (int16_t)(yt.x >> 16);
                     const int b0 = (int16_t)(yt.y & 0xFFFF), b1 = (int16_t)(yt.y >> 16);
-                    const int o0 = offP + (sy0 - pny0) * pstride;
-                    const int o1 = offP + (sy1 - pny0) * pstride;
+                    const int o0 = offP + (sy0 - prow0) * pstride;
+                    const int o1 = offP + (sy1 - prow0) * pstride;
                     uint32_t packed = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -208,6 +268,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
             }
           }
         }
+        }  // strips
         p = c;
         pstride = cstride;
         __syncthreads();
