@@ -1808,7 +1808,7 @@ extern "C" int orbx_debug_pair_overlap(orbx_t* h, int nb, float target_ms, int* 
         const size_t pl = ((size_t)h->pyrBufA + h->pyrBufB) * 4 + (size_t)h->pyrTabCap * 16;
         const size_t fl = (size_t)2 * (h->tileRows * h->tileStrideDw + 4) * 4 + (size_t)h->fastListCap * 2;
         const int nqb = (h->maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
-        const int32_t l[K] = {(int32_t)pl, (int32_t)fl, (int32_t)(dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel) + 18284), 13464, 31104, 24576};
+        const int32_t l[K] = {(int32_t)pl, (int32_t)fl, (int32_t)(dist_lds_bytes(h->nodeCap, g.maxCellsPerLevel) + 5552), 13464, 31104, 24576};
         const int32_t t[K] = {256, 64, kDistThreads, 256, 256, 256};
         const int32_t w[K] = {h->pyrBlocks * nb, g.totalCells * nb, g.nlevels * nb, h->blurTiles.base[g.nlevels] * nb, h->kpBlocksTotal * nb, nqb * nb};
         for (int k = 0; k < K; k++) { lds_bytes[k] = l[k]; wg_threads[k] = t[k]; wgs[k] = w[k]; }
