@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--pool", type=int, default=16, help="distinct batches of stream frames resident in HBM, cycled by the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the (untimed) host-buffer entry measurements")
+    ap.add_argument("--no-tracking-path", action="store_true", help="skip the (untimed) Tracking-shaped matcher measurements")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--no-replay", action="store_true", help="skip the untimed serialized replay (roofline.isolated); used under rocprofv3 so that its per-kernel averages are those of the timed launches")
     return ap.parse_args(argv)
@@ -297,6 +298,119 @@ def host_path(ex, cfg, frames, seconds=1.5):
     return out
 
 
+def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
+    """What Tracking runs per frame behind the extractor (never `value`; SURVEY.md 8d: "the grid-windowed variant ...
+    because that is what Tracking actually runs per frame"): Frame::Frame's tail (UndistortKeyPoints +
+    AssignFeaturesToGrid, Frame.cc:196-210) and SearchByProjection(CurrentFrame, LastFrame, th = 15, bMono)
+    (ORBmatcher.cc:1330-1472, Tracking.cc:925-936) with the identity pose, octave window +-1, every LastFrame feature a
+    query.  b1: one pageable host frame per call, keypoints + descriptors + the match table back on the host.
+    batched: B frames per step, frames resident in HBM, match tables written to pinned host memory.
+    dropin: the flattened host-array entry the ORBmatcher adapter calls (queries AND train side from host memory).
+    The CPU oracle is timed on the same pair beside it."""
+    import numpy as np
+    from orbslamm_amd import ORBmatcher, make_grid
+    from oracle import binding as ob
+    W, H = cfg["w"], cfg["h"]
+    B = ex.max_batch
+    out = {"what": "SearchByProjection(Cur, Last): identity pose, th=15, octave +-1, TH_HIGH=100, rotation check; mvKeysUn + 64x48 grid built on the device"}
+    m = ORBmatcher(0.9, True, device=ex.device)
+    sf = np.array(ex.GetScaleFactors(), np.float32)
+    g = make_grid(0.0, 0.0, float(W), float(H))
+    K, D0, bounds = [718.856, 718.856, 607.1928, 185.2157], [0, 0, 0, 0, 0], [0.0, float(W), 0.0, float(H)]
+    fs = m.frame_set(2 * B, ex.max_keypoints, K, D0, g, bounds, sf)
+    # ---- b1: host frame -> extract -> frame -> search -> match table on the host, one frame per call
+    ex.reset_stream()
+    lat, lat_search = [], []
+    nm = []
+    t_end = time.perf_counter() + seconds
+    i = 0
+    while time.perf_counter() < t_end or len(lat) < 30:
+        f = frames[i % len(frames)]
+        slot, prev = i & 1, (i & 1) ^ 1
+        t0 = time.perf_counter()
+        kps, desc, n, _, _ = ex.extract_match_host(f[None], match=False)
+        t1 = time.perf_counter()
+        fs.build_from_extractor(slot, ex)
+        if i:
+            fs.track([slot], [prev], th=15.0)
+            a, k = fs.results()
+            nm.append(int(k[0]))
+        else:
+            fs.sync()
+        t2 = time.perf_counter()
+        lat.append(t2 - t0); lat_search.append(t2 - t1)
+        i += 1
+    lat, lat_search = np.array(lat[5:]) * 1e3, np.array(lat_search[5:]) * 1e3
+    out["b1"] = {"ms_median": float(np.median(lat)), "ms_mean": float(lat.mean()), "fps": float(1e3 / lat.mean()), "frames": int(len(lat)),
+                 "search_ms_median": float(np.median(lat_search)), "search_ms_mean": float(lat_search.mean()),
+                 "matches_mean": float(np.mean(nm)), "rounds_last": fs.stats(0)[0], "candidates_last": fs.stats(0)[1],
+                 "what": "orbx_extract_match_batch(B=1, no brute-force match) + orbm_frameset_build_from_extractor + orbm_track_frames + orbm_track_results; search_ms = the last three"}
+    # ---- batched: B resident frames per step; pair p = (frame p, frame p-1), the first against the previous step's last
+    pool = len(dargs)
+
+    def step(n, extract=True):
+        base = (n & 1) * B
+        if extract:
+            ex.extract_batch_device(*dargs[n % pool])
+        fs.build_from_extractor(base, ex)
+        cur = np.arange(base, base + B)
+        last = np.concatenate([[((n & 1) ^ 1) * B + B - 1], cur[:-1]])
+        fs.track(cur, last, th=15.0)
+
+    for n in range(4):
+        step(n)
+    fs.results()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        step(n)
+        if n:
+            fs.results(back=1)  # the consumer reads step n-1's tables while step n runs
+        n += 1
+    a, k = fs.results()
+    ex.sync()
+    dt = time.perf_counter() - t0
+    out["batched"] = {"pairs_per_s": n * B / dt, "ms_per_step": dt / n * 1e3, "batch": B, "steps": n, "matches_mean": float(np.mean(k)),
+                      "what": "per step: orbx_extract_batch_device(B) + frame-set build + orbm_track_frames(B pairs), tables read one step behind"}
+    # the tracking kernels alone on the last extracted batch (k_frame_build + k_track_fused, both B workgroups)
+    for _ in range(3):
+        step(0, extract=False)
+    fs.results()
+    reps, t0 = 200, time.perf_counter()
+    for r in range(reps):
+        step(r, extract=False)
+    fs.results()
+    dt = time.perf_counter() - t0
+    out["batched"]["search_only_pairs_per_s"] = reps * B / dt
+    out["batched"]["search_only_ms_per_step"] = dt / reps * 1e3
+    # ---- dropin: everything from host arrays, per call (orbm_search_by_projection; what ORBmatcherT<...> calls)
+    kc, dc = fs.download(B - 1)
+    kl, dl = fs.download(B - 2)
+    uvr = np.stack([kl["x"], kl["y"], (np.float32(15.0) * sf[kl["octave"]]).astype(np.float32)], axis=1).astype(np.float32)
+    lvl = np.stack([kl["octave"] - 1, kl["octave"] + 1], axis=1).astype(np.int8)
+    occ0, a0 = np.zeros(len(kc), np.uint8), np.full(len(kc), -1, np.int32)
+    ts = []
+    for _ in range(60):
+        t0 = time.perf_counter()
+        ga, _, gn = m.SearchByProjection(4, 100, uvr, lvl, dl, kl["angle"], None, None, g, kc, dc, occ0, a0)
+        ts.append(time.perf_counter() - t0)
+    ts = np.array(ts[5:]) * 1e3
+    out["dropin"] = {"ms_median": float(np.median(ts)), "ms_mean": float(ts.mean()), "matches": int(gn), "rounds": m.last_search_stats()[0],
+                     "what": "orbm_search_by_projection: queries and train frame from pageable host memory, tables back on the host, per call (includes the ctypes wrapper's array checks)"}
+    # ---- the CPU oracle on the same pair (grid build + sequential search), and the check that the GPU said the same
+    gp = ob.make_grid_params(0.0, 0.0, float(W), float(H))
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        start, idx = ob.grid_build(gp, kc)
+        wa, _, wn = ob.search_by_projection(4, 0.9, True, 100, uvr, lvl, dl, kl["angle"], None, None, gp, kc, start, idx, dc, occ0, a0)
+    dt = (time.perf_counter() - t0) / reps
+    out["cpu_oracle"] = {"ms_per_pair": dt * 1e3, "pairs_per_s": 1.0 / dt, "cores": 1, "kind": "port", "matches": int(wn)}
+    out["parity_ok"] = bool(wn == gn and np.array_equal(wa, ga) and int(k[B - 1]) == wn and np.array_equal(a[B - 1, :len(kc)], wa))
+    fs.close()
+    m.close()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     import numpy as np
@@ -515,6 +629,8 @@ def run_rank(args):
             out["roofline"]["overlapped_streams"] = True
         if world == 1 and not args.no_host_path and hasattr(ex, "extract_match_host"):
             out["host_path"] = host_path(ex, cfg, first_batch)
+        if world == 1 and not args.no_tracking_path and hasattr(ex, "extract_match_host"):
+            out["tracking_path"] = tracking_path(ex, cfg, first_batch, dargs)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, first_batch)
         line = json.dumps(out) + "\n"

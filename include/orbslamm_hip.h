@@ -353,6 +353,43 @@ int orbm_search_by_projection_frame(orbm_t* h, const OrbmProjParams* pp,
                                     const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq,
                                     orbm_frame_t* train, uint8_t* t_occ, int32_t* assign, int* nmatches);
 
+/* rounds and candidates of the handle's last projection search (diagnostics: the queries of the reference's sequential
+ * loop are resolved in parallel rounds, see orbt_kernels.hip) */
+int orbm_last_search_stats(orbm_t* h, int* rounds, int* candidates);
+
+/* ---- the Tracking-shaped path, batched and without host round trips (round 3) -----------------------------------
+ * A frame set holds `slots` device-resident frames of at most `cap` features: mvKeysUn, descriptors, mGrid.
+ *   orbm_frameset_build*: the tail of Frame::Frame (src/Frame.cc:196-210: UndistortKeyPoints + AssignFeaturesToGrid) for
+ *     n frames in ONE launch from device-resident extractor output (frame i at d_keys + i*src_cap, d_desc + i*src_cap*32,
+ *     d_counts[i]; counts are read on the device), into slots (slot0 + i) % slots.  Asynchronous.
+ *   orbm_track_frames: int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th, bool bMono)
+ *     src/ORBmatcher.cc:1330-1472 as Tracking::TrackWithMotionModel calls it (src/Tracking.cc:925-936, th = 15 then 30,
+ *     bMono = true), for npairs (CurrentFrame, LastFrame) slot pairs in ONE launch.  Every LastFrame feature is a query
+ *     (as if it held a MapPoint with observations, none an outlier) projected with the identity pose: u, v =
+ *     mvKeysUn[i].pt, skipped outside `bounds` (:1375-1378), radius = th * mvScaleFactors[octave], octave window
+ *     [octave-1, octave+1] (:1381-1392) -- SURVEY.md 8(d)'s grid-windowed variant.  A caller with a pose uses
+ *     orbm_search_by_projection_frame on the same data.  pp->mode must be 4.  Asynchronous.
+ *   orbm_track_results: waits for the last (back = 0) or the last but one (back = 1) orbm_track_frames; assign[p*cap + t] =
+ *     LastFrame feature index held by CurrentFrame feature t (or -1), nmatches[p]; both point into pinned host memory the
+ *     kernel wrote (two result sets in alternation: valid until the call after next).
+ * bounds = mnMinX, mnMaxX, mnMinY, mnMaxY (Frame::ComputeImageBounds); scale_factors = mvScaleFactors. */
+typedef struct orbm_frameset orbm_frameset_t;
+int orbm_frameset_create(orbm_t* h, int slots, int cap, const float K[4], const float D[5], const OrbmGrid* grid,
+                         const float bounds[4], const float* scale_factors, int nlevels, orbm_frameset_t** out);
+int orbm_frameset_destroy(orbm_frameset_t* fs);
+int orbm_frameset_build(orbm_frameset_t* fs, int slot0, int n, const OrbxKeyPoint* d_keys, const uint8_t* d_desc,
+                        const int32_t* d_counts, int src_cap);
+/* the frames of the extractor's last batch (orbx_extract_batch_device / orbx_submit_batch), ordered behind its kernels on
+ * the device; the extractor will not reuse that result set before the build has read it. */
+int orbm_frameset_build_from_extractor(orbm_frameset_t* fs, int slot0, orbx_t* ex);
+int orbm_frameset_sync(orbm_frameset_t* fs);
+/* mvKeysUn / descriptors of one slot for the host side (pose optimisation reads mvKeysUn) */
+int orbm_frameset_download(orbm_frameset_t* fs, int slot, OrbxKeyPoint* keys_un, uint8_t* desc, int cap, int* n_out);
+int orbm_track_frames(orbm_frameset_t* fs, const OrbmProjParams* pp, float th, const int32_t* cur_slots,
+                      const int32_t* last_slots, int npairs);
+int orbm_track_results(orbm_frameset_t* fs, int back, const int32_t** assign, const int32_t** nmatches, int* npairs, int* cap);
+int orbm_track_stats(orbm_frameset_t* fs, int pair, int* rounds, int* candidates);
+
 /* void Frame::UndistortKeyPoints()   src/Frame.cc:404-434  (cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK)).
  * K = fx, fy, cx, cy; D = k1, k2, p1, p2, k3.  D[0] == 0: plain copy (:406-410).  Only pt changes. */
 int orbm_undistort_keypoints(orbm_t* h, const OrbxKeyPoint* keys, int n, const float K[4], const float D[5],

@@ -69,6 +69,8 @@ EXPORTS = [
     "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_distinctive_descriptors", "orbm_descriptors_to_text", "orbm_descriptors_from_text", "orbm_undistort_keypoints", "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_size",
     "orbm_frame_download_keys_un", "orbm_search_by_projection_frame", "orbm_frame_compute_bow", "orbm_search_by_bow_frames", "orbm_search_for_initialization_frames", "orbm_window_best_frame", "orbm_search_for_triangulation_frames",
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_transform",
+    "orbm_last_search_stats", "orbm_frameset_create", "orbm_frameset_destroy", "orbm_frameset_build", "orbm_frameset_build_from_extractor",
+    "orbm_frameset_sync", "orbm_frameset_download", "orbm_track_frames", "orbm_track_results", "orbm_track_stats",
 ]
 
 

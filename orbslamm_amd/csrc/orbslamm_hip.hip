@@ -28,6 +28,7 @@
 
 #include "orbx_kernels.hip"
 #include "orbm_kernels.hip"
+#include "orbt_kernels.hip"
 #include "orbv_kernels.hip"
 
 using namespace orbx;
@@ -55,6 +56,23 @@ static int fail(int code, const char* fmt, ...)
     } while (0)
 
 extern "C" const char* orbx_last_error(void) { return g_err.c_str(); }
+
+// live handles: objects that point at another handle (a frame set at its matcher and at the extractor it last read
+// from) check here before touching it in their destructor -- handles may be destroyed in any order
+static std::mutex g_liveMu;
+static std::vector<const void*> g_live;
+static void live_add(const void* h) { std::lock_guard<std::mutex> l(g_liveMu); g_live.push_back(h); }
+static void live_remove(const void* h)
+{
+    std::lock_guard<std::mutex> l(g_liveMu);
+    for (size_t i = 0; i < g_live.size(); i++) if (g_live[i] == h) { g_live[i] = g_live.back(); g_live.pop_back(); return; }
+}
+static bool live_has(const void* h)
+{
+    std::lock_guard<std::mutex> l(g_liveMu);
+    for (const void* p : g_live) if (p == h) return true;
+    return false;
+}
 
 extern "C" int orbx_device_count(void)
 {
@@ -268,6 +286,7 @@ struct orbx_handle {
     hipStream_t streamUp = nullptr, streamDown = nullptr;  // upload / results of a batch submitted while nothing else is in flight
     hipStream_t streamUpQ = nullptr, streamDownQ = nullptr;  // the same for a batch submitted behind others: hardware queues of their own
     hipEvent_t evOutOfSet[2] = {nullptr, nullptr};         // the download that last read result set s
+    hipEvent_t evExtReader[2] = {nullptr, nullptr};        // a frame set's build that last read result set s (owned by the frame set)
     CopyPool pool;
     int matchSet = 0;                    // result set the last matching wrote (d_match / d_nmatch half)
     void* d_stereo = nullptr; size_t stereoBytes = 0;  // orbx_compute_stereo_matches: uRight | depth | SAD | count
@@ -719,6 +738,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
     CRT(hipMemset(h->d_nmatch, 0, 2 * B * sizeof(int32_t)));
 #undef CRT
+    live_add(h);
     *out = h;
     return ORBX_OK;
 }
@@ -726,6 +746,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
 extern "C" void orbx_destroy(orbx_t* h)
 {
     if (!h) return;
+    live_remove(h);
     free_device(h);
     delete h;
 }
@@ -946,6 +967,7 @@ struct Launcher {
     {
         if (h->matchPending[set] && h->matchStream[set] != s) HIPCHK(hipStreamWaitEvent(s, h->evMatch[set], 0));
         if (h->evOutOfSet[set] && h->outStream[set] != s) HIPCHK(hipStreamWaitEvent(s, h->evOutOfSet[set], 0));
+        if (h->evExtReader[set]) HIPCHK(hipStreamWaitEvent(s, h->evExtReader[set], 0));
         h->prof.begin(P_ORIENT_DESC, s);
         if (done && !h->prof.cur)
             hipExtLaunchKernelGGL(k_orient_desc, dim3(h->kpBlocksTotal, xcd_grid_y(nb)), dim3(256), 0, s, nullptr, done, 0, (const Geom*)h->d_geom, src, h->kpBlocks,
@@ -1916,6 +1938,10 @@ struct orbm_handle {
     // growable scratch
     void* d_buf[32] = {nullptr};
     size_t d_cap[32] = {0};
+    // one packed upload / download per call (orbt_host.inc)
+    void* h_stage = nullptr; size_t h_stageCap = 0;
+    size_t projLdsAttr = 0, buildLdsAttr = 0, trackLdsAttr = 0;
+    int lastRounds = 0, lastCands = 0;   // of the last projection search (orbm_last_search_stats)
 };
 
 static int orbm_reserve(orbm_handle* h, int slot, size_t bytes)
@@ -1942,6 +1968,7 @@ extern "C" int orbm_create(int device, orbm_t** out)
         delete h;
         return fail(ORBX_E_HIP, "cannot create stream on device %d", device);
     }
+    live_add(h);
     *out = h;
     return ORBX_OK;
 }
@@ -1949,9 +1976,11 @@ extern "C" int orbm_create(int device, orbm_t** out)
 extern "C" void orbm_destroy(orbm_t* h)
 {
     if (!h) return;
+    live_remove(h);
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     for (auto p : h->d_buf) if (p) (void)hipFree(p);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     delete h;
 }
 
@@ -2195,78 +2224,7 @@ extern "C" int orbm_features_in_area(orbm_t* h, const OrbmGrid* grid, const Orbx
     return ORBX_OK;
 }
 
-// train side of a projection search, resident in HBM
-struct ProjTrain {
-    orbm::GridDev gd;
-    const orbm::KeyDev* keys;
-    const int32_t *cellStart, *cellIdx;
-    const uint8_t* desc;
-    int nt;
-};
-
-static int proj_core(orbm_handle* h, const OrbmProjParams* pp, const float* q_uvr, const int8_t* q_lvl, const uint8_t* qdesc,
-                     const float* qangle, const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq, const ProjTrain& tr,
-                     uint8_t* t_occ, int32_t* assign, int* nmatches, const float* q_ur = nullptr, const float* t_uright = nullptr)
-{
-    int rc;
-    const int nt = tr.nt;
-    enum { S_UVR, S_LVL, S_QD, S_QA, S_QV, S_QO, S_TD, S_CNT, S_OFF, S_KEY, S_CIDX, S_OCC, S_ASSIGN, S_NM, S_PUSHT, S_PUSHB };
-    const size_t sizes[] = {(size_t)nq * 12, (size_t)nq * 2, (size_t)nq * 32, (size_t)nq * 4, (size_t)nq, (size_t)nq,
-                            16, (size_t)nq * 4, (size_t)(nq + 1) * 4, 16, 16, (size_t)nt, (size_t)nt * 4, 16,
-                            (size_t)nq * 4, (size_t)nq};
-    for (int i = 0; i < 16; i++) if (i != S_TD && (rc = orbm_reserve(h, i, sizes[i]))) return rc;
-    hipStream_t s = h->stream;
-    UP(S_UVR, q_uvr, (size_t)nq * 12); UP(S_LVL, q_lvl, (size_t)nq * 2); UP(S_QD, qdesc, (size_t)nq * 32);
-    if (qangle) UP(S_QA, qangle, (size_t)nq * 4);
-    if (qvalid) UP(S_QV, qvalid, (size_t)nq);
-    if (q_obs_pos) UP(S_QO, q_obs_pos, (size_t)nq);
-    UP(S_OCC, t_occ, (size_t)nt); UP(S_ASSIGN, assign, (size_t)nt * 4);
-    enum { S_QUR = 21, S_TUR = 22 };
-    const bool stereo = q_ur && t_uright;
-    if (stereo) {
-        if ((rc = orbm_reserve(h, S_QUR, (size_t)nq * 4)) || (rc = orbm_reserve(h, S_TUR, (size_t)nt * 4))) return rc;
-        UP(S_QUR, q_ur, (size_t)nq * 4); UP(S_TUR, t_uright, (size_t)nt * 4);
-    }
-    orbm::ProjArgs a{};
-    a.qur = stereo ? (const float*)h->d_buf[S_QUR] : nullptr;
-    a.turight = stereo ? (const float*)h->d_buf[S_TUR] : nullptr;
-    a.grid = tr.gd;
-    a.tkeys = tr.keys;
-    a.cellStart = tr.cellStart; a.cellIdx = tr.cellIdx;
-    a.quvr = (const float*)h->d_buf[S_UVR]; a.qlvl = (const int8_t*)h->d_buf[S_LVL];
-    a.qdesc = (const uint8_t*)h->d_buf[S_QD]; a.qang = (const float*)h->d_buf[S_QA];
-    a.qvalid = qvalid ? (const uint8_t*)h->d_buf[S_QV] : nullptr;
-    a.qobs = q_obs_pos ? (const uint8_t*)h->d_buf[S_QO] : nullptr;
-    a.tdesc = tr.desc;
-    a.nq = nq; a.nt = nt;
-    a.candCnt = (int32_t*)h->d_buf[S_CNT]; a.candOff = (int32_t*)h->d_buf[S_OFF];
-    a.candKey = nullptr; a.candIdx = nullptr;
-    a.tocc = (uint8_t*)h->d_buf[S_OCC]; a.assign = (int32_t*)h->d_buf[S_ASSIGN]; a.nmatch = (int32_t*)h->d_buf[S_NM];
-    a.pushT = (int32_t*)h->d_buf[S_PUSHT]; a.pushBin = (uint8_t*)h->d_buf[S_PUSHB];
-    a.mode = pp->mode; a.nnratio = pp->nnratio; a.checkOri = pp->check_ori; a.thDist = pp->th_dist;
-    hipLaunchKernelGGL(orbm::k_proj_candidates, dim3((nq + 63) / 64), dim3(64), 0, s, a, 0);
-    hipLaunchKernelGGL(orbm::k_scan_small, dim3(1), dim3(1024), 0, s, (const int32_t*)a.candCnt, nq, a.candOff);
-    HIPCHK(hipGetLastError());
-    int32_t total = 0;
-    HIPCHK(hipMemcpyAsync(&total, a.candOff + nq, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if ((rc = orbm_reserve(h, S_KEY, (size_t)std::max(total, 1) * 4)) || (rc = orbm_reserve(h, S_CIDX, (size_t)std::max(total, 1) * 4))) return rc;
-    a.candKey = (uint32_t*)h->d_buf[S_KEY]; a.candIdx = (int32_t*)h->d_buf[S_CIDX];
-    hipLaunchKernelGGL(orbm::k_proj_candidates, dim3((nq + 63) / 64), dim3(64), 0, s, a, 1);
-    const int words = (nt + 31) / 32;
-    if ((size_t)words * 4 > 150 * 1024) return fail(ORBX_E_UNSUPPORTED, "too many train features for the LDS occupancy bitmap");
-    if ((size_t)words * 4 > 48 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)orbm::k_proj_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, words * 4));
-    hipLaunchKernelGGL(orbm::k_proj_resolve, dim3(1), dim3(64), (size_t)words * 4, s, a, words);
-    HIPCHK(hipGetLastError());
-    int32_t nm = 0;
-    HIPCHK(hipMemcpyAsync(t_occ, a.tocc, (size_t)nt, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(assign, a.assign, (size_t)nt * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&nm, a.nmatch, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (nmatches) *nmatches = nm;
-    return ORBX_OK;
-}
+#include "orbt_host.inc"
 
 static int proj_check(orbm_handle* h, const OrbmProjParams* pp, const float* q_uvr, const int8_t* q_lvl, const uint8_t* qdesc,
                       const float* qangle, int nq, int nt, const uint8_t* t_occ, const int32_t* assign, int* nmatches)
@@ -2307,16 +2265,9 @@ extern "C" int orbm_search_by_projection_stereo(orbm_t* h, const OrbmProjParams*
     if ((q_ur != nullptr) != (t_uright != nullptr)) return fail(ORBX_E_INVALID, "q_ur and t_uright go together");
     if (q_ur && pp->mode != 3 && pp->mode != 4) return fail(ORBX_E_INVALID, "only modes 3 and 4 have a stereo gate");
     if (nq == 0 || nt == 0) return ORBX_OK;
-    ProjTrain tr;
-    if ((rc = orbm_build_grid(h, grid, t_keys_un, nt, tr.gd))) return rc;
-    if ((rc = orbm_reserve(h, 6, (size_t)nt * 32))) return rc;
-    hipStream_t s = h->stream;
-    UP(6, tdesc, (size_t)nt * 32);
-    tr.keys = (const orbm::KeyDev*)h->d_buf[G_KEYS];
-    tr.cellStart = (const int32_t*)h->d_buf[G_START]; tr.cellIdx = (const int32_t*)h->d_buf[G_IDX];
-    tr.desc = (const uint8_t*)h->d_buf[6];
-    tr.nt = nt;
-    return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, tr, t_occ, assign, nmatches, q_ur, t_uright);
+    if (!grid || grid->cols < 1 || grid->rows < 1) return fail(ORBX_E_INVALID, "bad grid");
+    const ProjTrainHost th = {grid, t_keys_un, tdesc};
+    return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, nullptr, &th, nt, t_occ, assign, nmatches, q_ur, t_uright);
 }
 
 // ------------------------------------------------------------------ the Frame's matcher-side state in HBM
@@ -2407,8 +2358,8 @@ extern "C" int orbm_search_by_projection_frame(orbm_t* h, const OrbmProjParams* 
     int rc = proj_check(h, pp, q_uvr, q_lvl, qdesc, qangle, nq, nt, t_occ, assign, nmatches);
     if (rc) return rc;
     if (nq == 0 || nt == 0) return ORBX_OK;
-    ProjTrain tr = {train->gd, train->d_keysUn, train->d_start, train->d_idx, train->d_desc, nt};
-    return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, tr, t_occ, assign, nmatches);
+    const ProjTrain tr = {train->gd, train->d_keysUn, train->d_start, train->d_idx, train->d_desc, nt};
+    return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, &tr, nullptr, nt, t_occ, assign, nmatches);
 }
 
 // train side of a windowed best search, resident in HBM

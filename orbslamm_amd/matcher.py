@@ -178,6 +178,16 @@ class ORBmatcher:
                                                       ptr(qv), ptr(qo), q_uvr.shape[0], frame, ptr(t_occ), ptr(assign), C.byref(n)))
         return assign, t_occ, n.value
 
+    def last_search_stats(self):
+        """(rounds, candidates) of this handle's last projection search"""
+        r, c = C.c_int(0), C.c_int(0)
+        check(self._L.orbm_last_search_stats(self._h, C.byref(r), C.byref(c)))
+        return r.value, c.value
+
+    def frame_set(self, slots, cap, K, D, grid, bounds, scale_factors):
+        """a set of device-resident frames (FrameSet): Frame::Frame's tail and SearchByProjection(Cur, Last) batched"""
+        return FrameSet(self, slots, cap, K, D, grid, bounds, scale_factors)
+
     def window_best_frame(self, q_uvr, q_pred, qdesc, qvalid, frame, inv_sigma2=None, chi2=False):
         """orbm_window_best with a device-resident frame as train side (the KeyFrame of Fuse / SearchBySim3)"""
         q_uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
@@ -295,6 +305,76 @@ class ORBmatcher:
                                             C.c_float(y), C.c_float(r), int(minLevel), int(maxLevel), ptr(out),
                                             out.shape[0], C.byref(n)))
         return out[:n.value].copy()
+
+
+class FrameSet:
+    """`slots` device-resident frames (mvKeysUn, descriptors, mGrid) and the frame-to-frame projection search over
+    pairs of them, one launch per batch (include/orbslamm_hip.h: orbm_frameset_*, orbm_track_*)."""
+
+    def __init__(self, matcher, slots, cap, K, D, grid, bounds, scale_factors):
+        self._m = matcher
+        self._L = matcher._L
+        self.slots, self.cap = int(slots), int(cap)
+        K = np.ascontiguousarray(K, dtype=np.float32)
+        D = np.ascontiguousarray(D, dtype=np.float32)
+        b = np.ascontiguousarray(bounds, dtype=np.float32)
+        sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+        self._h = C.c_void_p()
+        check(self._L.orbm_frameset_create(matcher._h, self.slots, self.cap, ptr(K), ptr(D), C.byref(grid), ptr(b), ptr(sf), sf.shape[0],
+                                           C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbm_frameset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build(self, slot0, n, d_keys, d_desc, d_counts, src_cap):
+        check(self._L.orbm_frameset_build(self._h, int(slot0), int(n), C.c_void_p(int(d_keys)), C.c_void_p(int(d_desc)),
+                                          C.c_void_p(int(d_counts)), int(src_cap)))
+
+    def build_from_extractor(self, slot0, extractor):
+        check(self._L.orbm_frameset_build_from_extractor(self._h, int(slot0), extractor._h))
+
+    def sync(self):
+        check(self._L.orbm_frameset_sync(self._h))
+
+    def download(self, slot):
+        keys = np.zeros(self.cap, dtype=KP_DTYPE)
+        desc = np.zeros((self.cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        check(self._L.orbm_frameset_download(self._h, int(slot), ptr(keys), ptr(desc), self.cap, C.byref(n)))
+        return keys[:n.value].copy(), desc[:n.value].copy()
+
+    def track(self, cur_slots, last_slots, th=15.0, th_dist=100, nnratio=0.9, check_ori=True):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono=true) for every (cur, last) slot pair; asynchronous"""
+        pp = OrbmProjParams(4, float(nnratio), int(bool(check_ori)), int(th_dist))
+        cs = np.ascontiguousarray(cur_slots, dtype=np.int32)
+        ls = np.ascontiguousarray(last_slots, dtype=np.int32)
+        self._npairs = cs.shape[0]
+        check(self._L.orbm_track_frames(self._h, C.byref(pp), C.c_float(th), ptr(cs), ptr(ls), cs.shape[0]))
+
+    def results(self, back=0):
+        """waits for the last (back=0) or last-but-one (back=1) track(); (assign[npairs][cap] view of the pinned result
+        block, nmatches[npairs])"""
+        a, n, cap, npairs = C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_int(0)
+        check(self._L.orbm_track_results(self._h, int(back), C.byref(a), C.byref(n), C.byref(npairs), C.byref(cap)))
+        np_ = npairs.value
+        if np_ == 0:
+            return np.zeros((0, self.cap), np.int32), np.zeros(0, np.int32)
+        assign = np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_int32)), shape=(np_, cap.value))
+        nm = np.ctypeslib.as_array(C.cast(n, C.POINTER(C.c_int32)), shape=(np_,))
+        return assign, nm
+
+    def stats(self, pair):
+        r, c = C.c_int(0), C.c_int(0)
+        check(self._L.orbm_track_stats(self._h, int(pair), C.byref(r), C.byref(c)))
+        return r.value, c.value
 
 
 def descriptors_to_text(desc):

@@ -1,0 +1,171 @@
+"""GPU parity of the Tracking-shaped path (round 3): the fused, parallel-resolve SearchByProjection kernel on inputs
+built to stress its rounds, the batched Frame construction and the batched frame-to-frame search -- all through the C
+ABI, all against the sequential oracle (oracle/orb_match.c follows ORBmatcher.cc:45-129, 1330-1472 query by query)."""
+import numpy as np
+import pytest
+
+from conftest import random_descriptors
+from matcher_cases import make_proj_case, noisy_copies
+
+pytestmark = pytest.mark.gpu
+
+TUM_K = [517.306408, 516.469215, 318.643040, 255.313989]
+TUM_D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+KITTI_K = [718.856, 718.856, 607.1928, 185.2157]
+
+
+def _both(oracle, mode, th, ratio, ori, c, nt):
+    from orbslamm_amd import ORBmatcher, make_grid
+    g = make_grid(0.0, 0.0, c["w"], c["h"])
+    m = ORBmatcher(ratio, ori, device=0)
+    a0 = c.get("a0", np.full(nt, -1, np.int32))
+    ga, gocc, gn = m.SearchByProjection(mode, th, c["uvr"], c["lvl"], c["qd"], c["qa"], c["qv"], c["qo"], g,
+                                        c["tk"], c["td"], c["occ"], a0)
+    wa, wocc, wn = oracle.search_by_projection(mode, ratio, ori, th, c["uvr"], c["lvl"], c["qd"], c["qa"], c["qv"],
+                                               c["qo"], c["gp"], c["tk"], c["start"], c["idx"], c["td"], c["occ"], a0)
+    stats = m.last_search_stats()
+    m.close()
+    assert gn == wn, (gn, wn)
+    assert np.array_equal(ga, wa) and np.array_equal(gocc, wocc)
+    return wn, stats
+
+
+@pytest.mark.parametrize("mode,th,ratio", [(3, 100, 0.8), (4, 100, 0.9), (5, 64, 0.9), (6, 50, 0.75)])
+def test_contended_queries_resolve_in_reference_order(gpu, oracle, mode, th, ratio):
+    """Many queries compete for few train features: every query's window holds the same handful of features, so the
+    sequential loop's outcome hangs on the order (each accepted query takes a feature away from all later ones).  The
+    parallel rounds must reproduce it, including for queries whose MapPoint has no observations (modes 3/4: they take
+    nothing away and may be overwritten later)."""
+    rng = np.random.default_rng(500 + mode)
+    for nq, nt, clusters, spread in ((400, 60, 3, 4.0), (1500, 300, 10, 8.0), (64, 8, 1, 1.0), (3000, 2500, 40, 10.0)):
+        c = make_proj_case(rng, nq, nt)
+        # train features in tight clusters, queries thrown onto the cluster centres with near-identical descriptors
+        cx, cy = rng.uniform(100, 1100, clusters), rng.uniform(50, 330, clusters)
+        cl = rng.integers(0, clusters, nt)
+        c["tk"]["x"] = (cx[cl] + rng.normal(0, spread, nt)).astype(np.float32)
+        c["tk"]["y"] = (cy[cl] + rng.normal(0, spread, nt)).astype(np.float32)
+        c["tk"]["octave"] = rng.integers(0, 3, nt)
+        base = random_descriptors(rng, clusters)
+        c["td"] = noisy_copies(rng, base[cl], 6)
+        qc = rng.integers(0, clusters, nq)
+        c["qd"] = noisy_copies(rng, base[qc], 6)
+        c["uvr"][:, 0] = cx[qc] + rng.normal(0, 1.0, nq)
+        c["uvr"][:, 1] = cy[qc] + rng.normal(0, 1.0, nq)
+        c["uvr"][:, 2] = 40.0
+        c["lvl"][:] = (-1, -1) if mode != 3 else (0, 2)
+        c["start"], c["idx"] = oracle.grid_build(c["gp"], c["tk"])
+        c["a0"] = rng.integers(-1, 5, nt).astype(np.int32)  # assign is in/out: untouched entries keep their value
+        most = 0
+        for ori in (True, False):
+            for qo in (c["qo"], None, np.zeros(nq, np.uint8)):
+                cc = dict(c, qo=qo)
+                wn, (rounds, cands) = _both(oracle, mode, th, ratio, ori, cc, nt)
+                most = max(most, rounds)
+        assert wn > 0 and most > 3  # the case does contend
+
+
+def test_candidate_list_sizes_lds_arena_and_regrow(gpu, oracle):
+    """the candidate list lives in LDS when it fits, else in the handle's arena, which grows once when a call needs
+    more than it holds (reported by the kernel, never written past)"""
+    rng = np.random.default_rng(77)
+    seen = set()
+    for nq, nt, r in ((300, 900, 15.0), (600, 2000, 70.0), (2500, 3000, 2000.0), (300, 900, 15.0)):
+        c = make_proj_case(rng, nq, nt)
+        c["uvr"][:, 2] = r
+        if r > 50:
+            c["lvl"][:] = (-1, -1)
+        # mode 3 lists every feature of the window (the other modes only those within the distance threshold)
+        wn, (rounds, cands) = _both(oracle, 3, 100, 0.8, True, c, nt)
+        seen.add("lds" if cands <= 16 * nt else ("arena" if cands <= max(64 * nq, 65536) else "regrow"))
+        assert wn > 0
+    assert seen == {"lds", "arena", "regrow"}, seen
+
+
+def test_projection_degenerate_shapes(gpu, oracle):
+    from orbslamm_amd import ORBmatcher, make_grid
+    rng = np.random.default_rng(5)
+    c = make_proj_case(rng, 40, 50)
+    # all queries invalid; every train feature occupied on entry; a single query / a single train feature
+    _both(oracle, 4, 100, 0.9, True, dict(c, qv=np.zeros(40, np.uint8)), 50)
+    _both(oracle, 3, 100, 0.8, True, dict(c, occ=np.ones(50, np.uint8)), 50)
+    c1 = make_proj_case(rng, 1, 1)
+    _both(oracle, 4, 100, 0.9, True, c1, 1)
+    m = ORBmatcher(0.9, True, device=0)
+    g = make_grid(0.0, 0.0, 1241.0, 376.0)
+    a, occ, n = m.SearchByProjection(4, 100, np.zeros((0, 3), np.float32), np.zeros((0, 2), np.int8), np.zeros((0, 32), np.uint8),
+                                     np.zeros(0, np.float32), None, None, g, c["tk"], c["td"], c["occ"], np.full(50, -1, np.int32))
+    assert n == 0 and (a == -1).all() and np.array_equal(occ, c["occ"])
+    from orbslamm_amd._lib import OrbError
+    big = make_proj_case(rng, 10, 10001)
+    with pytest.raises(OrbError):  # the frame's grid must fit one CU's LDS: refused, not silently truncated
+        m.SearchByProjection(4, 100, big["uvr"], big["lvl"], big["qd"], big["qa"], None, None, g, big["tk"], big["td"], big["occ"],
+                             np.full(10001, -1, np.int32))
+
+
+def _identity_queries(keys_un, sf, th, bounds):
+    """the queries orbm_track_frames derives on the device (ORBmatcher.cc:1375-1392 with the identity pose)"""
+    uvr = np.stack([keys_un["x"], keys_un["y"], (np.float32(th) * sf[keys_un["octave"]]).astype(np.float32)], axis=1).astype(np.float32)
+    lvl = np.stack([keys_un["octave"] - 1, keys_un["octave"] + 1], axis=1).astype(np.int8)
+    x, y = keys_un["x"], keys_un["y"]
+    qv = ~((x < bounds[0]) | (x > bounds[1]) | (y < bounds[2]) | (y > bounds[3]))
+    return uvr, lvl, qv.astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,nf,K,D", [(640, 480, 1000, TUM_K, TUM_D), (1241, 376, 2000, KITTI_K, [0, 0, 0, 0, 0])])
+def test_frame_set_and_batched_tracking_search(gpu, oracle, w, h, nf, K, D):
+    """extractor -> frame set -> SearchByProjection(Cur, Last) for a batch of consecutive frames without leaving HBM:
+    mvKeysUn, descriptors and every match table equal the oracle's, fed with the downloaded arrays"""
+    from orbslamm_amd import ORBextractor, ORBmatcher, make_grid, synth
+    B = 6
+    fr = synth.make_frames(w, h, B, stream=5)
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=0)
+    sf = np.array(gex.GetScaleFactors(), np.float32)
+    gex.extract_batch_device(*gex.upload_frames(fr))
+    host = []
+    for f in range(B):
+        keys, desc = gex.download(f)
+        host.append((oracle.undistort_keypoints(keys, K, D), desc))
+    allx = np.concatenate([k["x"] for k, _ in host]); ally = np.concatenate([k["y"] for k, _ in host])
+    # any box works as "image bounds" (Frame::ComputeImageBounds is the caller's): one that cuts a few keypoints off
+    bounds = [float(np.floor(allx.min())) + 6, float(np.ceil(allx.max())) - 6, float(np.floor(ally.min())) + 6, float(np.ceil(ally.max())) - 6]
+    g = make_grid(bounds[0], bounds[2], bounds[1], bounds[3])
+    gp = oracle.make_grid_params(bounds[0], bounds[2], bounds[1], bounds[3])
+    m = ORBmatcher(0.9, True, device=0)
+    cap = gex.max_keypoints
+    fs = m.frame_set(B, cap, K, D, g, bounds, sf)
+    fs.build_from_extractor(0, gex)
+    for f in range(B):
+        ku, dd = fs.download(f)
+        assert ku.tobytes() == host[f][0].tobytes() and dd.tobytes() == host[f][1].tobytes()
+    cur = np.arange(1, B)
+    last = np.arange(0, B - 1)
+    for th, ori in ((15.0, True), (30.0, True), (15.0, False)):
+        fs.track(cur, last, th=th, th_dist=100, nnratio=0.9, check_ori=ori)
+        assign, nm = fs.results()
+        total = 0
+        for p in range(B - 1):
+            kc, dc = host[cur[p]]
+            kl, dl = host[last[p]]
+            uvr, lvl, qv = _identity_queries(kl, sf, th, bounds)
+            start, idx = oracle.grid_build(gp, kc)
+            wa, _, wn = oracle.search_by_projection(4, 0.9, ori, 100, uvr, lvl, dl, kl["angle"], qv, None, gp, kc, start, idx, dc,
+                                                    np.zeros(len(kc), np.uint8), np.full(len(kc), -1, np.int32))
+            assert nm[p] == wn, (p, nm[p], wn)
+            assert np.array_equal(assign[p, :len(kc)], wa)
+            total += wn
+            r, cands = fs.stats(p)
+            assert r >= 1 and cands > 0
+        assert total > 200 * (B - 1)
+    # a frame set built slot by slot from device pointers gives the same frames (ring order: slot0 wraps around)
+    fs2 = m.frame_set(4, cap, K, D, g, bounds, sf)
+    dk, dd, dc, rcap = gex.device_results()
+    fs2.build(3, 2, dk + 2 * rcap * 28, dd + 2 * rcap * 32, dc + 2 * 4, rcap)   # frames 2, 3 -> slots 3, 0
+    for slot, f in ((3, 2), (0, 3)):
+        ku, de = fs2.download(slot)
+        assert ku.tobytes() == host[f][0].tobytes() and de.tobytes() == host[f][1].tobytes()
+    fs2.track([0], [3], th=15.0)
+    a2, n2 = fs2.results()
+    fs.track([3], [2], th=15.0)
+    a1, n1 = fs.results()
+    assert n1[0] == n2[0] and np.array_equal(a1[0, :len(host[3][0])], a2[0, :len(host[3][0])])
+    fs.close(); fs2.close()
