@@ -707,7 +707,7 @@ struct ProjArgs {
     uint32_t* candKey;     // CSR: dist<<22 | pos<<4 | octave   (pos = rank in the reference's scan order)
     int32_t* candIdx;      // CSR: train feature index
     uint8_t* tocc; int32_t* assign; int32_t* nmatch;
-    int32_t* pushT; uint8_t* pushBin;   // rotation-histogram pushes, replayed by the pruning step
+    int32_t* pushT; uint8_t* pushBin;   // rotation-histogram pushes, replayed by the pruning step (k_init_resolve)
     int32_t mode; float nnratio; int32_t checkOri; int32_t thDist;
 };
 
@@ -746,86 +746,6 @@ __global__ void k_proj_candidates(ProjArgs a, int pass)
             pos++;
         });
     }
-}
-
-// sequential resolve in the reference's query order; one wave, occupancy bitmap in LDS
-__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a, int bitmapWords)
-{
-    extern __shared__ uint32_t occ[];  // nt bits
-    __shared__ int hist[32];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < bitmapWords; i += 64) {
-        uint32_t w = 0;
-        for (int b = 0; b < 32; b++) { const int t = i * 32 + b; if (t < a.nt && a.tocc[t]) w |= 1u << b; }
-        occ[i] = w;
-    }
-    if (lane < 32) hist[lane] = 0;
-    __syncthreads();
-    const bool useRot = a.checkOri && (a.mode == 4 || a.mode == 5);
-    // pushes into the rotation histogram are replayed for pruning: (train index, bin), one per accepted query
-    int nPush = 0, nmatches = 0;
-    int32_t* pushT = a.pushT;
-    uint8_t* pushBin = a.pushBin;
-    for (int q = 0; q < a.nq; q++) {
-        const int cs = a.candOff[q], ce = a.candOff[q + 1];
-        if (ce == cs) continue;
-        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-        for (int c = cs + lane; c < ce; c += 64) {
-            const int t = a.candIdx[c];
-            if (occ[t >> 5] & (1u << (t & 31))) continue;
-            const uint32_t key = a.candKey[c];
-            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
-        }
-#pragma unroll
-        for (int dd = 32; dd >= 1; dd >>= 1) {
-            const uint32_t o1 = __shfl_xor(k1, dd), o2 = __shfl_xor(k2, dd);
-            top2_merge(k1, k2, o1, o2);
-        }
-        if (k1 == 0xFFFFFFFFu) continue;  // bestDist stays 256 > every threshold
-        const int best = (int)(k1 >> 22);
-        const int best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 22);
-        const int bestLevel = (int)(k1 & 15), bestLevel2 = k2 == 0xFFFFFFFFu ? -1 : (int)(k2 & 15);
-        if (best <= a.thDist) {
-            if (a.mode == 3 && bestLevel == bestLevel2 && (float)best > __fmul_rn(a.nnratio, (float)best2)) continue;
-            const int t = a.candIdx[cs + (int)((k1 >> 4) & 0x3FFFF)];
-            nmatches++;
-            if (lane == 0) {
-                a.assign[t] = q;
-                const bool block = (a.mode == 3 || a.mode == 4) ? (!a.qobs || a.qobs[q]) : true;
-                if (block) occ[t >> 5] |= 1u << (t & 31);
-                if (useRot) {
-                    const int bin = rot_bin(a.qang[q], a.tkeys[t].angle);
-                    pushT[nPush] = t;
-                    pushBin[nPush] = (uint8_t)bin;
-                    hist[bin]++;
-                }
-            }
-            if (useRot) nPush++;
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    if (useRot && lane == 0) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < kHistoLength; i++) {
-            const int s = hist[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
-        }
-        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-        for (int p = 0; p < nPush; p++) {
-            const int bin = pushBin[p];
-            if (bin != ind1 && bin != ind2 && bin != ind3) { a.assign[pushT[p]] = -1; nmatches--; }
-        }
-    }
-    __syncthreads();
-    for (int i = lane; i < bitmapWords; i += 64) {
-        const uint32_t w = occ[i];
-        for (int b = 0; b < 32; b++) { const int t = i * 32 + b; if (t < a.nt) a.tocc[t] = (w >> b) & 1; }
-    }
-    if (lane == 0) *a.nmatch = nmatches;
 }
 
 // one-query GetFeaturesInArea (tests)

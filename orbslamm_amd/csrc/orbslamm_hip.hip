@@ -1940,7 +1940,7 @@ struct orbm_handle {
     size_t d_cap[32] = {0};
     // one packed upload / download per call (orbt_host.inc)
     void* h_stage = nullptr; size_t h_stageCap = 0;
-    size_t projLdsAttr = 0, buildLdsAttr = 0, trackLdsAttr = 0;
+    size_t ldsAttr[8] = {0};             // hipFuncAttributeMaxDynamicSharedMemorySize already raised for kernel i
     int lastRounds = 0, lastCands = 0;   // of the last projection search (orbm_last_search_stats)
 };
 
@@ -2278,6 +2278,8 @@ struct orbm_frame {
     orbm::KeyDev* d_keysUn = nullptr;
     uint8_t* d_desc = nullptr;
     int32_t *d_cnt = nullptr, *d_start = nullptr, *d_fill = nullptr, *d_idx = nullptr;
+    uint4* d_rec = nullptr;                  // the features in grid order (orbt::FrameSetDev::rec), read by the projection searches
+    int32_t* d_n = nullptr;
     float* d_ang = nullptr;                  // mvKeysUn[i].angle, contiguous (the BoW search reads angles by feature index)
     bool hasBow = false;                     // orbm_frame_compute_bow ran: FeatureVector as CSR, node ids on the host
     std::vector<uint32_t> fvNode;
@@ -2291,7 +2293,7 @@ extern "C" int orbm_frame_destroy(orbm_frame_t* f)
     if (f->owner && f->owner->device >= 0) {
         (void)hipSetDevice(f->owner->device);
         (void)hipStreamSynchronize(f->owner->stream);
-        void* ptrs[] = {f->d_keysUn, f->d_desc, f->d_cnt, f->d_start, f->d_fill, f->d_idx, f->d_ang, f->d_fvStart, f->d_fvIdx};
+        void* ptrs[] = {f->d_keysUn, f->d_desc, f->d_cnt, f->d_start, f->d_fill, f->d_idx, f->d_ang, f->d_fvStart, f->d_fvIdx, f->d_rec, f->d_n};
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
     delete f;
@@ -2318,18 +2320,35 @@ extern "C" int orbm_frame_create(orbm_t* h, const OrbxKeyPoint* d_keys, const ui
     FCR(hipMalloc(&f->d_idx, (size_t)nn * 4));
     FCR(hipMalloc(&f->d_ang, (size_t)nn * 4));
     hipStream_t s = h->stream;
-    if (n) {
-        FCR(hipMemcpyAsync(f->d_desc, d_desc, (size_t)n * 32, hipMemcpyDeviceToDevice, s));
-        if (D[0] == 0.0f) {  // mvKeysUn = mvKeys (Frame.cc:406-410)
-            FCR(hipMemcpyAsync(f->d_keysUn, d_keys, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToDevice, s));
-        } else {
-            orbm::UndistArgs a = {K[0], K[1], K[2], K[3], D[0], D[1], D[2], D[3], D[4]};
-            hipLaunchKernelGGL(orbm::k_undistort, dim3((n + 255) / 256), dim3(256), 0, s, (const orbm::KeyDev*)d_keys, n, a, f->d_keysUn);
+    FCR(hipMalloc(&f->d_rec, (size_t)nn * 16));
+    FCR(hipMalloc(&f->d_n, 16));
+    if (ncell <= kProjMaxCells && n <= 16384 && !((uintptr_t)d_desc & 15)) {
+        // one launch: mvKeysUn, angles, descriptors, grid, grid-ordered records
+        orbt::FrameBuildArgs fa{};
+        fa.fs = {f->d_keysUn, f->d_desc, f->d_ang, f->d_start, f->d_idx, f->d_rec, f->d_n, nn, ncell};
+        fa.srcKeys = (const orbm::KeyDev*)d_keys; fa.srcDesc = d_desc; fa.srcCount = nullptr; fa.srcCap = nn; fa.srcN = n;
+        fa.slot0 = 0; fa.slotMod = 1;
+        fa.grid = {grid->minX, grid->minY, grid->invW, grid->invH, grid->cols, grid->rows};
+        fa.und = {K[0], K[1], K[2], K[3], D[0], D[1], D[2], D[3], D[4]};
+        fa.undistort = D[0] != 0.0f;  // mvKeysUn = mvKeys otherwise (Frame.cc:406-410)
+        f->gd = fa.grid;
+        if ((rc = frame_build_launch(h, fa, 1))) { orbm_frame_destroy(f); return rc; }
+    } else {
+        if (n) {
+            FCR(hipMemcpyAsync(f->d_desc, d_desc, (size_t)n * 32, hipMemcpyDeviceToDevice, s));
+            if (D[0] == 0.0f) {  // mvKeysUn = mvKeys (Frame.cc:406-410)
+                FCR(hipMemcpyAsync(f->d_keysUn, d_keys, (size_t)n * sizeof(OrbxKeyPoint), hipMemcpyDeviceToDevice, s));
+            } else {
+                orbm::UndistArgs a = {K[0], K[1], K[2], K[3], D[0], D[1], D[2], D[3], D[4]};
+                hipLaunchKernelGGL(orbm::k_undistort, dim3((n + 255) / 256), dim3(256), 0, s, (const orbm::KeyDev*)d_keys, n, a, f->d_keysUn);
+            }
+            FCR(hipMemcpy2DAsync(f->d_ang, 4, (const uint8_t*)d_keys + 12, sizeof(OrbxKeyPoint), 4, (size_t)n, hipMemcpyDeviceToDevice, s));
         }
+        FCR(hipFree(f->d_rec));  // a grid this large has no LDS-resident form: no projection search on this frame
+        f->d_rec = nullptr;
+        if ((rc = grid_build_device(grid, f->d_keysUn, n, f->d_cnt, f->d_start, f->d_fill, f->d_idx, s, f->gd))) { orbm_frame_destroy(f); return rc; }
     }
-    if (n) FCR(hipMemcpy2DAsync(f->d_ang, 4, (const uint8_t*)d_keys + 12, sizeof(OrbxKeyPoint), 4, (size_t)n, hipMemcpyDeviceToDevice, s));
 #undef FCR
-    if ((rc = grid_build_device(grid, f->d_keysUn, n, f->d_cnt, f->d_start, f->d_fill, f->d_idx, s, f->gd))) { orbm_frame_destroy(f); return rc; }
     if (hipStreamSynchronize(s) != hipSuccess) { orbm_frame_destroy(f); return fail(ORBX_E_HIP, "frame construction failed"); }
     *out = f;
     return ORBX_OK;
@@ -2358,7 +2377,8 @@ extern "C" int orbm_search_by_projection_frame(orbm_t* h, const OrbmProjParams* 
     int rc = proj_check(h, pp, q_uvr, q_lvl, qdesc, qangle, nq, nt, t_occ, assign, nmatches);
     if (rc) return rc;
     if (nq == 0 || nt == 0) return ORBX_OK;
-    const ProjTrain tr = {train->gd, train->d_keysUn, train->d_start, train->d_idx, train->d_desc, nt};
+    if (!train->d_rec) return fail(ORBX_E_UNSUPPORTED, "the frame's grid is too large for the projection search");
+    const ProjTrain tr = {train->gd, train->d_keysUn, train->d_start, train->d_idx, train->d_desc, nt, train->d_rec};
     return proj_core(h, pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, &tr, nullptr, nt, t_occ, assign, nmatches);
 }
 

@@ -36,6 +36,13 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kFree = 0x7FFFFFFF;
 constexpr int kMaxQueryIters = 32;  // decided-bit per (thread, iteration): nq <= 32 * 1024
 
+#ifdef ORBT_PHASE_TIMING  // tools/proj_phases.sh: where a workgroup of k_proj_fused spends its time (100 MHz wall clock)
+__device__ unsigned long long g_orbtPhase[16];
+#define ORBT_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_orbtPhase[i] = wall_clock64(); } while (0)
+#else
+#define ORBT_MARK(i) do { } while (0)
+#endif
+
 // exclusive scan of one value per thread over the workgroup; returns the exclusive prefix, *total = sum
 __device__ __forceinline__ int block_scan_excl(int v, int* wsum, int* total)
 {
@@ -54,8 +61,10 @@ __device__ __forceinline__ int block_scan_excl(int v, int* wsum, int* total)
 }
 
 // ------------------------------------------------------------------ frame set: B device-resident frames, one launch
-struct FrameSetDev {  // slot s: keysUn + s*cap, desc + s*cap*32, ang + s*cap, cellStart + s*(ncell+1), cellIdx + s*cap, n + s
-    KeyDev* keysUn; uint8_t* desc; float* ang; int32_t* cellStart; int32_t* cellIdx; int32_t* n;
+struct FrameSetDev {  // slot s: keysUn + s*cap, desc + s*cap*32, ang + s*cap, cellStart + s*(ncell+1), cellIdx + s*cap, rec + s*cap, n + s
+    KeyDev* keysUn; uint8_t* desc; float* ang; int32_t* cellStart; int32_t* cellIdx;
+    uint4* rec;   // the features in GRID order as {x, y, index | octave << 24, 0}: what a window walk reads, in one piece
+    int32_t* n;
     int32_t cap, ncell;
 };
 
@@ -95,13 +104,14 @@ __device__ __forceinline__ void undistort_point(const UndistArgs& a, float& px, 
 
 // One workgroup per frame: mvKeysUn, the angle column, a private copy of the descriptors and mGrid as CSR
 // (cell-major ix*rows+iy, ascending feature index inside a cell = the reference's push_back order, Frame.cc:236-244).
-// LDS: 2 * ncell ints (counts -> starts, fill cursors).
+// LDS: 2 * ncell ints (counts -> starts, fill cursors) + cap uint16 (the cell lists, sorted in place before they go out).
 __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
 {
     extern __shared__ int32_t gl[];
     __shared__ int wsum[kWaves];
     int32_t* cnt = gl;
     int32_t* cur = gl + a.fs.ncell;
+    uint16_t* lst = (uint16_t*)(gl + 2 * a.fs.ncell);
     const int tid = threadIdx.x;
     const int src = blockIdx.x;
     const int slot = (a.slot0 + src) % a.slotMod;
@@ -111,6 +121,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
     float* __restrict__ da = a.fs.ang + (int64_t)slot * a.fs.cap;
     int32_t* __restrict__ cs = a.fs.cellStart + (int64_t)slot * (a.fs.ncell + 1);
     int32_t* __restrict__ ci = a.fs.cellIdx + (int64_t)slot * a.fs.cap;
+    uint4* __restrict__ rec = a.fs.rec + (int64_t)slot * a.fs.cap;
     for (int c = tid; c < a.fs.ncell; c += kThreads) { cnt[c] = 0; cur[c] = 0; }
     __syncthreads();
     for (int i = tid; i < n; i += kThreads) {
@@ -143,26 +154,33 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
         int px, py;
         if (orbm::pos_in_grid(a.grid, kp.x, kp.y, px, py)) {
             const int c = px * a.grid.rows + py;
-            ci[cnt[c] + atomicAdd(&cur[c], 1)] = i;
+            lst[cnt[c] + atomicAdd(&cur[c], 1)] = (uint16_t)i;
         }
     }
     __syncthreads();
     for (int c = tid; c < a.fs.ncell; c += kThreads) {  // restore insertion order inside every cell
         const int s = cnt[c], e = s + cur[c];
         for (int i = s + 1; i < e; i++) {
-            const int v = ci[i];
+            const uint16_t v = lst[i];
             int j = i - 1;
-            while (j >= s && ci[j] > v) { ci[j + 1] = ci[j]; j--; }
-            ci[j + 1] = v;
+            while (j >= s && lst[j] > v) { lst[j + 1] = lst[j]; j--; }
+            lst[j + 1] = v;
         }
+    }
+    __syncthreads();
+    for (int j = tid; j < carry; j += kThreads) {
+        const int i = lst[j];
+        const KeyDev& kp = dk[i];
+        ci[j] = i;
+        rec[j] = make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), (uint32_t)i | ((uint32_t)kp.octave << 24), 0u);
     }
 }
 
-// ------------------------------------------------------------------ SearchByProjection, fused and batched
+// ------------------------------------------------------------------ SearchByProjection, batched: candidates + resolve
 struct ProjPair {
     // train side = the frame whose grid is searched (CurrentFrame of modes 3-5, the KeyFrame of mode 6)
     GridDev grid;
-    const KeyDev* tkeys; const int32_t* cellStart; const int32_t* cellIdx; const uint8_t* tdesc;
+    const KeyDev* tkeys; const int32_t* cellStart; const uint4* trec; const uint8_t* tdesc;   // trec: FrameSetDev::rec
     const int32_t* ntPtr; int32_t nt;            // ntPtr: count read on the device (frame set), else nt
     // query side: explicit arrays ...
     const float* quvr; const int8_t* qlvl; const uint8_t* qdesc; const float* qang;
@@ -178,7 +196,11 @@ struct ProjPair {
     int32_t* assign; int32_t initAssign;         // initAssign: assign starts as all -1 (not read)
     int32_t* nmatch;                             // < 0: candidate arena overflow, -(needed entries) - 1
     // scratch
-    int32_t* candOff; uint32_t* cand; int32_t candCap; int32_t* qres;
+    int32_t* total;                              // candidates listed so far; zero on entry, left zero by the resolve
+    int32_t* candOff; int32_t* candCnt;          // per query: its list = cand[candOff[q] .. +candCnt[q])
+    uint2* cand; int32_t candCap;                // {distance << 20 | octave << 16 | train index, query}
+    int32_t* qres;                               // [nq]
+    int32_t* qscr;                               // [2 nq ints + nq bytes] best / second / state of a query when they do not fit LDS
     int32_t* stats;                              // optional: [0] rounds, [1] candidates
 };
 
@@ -186,257 +208,364 @@ struct ProjCommon {
     int32_t mode; float nnratio; int32_t checkOri; int32_t thDist;
     const float* scale; int32_t nlevels;
     int32_t tCap;      // LDS entries per per-train array (>= every pair's nt)
-    int32_t cellCap;   // LDS entries of the cell-start table (>= cols*rows + 1 of every pair)
-    int32_t ldsCand;   // candidate entries that fit in LDS behind the tables; longer lists go to the pair's arena
+    int32_t cellCap;   // LDS entries of the cell-start table (>= cols*rows + 1 of every pair; even)
+    int32_t stageCap;  // candidates: entries (8 bytes) of a slice's staging buffer in LDS behind the grid
+    int32_t qCap;      // resolve: queries whose tables fit in LDS   } more of either: the rounds work in memory
+    int32_t ldsCand;   // resolve: candidate entries that fit in LDS }
 };
 
-// LDS (dynamic), in this order:
-//   recX, recY (float) and recI (index | octave << 24) of the train features in GRID order  3 * tCap dwords
-//   occBy, minUnd[2], winner                                                                 4 * tCap dwords
-//   candidates                                                                               ldsCand dwords
-//   cell starts (uint16)                                                                     cellCap halves
-// The whole matcher-side state of a frame (2000 features: 62 KB) sits in one CU's 160 KB: GetFeaturesInArea becomes
-// a walk at LDS latency, and since cells are stored column-major (ix * rows + iy) one grid column of a window is ONE
-// contiguous run of records in the reference's scan order (Frame.cc:352-376).
-template <class F>
-__device__ __forceinline__ void lds_area(const GridDev& g, const float* recX, const float* recY, const uint32_t* recI,
-                                         const uint16_t* cst, float x, float y, float r, int minLevel, int maxLevel, F f)
+constexpr int kCandThreads = 256;
+constexpr int kCandLanes = 4;                            // lanes per query: the grid columns of its window are dealt round-robin
+constexpr int kCandQueries = kCandThreads / kCandLanes;  // queries per workgroup (a "slice")
+constexpr int kCandPasses = 4;                           // columns per lane; a wider window is walked by lane 0 alone
+
+// The train frame's grid in LDS: its features in GRID order as {x, y, index | octave << 24, 0} (one 16-byte read per
+// visit) and the cell starts (uint16).  GetFeaturesInArea becomes a walk at LDS latency, and since cells are stored
+// column-major (ix * rows + iy) one grid column of a window is ONE contiguous run of records in the reference's scan
+// order (Frame.cc:352-376).
+struct AreaWin { int x0, x1, y0, y1; bool check; };
+
+// cell range of GetFeaturesInArea (Frame.cc:332-346); false: the window misses the grid
+__device__ __forceinline__ bool area_window(const GridDev& g, float x, float y, float r, int minLevel, int maxLevel, AreaWin& w)
 {
-    int nMinCellX = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW));
-    if (nMinCellX < 0) nMinCellX = 0;
-    if (nMinCellX >= g.cols) return;
-    int nMaxCellX = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW));
-    if (nMaxCellX > g.cols - 1) nMaxCellX = g.cols - 1;
-    if (nMaxCellX < 0) return;
-    int nMinCellY = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH));
-    if (nMinCellY < 0) nMinCellY = 0;
-    if (nMinCellY >= g.rows) return;
-    int nMaxCellY = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH));
-    if (nMaxCellY > g.rows - 1) nMaxCellY = g.rows - 1;
-    if (nMaxCellY < 0) return;
-    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-        const int j1 = cst[ix * g.rows + nMaxCellY + 1];
-        for (int j = cst[ix * g.rows + nMinCellY]; j < j1; j++) {
-            const uint32_t io = recI[j];
-            const int oct = (int)(io >> 24);
-            if (bCheckLevels) {
-                if (oct < minLevel) continue;
-                if (maxLevel >= 0 && oct > maxLevel) continue;
-            }
-            const float distx = __fsub_rn(recX[j], x), disty = __fsub_rn(recY[j], y);
-            if (fabsf(distx) < r && fabsf(disty) < r) f((int)(io & 0xFFFFFF), oct);
+    w.x0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW));
+    if (w.x0 < 0) w.x0 = 0;
+    if (w.x0 >= g.cols) return false;
+    w.x1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW));
+    if (w.x1 > g.cols - 1) w.x1 = g.cols - 1;
+    if (w.x1 < 0) return false;
+    w.y0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH));
+    if (w.y0 < 0) w.y0 = 0;
+    if (w.y0 >= g.rows) return false;
+    w.y1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH));
+    if (w.y1 > g.rows - 1) w.y1 = g.rows - 1;
+    if (w.y1 < 0) return false;
+    w.check = (minLevel > 0) || (maxLevel >= 0);
+    return true;
+}
+
+template <class F>
+__device__ __forceinline__ void area_column(const GridDev& g, const uint4* rec, const uint16_t* cst, const AreaWin& w, int ix,
+                                            float x, float y, float r, int minLevel, int maxLevel, F f)
+{
+    const int j1 = cst[ix * g.rows + w.y1 + 1];
+    for (int j = cst[ix * g.rows + w.y0]; j < j1; j++) {
+        const uint4 e = rec[j];
+        const int oct = (int)(e.z >> 24);
+        if (w.check) {
+            if (oct < minLevel) continue;
+            if (maxLevel >= 0 && oct > maxLevel) continue;
         }
+        const float distx = __fsub_rn(__uint_as_float(e.x), x), disty = __fsub_rn(__uint_as_float(e.y), y);
+        if (fabsf(distx) < r && fabsf(disty) < r) f((int)(e.z & 0xFFFFFF), oct);
     }
 }
 
-__device__ __forceinline__ void proj_body(const ProjPair& P, const ProjCommon& c)
+__device__ __forceinline__ int hamming_rows(const uint8_t* __restrict__ qd, uint32_t q, const uint8_t* __restrict__ td, uint32_t t)
+{
+    const uint4* qp = (const uint4*)(qd + (int64_t)q * 32);
+    const uint4* tp = (const uint4*)(td + (int64_t)t * 32);
+    const uint4 a0 = qp[0], a1 = qp[1], b0 = tp[0], b1 = tp[1];
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// exclusive scan over the 256 threads of a candidate workgroup
+__device__ __forceinline__ int wg_scan_excl(int v, int* wsum, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    __syncthreads();  // wsum may still be read from the previous use
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kCandThreads / 64; w++) { const int s = wsum[w]; if (w < wave) woff += s; tot += s; }
+    *total = tot;
+    return woff + incl - v;
+}
+
+// exclusive prefix over the kCandLanes lanes of a query, *tot = their sum
+__device__ __forceinline__ int quad_scan_excl(int v, int c, int* tot)
+{
+    int incl = v;
+    int t = __shfl_up(incl, 1, kCandLanes); if (c >= 1) incl += t;
+    t = __shfl_up(incl, 2, kCandLanes); if (c >= 2) incl += t;
+    *tot = __shfl(incl, kCandLanes - 1, kCandLanes);
+    return incl - v;
+}
+
+// Candidates of a slice of 64 queries, four lanes per query (a query's grid columns are dealt to its lanes, so the
+// 7-column window of a coarse-level query costs what the 3-column window of a fine one does): the windows are walked in
+// LDS (count, scan, walk again and list into an LDS staging buffer), the Hamming distances are filled in by a flat loop
+// -- one entry per thread and step, all loads independent (inside the divergent window walk every gather would cost the
+// whole wave a memory round trip) -- and what lies within the threshold goes to a chunk of the pair's arena allocated
+// with one atomicAdd.  Lists keep the reference's scan order (GetFeaturesInArea, Frame.cc:327-380): column by column.
+__device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const ProjCommon& c, int slice)
 {
     extern __shared__ int32_t tl[];
-    __shared__ int hist[32];
-    __shared__ int wsum[kWaves];
-    __shared__ int sPending[3];
-    __shared__ int sInd[3];
-    __shared__ int sCount;
-    float* recX = (float*)tl;
-    float* recY = recX + c.tCap;
-    uint32_t* recI = (uint32_t*)(recY + c.tCap);
-    int32_t* occBy = (int32_t*)(recI + c.tCap);  // kFree, -1 (occupied on entry) or the blocking query that took the feature
-    int32_t* minUnd0 = occBy + c.tCap;           // two copies, used by alternate rounds (the idle one is cleared meanwhile)
-    int32_t* winner = occBy + 3 * c.tCap;        // last query (in query order) that took the feature in this call
-    uint32_t* candL = (uint32_t*)(occBy + 4 * c.tCap);
-    uint16_t* cst = (uint16_t*)(candL + c.ldsCand);
-    const int tid = threadIdx.x;
+    __shared__ int wsum[kCandThreads / 64];
+    __shared__ int sBase;
+    uint4* rec = (uint4*)tl;
+    uint2* stage = (uint2*)(rec + c.tCap);
+    uint16_t* cst = (uint16_t*)(stage + c.stageCap);
+    const int tid = threadIdx.x, lc = tid & (kCandLanes - 1);
     const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
     const int nq = min(P.nqPtr ? *P.nqPtr : P.nq, kMaxQueryIters * kThreads);
-    const bool useRot = c.checkOri && (c.mode == 4 || c.mode == 5);
-    const bool obsRule = c.mode == 3 || c.mode == 4;
+    if (nt <= 0 || slice * kCandQueries >= nq) return;
     const int ncell = min(P.grid.cols * P.grid.rows, c.cellCap - 1);
-
-    for (int t = tid; t < nt; t += kThreads) {
-        occBy[t] = (P.toccIn && P.toccIn[t]) ? -1 : kFree;
-        minUnd0[t] = kFree; minUnd0[c.tCap + t] = kFree;
-        winner[t] = -1;
-    }
-    if (tid < 32) hist[tid] = 0;
-    if (tid < 3) sPending[tid] = 0;
-    if (tid == 0) sCount = 0;
-    if (nq <= 0 || nt <= 0) {
-        for (int t = tid; t < nt; t += kThreads) {
-            if (P.initAssign) P.assign[t] = -1;
-            P.toccOut[t] = (P.toccIn && P.toccIn[t]) ? 1 : 0;
-        }
-        if (tid == 0) { *P.nmatch = 0; if (P.stats) { P.stats[0] = 0; P.stats[1] = 0; } }
-        return;
-    }
-    // the train frame's grid into LDS
-    for (int ci = tid; ci <= ncell; ci += kThreads) cst[ci] = (uint16_t)P.cellStart[ci];
+    for (int ci = tid; ci <= ncell; ci += kCandThreads) cst[ci] = (uint16_t)P.cellStart[ci];
     const int ngrid = min(P.cellStart[ncell], nt);
-    for (int j = tid; j < ngrid; j += kThreads) {
-        const int i = P.cellIdx[j];
-        const KeyDev& kp = P.tkeys[i];
-        recX[j] = kp.x; recY[j] = kp.y;
-        recI[j] = (uint32_t)i | ((uint32_t)kp.octave << 24);
-    }
-    __syncthreads();
-
-    // the query's search window; false = the reference skips this query before GetFeaturesInArea
-    auto window = [&](int q, float& u, float& v, float& r, int& minL, int& maxL) -> bool {
-        if (P.qvalid && !P.qvalid[q]) return false;
+    for (int j = tid; j < ngrid; j += kCandThreads) rec[j] = P.trec[j];
+    // the query's search window; !ok = the reference skips this query before GetFeaturesInArea
+    const int q = slice * kCandQueries + (tid >> 2);
+    float u = 0.f, v = 0.f, r = 0.f; int minL = 0, maxL = 0;
+    bool ok = q < nq && !(P.qvalid && !P.qvalid[q]);
+    if (ok) {
         if (P.quvr) {
             u = P.quvr[3 * q]; v = P.quvr[3 * q + 1]; r = P.quvr[3 * q + 2];
             minL = P.qlvl[2 * q]; maxL = P.qlvl[2 * q + 1];
-            return true;
+        } else {
+            const KeyDev& k = P.qkeys[q];
+            u = k.x; v = k.y;
+            if (u < P.minX || u > P.maxX || v < P.minY || v > P.maxY) ok = false;
+            const int o = k.octave;
+            r = __fmul_rn(P.th, c.scale[min(max(o, 0), c.nlevels - 1)]);
+            minL = o - 1; maxL = o + 1;
         }
-        const KeyDev& k = P.qkeys[q];
-        u = k.x; v = k.y;
-        if (u < P.minX || u > P.maxX) return false;
-        if (v < P.minY || v > P.maxY) return false;
-        const int o = k.octave;
-        r = __fmul_rn(P.th, c.scale[min(max(o, 0), c.nlevels - 1)]);
-        minL = o - 1; maxL = o + 1;
-        return true;
-    };
-    auto stereo_ok = [&](int q, int t, float r) {
+    }
+    AreaWin w{};
+    if (ok) ok = area_window(P.grid, u, v, r, minL, maxL, w);
+    const bool wide = ok && (w.x1 - w.x0 + 1 > kCandLanes * kCandPasses);
+    const float qur = (ok && P.turight) ? P.qur[q] : 0.f;
+    auto stereo_ok = [&](int t) {
         if (!P.turight) return true;
         const float tr = P.turight[t];
-        return !(tr > 0.f) || !(fabsf(__fsub_rn(P.qur[q], tr)) > r);
+        return !(tr > 0.f) || !(fabsf(__fsub_rn(qur, tr)) > r);
     };
-
-    // ---- candidates: count, scan, fill (reference scan order: GetFeaturesInArea, Frame.cc:327-380).
-    // Only mode 3 looks at anything but the best free candidate (its ratio test reads the second best whatever its
-    // distance); in the other modes a candidate farther than the acceptance threshold can never be taken, so it is
-    // not listed at all -- lists shrink to the plausible matches and so does the contention between queries.
-    const bool listAll = c.mode == 3;
-    int carry = 0;
-    for (int base = 0; base < nq; base += kThreads) {
-        const int q = base + tid;
-        int cnt = 0;
-        float u, v, r; int minL, maxL;
-        if (q < nq && window(q, u, v, r, minL, maxL)) {
-            uint32_t qw[8];
-            const uint32_t* qp = (const uint32_t*)(P.qdesc + (int64_t)q * 32);
+    // f(pass, column) for this lane's columns, in the order the query's list wants them within the lane
+    auto my_columns = [&](auto f) {
+        if (!ok) return;
+        if (wide) { if (lc == 0) for (int ix = w.x0; ix <= w.x1; ix++) f(0, ix); return; }
 #pragma unroll
-            for (int i = 0; i < 8; i++) qw[i] = qp[i];
-            lds_area(P.grid, recX, recY, recI, cst, u, v, r, minL, maxL, [&](int t, int) {
-                if (!stereo_ok(q, t, r)) return;
-                if (listAll || orbm::hamming256(qw, (const uint32_t*)(P.tdesc + (int64_t)t * 32)) <= c.thDist) cnt++;
-            });
-        }
-        int tot;
-        const int ex = block_scan_excl(cnt, wsum, &tot);
-        if (q < nq) P.candOff[q] = carry + ex;
-        carry += tot;
+        for (int pi = 0; pi < kCandPasses; pi++) { const int ix = w.x0 + pi * kCandLanes + lc; if (ix <= w.x1) f(pi, ix); }
+    };
+    __syncthreads();
+    int cnt[kCandPasses] = {0, 0, 0, 0};
+    my_columns([&](int pi, int ix) {
+        int n = 0;
+        area_column(P.grid, rec, cst, w, ix, u, v, r, minL, maxL, [&](int t, int) { if (stereo_ok(t)) n++; });
+#pragma unroll
+        for (int k = 0; k < kCandPasses; k++) if (k == pi) cnt[k] += n;
+    });
+    // a query's list: pass by pass, inside a pass lane by lane (= column by column)
+    int off[kCandPasses], qtot = 0;
+#pragma unroll
+    for (int pi = 0; pi < kCandPasses; pi++) {
+        int ptot;
+        off[pi] = qtot + quad_scan_excl(cnt[pi], lc, &ptot);
+        qtot += ptot;
     }
-    if (tid == 0) P.candOff[nq] = carry;
-    const bool inLds = carry <= c.ldsCand;
-    if (!inLds && carry > P.candCap) {  // uniform: nothing is written past the arena
-        if (tid == 0) { *P.nmatch = -carry - 1; if (P.stats) { P.stats[0] = 0; P.stats[1] = carry; } }
+    int tot;
+    const int qoff = __shfl(wg_scan_excl(lc == 0 ? qtot : 0, wsum, &tot), 0, kCandLanes);
+    if (tot == 0) {  // uniform
+        if (q < nq && lc == 0) { P.candOff[q] = 0; P.candCnt[q] = 0; }
         return;
     }
-    __syncthreads();
-    uint32_t decided = 0;
-    for (int j = 0, q = tid; q < nq; q += kThreads, j++) {
-        const int b0 = P.candOff[q], b1 = P.candOff[q + 1];
-        P.qres[q] = -1;
-        if (b1 == b0) { decided |= 1u << j; continue; }
-        float u, v, r; int minL, maxL;
-        window(q, u, v, r, minL, maxL);
-        uint32_t qw[8];
-        const uint32_t* qp = (const uint32_t*)(P.qdesc + (int64_t)q * 32);
+    // Only mode 3 looks at anything but the best free candidate (its ratio test reads the second best whatever its
+    // distance); in the other modes a candidate farther than the acceptance threshold can never be taken, so it is
+    // dropped here -- lists shrink to the plausible matches and so does the contention between queries.
+    const int dMax = c.mode == 3 ? 256 : c.thDist;
+    const bool staged = tot <= c.stageCap;  // else (very wide windows): straight into the arena, unfiltered
+    int base = 0;
+    if (!staged) {
+        if (tid == 0) sBase = atomicAdd(P.total, tot);
+        __syncthreads();
+        base = sBase;
+        const bool fits = base + tot <= P.candCap;  // uniform; the resolve reports the overflow (total > candCap)
+        if (q < nq && lc == 0) { P.candOff[q] = base + qoff; P.candCnt[q] = fits ? qtot : 0; }
+        if (!fits) return;
+    }
+    uint2* list = staged ? stage : P.cand + base;
+    int wrun = off[0];  // wide: lane 0 walks all columns one after the other, positions simply continue
+    my_columns([&](int pi, int ix) {
+        int pos = qoff + wrun;
+        if (!wide) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) qw[i] = qp[i];
-        int pos = b0;
-        lds_area(P.grid, recX, recY, recI, cst, u, v, r, minL, maxL, [&](int t, int oct) {
-            if (!stereo_ok(q, t, r)) return;
-            const int d = orbm::hamming256(qw, (const uint32_t*)(P.tdesc + (int64_t)t * 32));
-            if (!listAll && d > c.thDist) return;
-            // entries stay in the reference's scan order, so "first of equals wins" (strict <) needs no rank
-            const uint32_t e = ((uint32_t)d << 20) | ((uint32_t)(oct & 15) << 16) | (uint32_t)t;
-            if (inLds) candL[pos] = e; else P.cand[pos] = e;
-            pos++;
+            for (int k = 0; k < kCandPasses; k++) if (k == pi) pos = qoff + off[k];
+        }
+        area_column(P.grid, rec, cst, w, ix, u, v, r, minL, maxL, [&](int t, int oct) {
+            if (!stereo_ok(t)) return;
+            list[pos++] = make_uint2(((uint32_t)(oct & 15) << 16) | (uint32_t)t, (uint32_t)q);
         });
+        wrun = pos - qoff;
+    });
+    __syncthreads();
+    for (int k = tid; k < tot; k += kCandThreads) {
+        const uint2 e = list[k];
+        list[k].x = e.x | ((uint32_t)hamming_rows(P.qdesc, e.y, P.tdesc, e.x & 0xFFFF) << 20);
+    }
+    if (!staged) return;
+    __syncthreads();
+    // compaction: each lane takes a quarter of its query's list
+    const int seg = (qtot + kCandLanes - 1) / kCandLanes;
+    const int k0 = qoff + min(lc * seg, qtot), k1 = qoff + min((lc + 1) * seg, qtot);
+    int keep = 0;
+    for (int k = k0; k < k1; k++) keep += (int)(stage[k].x >> 20) <= dMax;
+    int qkeep;
+    const int kofs = quad_scan_excl(keep, lc, &qkeep);
+    int ktot;
+    const int kex = __shfl(wg_scan_excl(lc == 0 ? qkeep : 0, wsum, &ktot), 0, kCandLanes);
+    if (tid == 0) sBase = ktot ? atomicAdd(P.total, ktot) : 0;
+    __syncthreads();
+    base = sBase;
+    const bool fits = base + ktot <= P.candCap;
+    if (q < nq && lc == 0) { P.candOff[q] = base + kex; P.candCnt[q] = fits ? qkeep : 0; }
+    if (!fits) return;
+    int pos = base + kex + kofs;
+    for (int k = k0; k < k1; k++) {
+        const uint2 e = stage[k];
+        if ((int)(e.x >> 20) <= dMax) P.cand[pos++] = e;
+    }
+}
+
+// The sequential part, in parallel rounds (see the head of this file).  One workgroup of 1024 per pair.
+// The rounds are ENTRY-parallel: a flat loop over all candidate entries posts, for every live entry, the query on its
+// train feature (atomicMin) and the entry on its query (atomicMin of distance << 22 | position in the query's list: the
+// first of equal distances in scan order wins, like the reference's strict <); then one step per undecided query
+// reads its best (mode 3: a second flat pass finds the runner-up), checks that nobody lower has posted on it and
+// commits.  A thread-per-query walk of the lists costs every wave its longest list, a chain of dependent LDS reads per
+// entry, in every round; the flat loop keeps all lanes busy and its reads independent.
+// LDS (dynamic): occBy, minUnd[2], winner (4 * tCap dwords) | per query: offset, best, second, result (4 * qCap dwords)
+// | candidates (ldsCand dwords) | their queries (ldsCand halves) | per query: state byte (qCap bytes).
+// L = false: the per-query tables and the lists stay in memory (more queries or candidates than the LDS plan holds).
+constexpr uint8_t kQDecided = 1, kQBlocking = 2;
+
+template <bool L>
+__device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const ProjCommon& c, int nq, int nt, int total,
+                                                   int32_t* occBy, int32_t* minUnd0, int32_t* winner, int32_t* qtab, int* hist,
+                                                   int* sPending, int* sInd, int* sCount)
+{
+    const int tid = threadIdx.x;
+    const bool useRot = c.checkOri && (c.mode == 4 || c.mode == 5);
+    const bool obsRule = c.mode == 3 || c.mode == 4;
+    // Only mode 3 looks at anything but the best free candidate (its ratio test reads the second best whatever its
+    // distance); in the other modes a candidate farther than the acceptance threshold can never be taken: skipped.
+    const int dMax = c.mode == 3 ? 256 : c.thDist;
+    int32_t *qoff, *best1, *best2, *qres;
+    uint32_t* candL = nullptr; uint16_t* ownL = nullptr; uint8_t* qst;
+    if constexpr (L) {
+        qoff = qtab; best1 = qtab + c.qCap; best2 = qtab + 2 * c.qCap; qres = qtab + 3 * c.qCap;
+        candL = (uint32_t*)(qtab + 4 * c.qCap);
+        ownL = (uint16_t*)(candL + c.ldsCand);
+        qst = (uint8_t*)(ownL + c.ldsCand);
+        for (int k = tid; k < total; k += kThreads) { const uint2 e = P.cand[k]; candL[k] = e.x; ownL[k] = (uint16_t)e.y; }
+    } else {
+        qoff = P.candOff; best1 = P.qscr; best2 = P.qscr + nq; qres = P.qres; qst = (uint8_t*)(P.qscr + 2 * nq);
+    }
+    auto entry = [&](int k) -> uint2 { if constexpr (L) return make_uint2(candL[k], ownL[k]); else return P.cand[k]; };
+    for (int q = tid; q < nq; q += kThreads) {
+        const int cnt = nt > 0 ? P.candCnt[q] : 0;
+        if constexpr (L) qoff[q] = P.candOff[q];
+        best1[q] = kFree; best2[q] = kFree; qres[q] = -1;
+        qst[q] = (cnt == 0 ? kQDecided : 0) | ((!obsRule || !P.qobs || P.qobs[q]) ? kQBlocking : 0);
     }
     __syncthreads();
+    ORBT_MARK(1);
 
-    // ---- rounds
     int nAcc = 0, round = 0;
     for (;; round++) {
         int32_t* minUnd = minUnd0 + (round & 1) * c.tCap;
         int32_t* idle = minUnd0 + ((round + 1) & 1) * c.tCap;
-        for (int j = 0, q = tid; q < nq; q += kThreads, j++) {
-            if (decided & (1u << j)) continue;
-            if (obsRule && P.qobs && !P.qobs[q]) continue;  // takes nothing away from anybody
-            for (int k = P.candOff[q], e = P.candOff[q + 1]; k < e; k++) {
-                const uint32_t cd = inLds ? candL[k] : P.cand[k];
-                const int t = (int)(cd & 0xFFFF);
-                if ((int)(cd >> 20) <= c.thDist && occBy[t] >= q) atomicMin(&minUnd[t], q);  // (it can only ever take one within the threshold)
-            }
+        for (int k = tid; k < total; k += kThreads) {
+            const uint2 e = entry(k);
+            const int q = (int)e.y, d = (int)(e.x >> 20), t = (int)(e.x & 0xFFFF);
+            const uint8_t st = qst[q];
+            if ((st & kQDecided) || d > dMax) continue;
+            if (occBy[t] < q) continue;  // taken before this query's turn (or occupied on entry)
+            // a query without observations takes nothing away from anybody; nobody can take what is beyond the threshold
+            if ((st & kQBlocking) && d <= c.thDist) atomicMin(&minUnd[t], q);
+            atomicMin(&best1[q], (d << 22) | (k - qoff[q]));
         }
         if (tid == 0) sPending[(round + 1) % 3] = 0;  // three counters in rotation: the one being read after a round's last barrier is not reset before the round after next
         __syncthreads();
-        int pend = 0;
-        for (int j = 0, q = tid; q < nq; q += kThreads, j++) {
-            if (decided & (1u << j)) continue;
-            int b1 = 256, b2 = 256;
-            uint32_t e1 = 0, e2 = 0;
-            bool has2 = false;
-            for (int k = P.candOff[q], e = P.candOff[q + 1]; k < e; k++) {
-                const uint32_t cd = inLds ? candL[k] : P.cand[k];
-                if (occBy[cd & 0xFFFF] < q) continue;  // taken before this query's turn (or occupied on entry)
-                const int d = (int)(cd >> 20);
-                if (d < b1) { b2 = b1; e2 = e1; has2 = b2 < 256; b1 = d; e1 = cd; }   // ORBmatcher.cc:102-114
-                else if (d < b2) { b2 = d; e2 = cd; has2 = true; }
+        if (c.mode == 3) {  // the runner-up: the best of what is left (ORBmatcher.cc:102-114)
+            for (int k = tid; k < total; k += kThreads) {
+                const uint2 e = entry(k);
+                const int q = (int)e.y, t = (int)(e.x & 0xFFFF);
+                if ((qst[q] & kQDecided) || occBy[t] < q) continue;
+                const int key = ((int)(e.x >> 20) << 22) | (k - qoff[q]);
+                if (key != best1[q]) atomicMin(&best2[q], key);
             }
-            if (b1 > c.thDist || b1 >= 256) { decided |= 1u << j; continue; }  // can only get worse: no match
-            const int t1 = (int)(e1 & 0xFFFF), t2 = (int)(e2 & 0xFFFF);
-            const bool stable = minUnd[t1] >= q && (c.mode != 3 || !has2 || minUnd[t2] >= q);
+            __syncthreads();
+        }
+        int pend = 0;
+        for (int q = tid; q < nq; q += kThreads) {
+            const uint8_t st = qst[q];
+            if (st & kQDecided) continue;
+            const int k1 = best1[q], k2 = best2[q];
+            best1[q] = kFree; best2[q] = kFree;
+            const int b1 = k1 == kFree ? 256 : k1 >> 22;
+            if (b1 > c.thDist || b1 >= 256) { qst[q] = st | kQDecided; continue; }  // can only get worse: no match
+            const uint32_t e1 = entry(qoff[q] + (k1 & 0x3FFFFF)).x;
+            const int t1 = (int)(e1 & 0xFFFF);
+            const bool has2 = c.mode == 3 && k2 != kFree;
+            const uint32_t e2 = has2 ? entry(qoff[q] + (k2 & 0x3FFFFF)).x : 0u;
+            const bool stable = minUnd[t1] >= q && (!has2 || minUnd[e2 & 0xFFFF] >= q);
             if (!stable) { pend++; continue; }
-            decided |= 1u << j;
-            if (c.mode == 3 && has2 && ((e1 >> 16) & 15) == ((e2 >> 16) & 15) &&
-                (float)b1 > __fmul_rn(c.nnratio, (float)b2)) continue;  // ORBmatcher.cc:120-121
+            qst[q] = st | kQDecided;
+            if (has2 && ((e1 >> 16) & 15) == ((e2 >> 16) & 15) &&
+                (float)b1 > __fmul_rn(c.nnratio, (float)(k2 >> 22))) continue;  // ORBmatcher.cc:120-121
             nAcc++;
             atomicMax(&winner[t1], q);
-            if (!obsRule || !P.qobs || P.qobs[q]) occBy[t1] = q;
-            int res = t1;
-            if (useRot) {
-                const int bin = orbm::rot_bin(P.qang ? P.qang[q] : P.qkeys[q].angle, P.tkeys[t1].angle);
-                atomicAdd(&hist[bin], 1);
-                res |= bin << 24;
-            }
-            P.qres[q] = res;
+            if (st & kQBlocking) occBy[t1] = q;
+            qres[q] = t1;
         }
         for (int t = tid; t < nt; t += kThreads) idle[t] = kFree;
         if (pend) atomicAdd(&sPending[round % 3], pend);
         __syncthreads();
         if (sPending[round % 3] == 0) break;
     }
+    ORBT_MARK(2);
 
-    // ---- write back; rotation consistency (ComputeThreeMaxima :1603-1644 + pruning)
-    if (useRot && tid == 0) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < orbm::kHistoLength; i++) {
-            const int s = hist[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
+    // ---- write back; rotation consistency (ComputeThreeMaxima :1603-1644 + pruning).  The bins are computed here, in
+    // one go for all accepted queries: inside the rounds the two angle gathers would add a memory round trip to every round
+    if (useRot) {
+        for (int q = tid; q < nq; q += kThreads) {
+            const int t1 = qres[q];
+            if (t1 < 0) continue;
+            const int bin = orbm::rot_bin(P.qang ? P.qang[q] : P.qkeys[q].angle, P.tkeys[t1].angle);
+            atomicAdd(&hist[bin], 1);
+            best1[q] = bin;  // (the table is free now)
         }
-        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+        __syncthreads();
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < orbm::kHistoLength; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+            sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // every assign entry is written ONCE (it may live in pinned host memory): the pruning goes through the LDS table
     int nPruned = 0;
     if (useRot) {
         for (int q = tid; q < nq; q += kThreads) {
-            const int res = P.qres[q];
-            if (res < 0) continue;
-            const int bin = res >> 24;
-            if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) { winner[res & 0xFFFF] = -2; nPruned++; }
+            const int t1 = qres[q];
+            if (t1 < 0) continue;
+            const int bin = best1[q];
+            if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) { winner[t1] = -2; nPruned++; }
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int t = tid; t < nt; t += kThreads) {
         const int w = winner[t];
         if (w == -2) P.assign[t] = -1;
@@ -446,15 +575,59 @@ __device__ __forceinline__ void proj_body(const ProjPair& P, const ProjCommon& c
     int local = nAcc - nPruned;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
-    if ((tid & 63) == 0 && local) atomicAdd(&sCount, local);
+    if ((tid & 63) == 0 && local) atomicAdd(sCount, local);
     __syncthreads();
-    if (tid == 0) { *P.nmatch = sCount; if (P.stats) { P.stats[0] = round + 1; P.stats[1] = carry; } }
+    if (tid == 0) {
+        if (nq > 0 && nt > 0) *P.total = 0;  // left zero for the next call's candidate kernel
+        *P.nmatch = *sCount;
+        if (P.stats) { P.stats[0] = (nq > 0 && nt > 0) ? round + 1 : 0; P.stats[1] = total; }
+    }
+    ORBT_MARK(3);
 }
 
-__global__ __launch_bounds__(kThreads) void k_proj_fused(const ProjPair* __restrict__ pairs, ProjCommon c)
+__device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjCommon& c)
+{
+    extern __shared__ int32_t tl[];
+    __shared__ int hist[32];
+    __shared__ int sPending[3];
+    __shared__ int sInd[3];
+    __shared__ int sCount;
+    int32_t* occBy = tl;                   // kFree, -1 (occupied on entry) or the blocking query that took the feature
+    int32_t* minUnd0 = occBy + c.tCap;     // two copies, used by alternate rounds (the idle one is cleared meanwhile)
+    int32_t* winner = occBy + 3 * c.tCap;  // last query (in query order) that took the feature in this call
+    int32_t* qtab = occBy + 4 * c.tCap;
+    const int tid = threadIdx.x;
+    const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
+    const int nq = min(P.nqPtr ? *P.nqPtr : P.nq, kMaxQueryIters * kThreads);
+    const int total = (nq > 0 && nt > 0) ? *P.total : 0;
+    ORBT_MARK(0);
+    for (int t = tid; t < nt; t += kThreads) {
+        occBy[t] = (P.toccIn && P.toccIn[t]) ? -1 : kFree;
+        minUnd0[t] = kFree; minUnd0[c.tCap + t] = kFree;
+        winner[t] = -1;
+    }
+    if (tid < 32) hist[tid] = 0;
+    if (tid < 3) sPending[tid] = 0;
+    if (tid == 0) sCount = 0;
+    if (total > P.candCap) {  // nothing was listed past the arena; the caller grows it and calls again
+        __syncthreads();
+        if (tid == 0) { *P.total = 0; *P.nmatch = -total - 1; if (P.stats) { P.stats[0] = 0; P.stats[1] = total; } }
+        return;
+    }
+    if (total <= c.ldsCand && nq <= c.qCap) proj_resolve_rounds<true>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount);
+    else proj_resolve_rounds<false>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount);
+}
+
+__global__ __launch_bounds__(kCandThreads) void k_proj_candidates(const ProjPair* __restrict__ pairs, ProjCommon c)
+{
+    const ProjPair P = pairs[blockIdx.y];
+    proj_candidates_body(P, c, blockIdx.x);
+}
+
+__global__ __launch_bounds__(kThreads) void k_proj_resolve(const ProjPair* __restrict__ pairs, ProjCommon c)
 {
     const ProjPair P = pairs[blockIdx.x];
-    proj_body(P, c);
+    proj_resolve_body(P, c);
 }
 
 // The frame-to-frame search over pairs of a frame set's slots: the pair records are made here from the slot numbers
@@ -465,19 +638,19 @@ struct TrackArgs {
     GridDev grid;
     float th, minX, maxX, minY, maxY;
     uint8_t* occ; int32_t* assign; int32_t* nmatch; int32_t* stats;   // [pair][cap], [pair][cap] (pinned host), [pair], [pair][2]
-    int32_t* candOff; uint32_t* cand; int32_t candCap; int32_t* qres;  // [pair][cap+1], [pair][candCap], [pair][cap]
+    int32_t* total; int32_t* candOff; int32_t* candCnt; uint2* cand; int32_t candCap; int32_t* qres; int32_t* qscr;  // [pair], [pair][cap] x2, [pair][candCap], [pair][cap], [pair][3 cap]
     int32_t pair0;
     int16_t cur[kTrackMaxPairs], last[kTrackMaxPairs];
 };
 
-__global__ __launch_bounds__(kThreads) void k_track_fused(TrackArgs a, ProjCommon c)
+__device__ __forceinline__ ProjPair track_pair(const TrackArgs& a, int b)
 {
-    const int b = blockIdx.x, p = a.pair0 + b;
+    const int p = a.pair0 + b;
     const int64_t C = a.fs.cap;
     const int cs = a.cur[b], ls = a.last[b];
     ProjPair P;
     P.grid = a.grid;
-    P.tkeys = a.fs.keysUn + cs * C; P.cellStart = a.fs.cellStart + (int64_t)cs * (a.fs.ncell + 1); P.cellIdx = a.fs.cellIdx + cs * C;
+    P.tkeys = a.fs.keysUn + cs * C; P.cellStart = a.fs.cellStart + (int64_t)cs * (a.fs.ncell + 1); P.trec = a.fs.rec + cs * C;
     P.tdesc = a.fs.desc + cs * C * 32; P.ntPtr = a.fs.n + cs; P.nt = 0;
     P.quvr = nullptr; P.qlvl = nullptr; P.qdesc = a.fs.desc + ls * C * 32; P.qang = nullptr; P.qvalid = nullptr; P.qobs = nullptr;
     P.qur = nullptr; P.turight = nullptr;
@@ -486,9 +659,22 @@ __global__ __launch_bounds__(kThreads) void k_track_fused(TrackArgs a, ProjCommo
     P.toccIn = nullptr; P.toccOut = a.occ + p * C;
     P.assign = a.assign + p * C; P.initAssign = 1;
     P.nmatch = a.nmatch + p;
-    P.candOff = a.candOff + (int64_t)p * (C + 1); P.cand = a.cand + (int64_t)p * a.candCap; P.candCap = a.candCap;
-    P.qres = a.qres + p * C; P.stats = a.stats + 2 * p;
-    proj_body(P, c);
+    P.total = a.total + p;
+    P.candOff = a.candOff + p * C; P.candCnt = a.candCnt + p * C; P.cand = a.cand + (int64_t)p * a.candCap; P.candCap = a.candCap;
+    P.qres = a.qres + p * C; P.qscr = a.qscr + p * C * 3; P.stats = a.stats + 2 * p;
+    return P;
+}
+
+__global__ __launch_bounds__(kCandThreads) void k_track_candidates(TrackArgs a, ProjCommon c)
+{
+    const ProjPair P = track_pair(a, blockIdx.y);
+    proj_candidates_body(P, c, blockIdx.x);
+}
+
+__global__ __launch_bounds__(kThreads) void k_track_resolve(TrackArgs a, ProjCommon c)
+{
+    const ProjPair P = track_pair(a, blockIdx.x);
+    proj_resolve_body(P, c);
 }
 
 }  // namespace orbt
