@@ -406,6 +406,50 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
     dt = (time.perf_counter() - t0) / reps
     out["cpu_oracle"] = {"ms_per_pair": dt * 1e3, "pairs_per_s": 1.0 / dt, "cores": 1, "kind": "port", "matches": int(wn)}
     out["parity_ok"] = bool(wn == gn and np.array_equal(wa, ga) and int(k[B - 1]) == wn and np.array_equal(a[B - 1, :len(kc)], wa))
+    # ---- TrackReferenceKeyFrame's pair (Tracking.cc:805-812): Frame::ComputeBoW on the new frame, then
+    # SearchByBoW(KeyFrame = the previous frame, Frame), on a synthetic vocabulary of ORBvoc's shape (k = 10, L = 6)
+    try:
+        from orbslamm_amd import ORBVocabulary, synth
+        voc = synth.make_vocabulary(10, 6)
+        G = ORBVocabulary(10, 6, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], device=ex.device)
+        mb = ORBmatcher(0.7, True, device=ex.device)
+        dk, dd, _, rcap = ex.device_results()   # the last extracted batch
+        nk = [len(ex.download(f)[0]) for f in (B - 2, B - 1)]
+        tt, ts_ = [], []
+        F0 = mb.frame_from_device(dk + (B - 2) * rcap * 28, dd + (B - 2) * rcap * 32, nk[0], K, D0, g)
+        mb.frame_compute_bow(F0, G, 4)
+        for _ in range(40):
+            t0 = time.perf_counter()
+            F1 = mb.frame_from_device(dk + (B - 1) * rcap * 28, dd + (B - 1) * rcap * 32, nk[1], K, D0, g)
+            t1 = time.perf_counter()
+            mb.frame_compute_bow(F1, G, 4)
+            t2 = time.perf_counter()
+            gm, gnb = mb.SearchByBoWFrames(F0, None, F1, None, True)
+            t3 = time.perf_counter()
+            tt.append(t2 - t1); ts_.append(t3 - t2)
+            mb.frame_destroy(F1)
+        mb.frame_destroy(F0)
+        O = ob.Vocabulary(10, 6, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+        t0 = time.perf_counter()
+        for _ in range(3):
+            _, fvc = O.transform(dc, 4)
+        t1 = time.perf_counter()
+        _, fvl = O.transform(dl, 4)
+        t2 = time.perf_counter()
+        for _ in range(5):
+            wm, wnb = ob.search_by_bow(dl, kl["angle"], None, fvl, dc, kc["angle"], None, fvc, 0.7, True, True)
+        t3 = time.perf_counter()
+        tt, ts_ = np.array(tt[5:]) * 1e3, np.array(ts_[5:]) * 1e3
+        out["bow"] = {"compute_bow_ms_median": float(np.median(tt)), "compute_bow_ms_mean": float(tt.mean()),
+                      "search_by_bow_ms_median": float(np.median(ts_)), "search_by_bow_ms_mean": float(ts_.mean()), "matches": int(gnb),
+                      "cpu_oracle": {"transform_ms": (t1 - t0) / 3 * 1e3, "search_by_bow_ms": (t3 - t2) / 5 * 1e3, "cores": 1, "kind": "port"},
+                      "parity_ok": bool(gnb == wnb and np.array_equal(gm, wm)),
+                      "what": "orbm_frame_compute_bow (vocabulary descent + BowVector/FeatureVector, BowVector to the host) and orbm_search_by_bow_frames "
+                              "(nnratio 0.7, rotation check) between two device-resident frames, per call; vocabulary: synthetic complete tree k=10, L=6 (1.1 M nodes)"}
+        mb.close()
+        G.close()
+    except Exception as e:  # never lose the record over the secondary block
+        out["bow"] = {"error": repr(e)}
     fs.close()
     m.close()
     return out

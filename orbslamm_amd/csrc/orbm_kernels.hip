@@ -505,6 +505,54 @@ __global__ __launch_bounds__(64) void k_bow_pairs(BowArgs a)
     const int nodeQ = a.pairQ[blockIdx.x], nodeT = a.pairT[blockIdx.x];
     const int qs = a.qstart[nodeQ], qe = a.qstart[nodeQ + 1];
     const int ts = a.tstart[nodeT], te = a.tstart[nodeT + 1];
+    if (qe - qs <= 64 && te - ts <= 64) {
+        // The common case (a vocabulary node holds a few dozen features of a frame): lane l keeps train feature l AND
+        // query l of the node in registers -- descriptor, angle, flags -- so everything is loaded once, up front and
+        // in parallel, and the sequential walk over the queries (:205-211) is register work: the query's descriptor is
+        // broadcast lane to lane, the "already matched" flag lives with the lane that owns the train feature.
+        const bool hasT = lane < te - ts, hasQ = lane < qe - qs;
+        const int t = hasT ? a.tidx[ts + lane] : 0, q = hasQ ? a.qidx[qs + lane] : 0;
+        uint32_t tw[8], qw[8];
+        const uint32_t* tp = (const uint32_t*)(a.tdesc + (int64_t)t * 32);
+        const uint32_t* qp = (const uint32_t*)(a.qdesc + (int64_t)q * 32);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { tw[i] = tp[i]; qw[i] = qp[i]; }
+        const float tang = a.checkOri ? a.tang[t] : 0.f, qang = a.checkOri ? a.qang[q] : 0.f;
+        bool tfree = hasT && !a.matched[t] && !(a.tvalid && !a.tvalid[t]);
+        const bool qok = hasQ && !(a.qvalid && !a.qvalid[q]);
+        for (int iq = 0; iq < qe - qs; iq++) {
+            if (!__shfl((int)qok, iq)) continue;  // wave-uniform
+            int d = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) d += __popc(tw[i] ^ (uint32_t)__shfl((int)qw[i], iq));
+            // key = dist << 22 | scan position (= lane)
+            uint32_t k1 = tfree ? (((uint32_t)d << 22) | (uint32_t)lane) : 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) {
+                const uint32_t o1 = __shfl_xor(k1, dd), o2 = __shfl_xor(k2, dd);
+                top2_merge(k1, k2, o1, o2);
+            }
+            const int best1 = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 22);
+            const int best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 22);
+            if (best1 <= a.thLow && (float)best1 < __fmul_rn(a.nnratio, (float)best2)) {
+                const int win = (int)(k1 & 0x3FFFFFu);
+                const int qi = __shfl(q, iq);
+                const float qa = __shfl(qang, iq);
+                if (lane == win) {
+                    tfree = false;
+                    a.matched[t] = 1;
+                    const int o = a.outByTrain ? t : qi;
+                    a.match[o] = a.outByTrain ? qi : t;
+                    if (a.checkOri) {
+                        const int bin = rot_bin(qa, tang);
+                        a.binOf[o] = (uint8_t)bin;
+                        atomicAdd(&a.hist[bin], 1);
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int iq = qs; iq < qe; iq++) {
         const int q = a.qidx[iq];
         if (a.qvalid && !a.qvalid[q]) continue;  // wave-uniform

@@ -2848,7 +2848,7 @@ static int voc_transform_device(orbv_handle* h, const uint8_t* d_desc, int n, in
 {
     counts[0] = counts[1] = 0;
     if (n > 8192) return fail(ORBX_E_UNSUPPORTED, "more than 8192 descriptors per transform");
-    int P = 1;
+    int P = 2;
     while (P < n) P <<= 1;
     const size_t sizes[] = {(size_t)n * 32, (size_t)n * 4, (size_t)n * 4, (size_t)n * 8, (size_t)n * 4, (size_t)n * 8,
                             (size_t)n * 4, (size_t)(n + 1) * 4, (size_t)n * 4, 16};
@@ -2859,9 +2859,11 @@ static int voc_transform_device(orbv_handle* h, const uint8_t* d_desc, int n, in
     orbv::VocDev v{h->d_childStart, h->d_childIdx, h->d_desc, h->d_wordId, h->d_weight, h->L, h->scoring, h->weighting};
     hipLaunchKernelGGL(orbv::k_voc_descend, dim3((n + 63) / 64), dim3(64), 0, s, v, d_desc, n, levelsup,
                        (uint32_t*)h->d_buf[SV_WORD], (uint32_t*)h->d_buf[SV_NODE], (double*)h->d_buf[SV_W]);
-    const size_t lds = (size_t)P * 12;
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)orbv::k_voc_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(orbv::k_voc_aggregate, dim3(1), dim3(orbv::kAggThreads), lds, s, v, n, P, (const uint32_t*)h->d_buf[SV_WORD],
+    const bool accLds = P <= 4096;
+    const size_t lds = (size_t)P * (accLds ? 20 : 12);
+    auto kern = accLds ? orbv::k_voc_aggregate<true> : orbv::k_voc_aggregate<false>;
+    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(orbv::kAggThreads), lds, s, v, n, P, (const uint32_t*)h->d_buf[SV_WORD],
                        (const uint32_t*)h->d_buf[SV_NODE], (const double*)h->d_buf[SV_W], (uint32_t*)h->d_buf[SV_OW],
                        (double*)h->d_buf[SV_OV], (uint32_t*)h->d_buf[SV_FN], (int32_t*)h->d_buf[SV_FS], (int32_t*)h->d_buf[SV_FI],
                        (int32_t*)h->d_buf[SV_CNT]);

@@ -214,7 +214,7 @@ struct ProjCommon {
     int32_t ldsCand;   // resolve: candidate entries that fit in LDS }
 };
 
-constexpr int kCandThreads = 256;
+constexpr int kCandThreads = 512;
 constexpr int kCandLanes = 4;                            // lanes per query: the grid columns of its window are dealt round-robin
 constexpr int kCandQueries = kCandThreads / kCandLanes;  // queries per workgroup (a "slice")
 constexpr int kCandPasses = 4;                           // columns per lane; a wider window is walked by lane 0 alone

@@ -100,7 +100,8 @@ __device__ __forceinline__ int boundaries_scan(const uint64_t* a, int m, uint32_
     return tot;
 }
 
-// BowVector + FeatureVector of one descriptor set.  P = power of two >= n, LDS: P*8 + P*4 bytes.
+// BowVector + FeatureVector of one descriptor set.  P = power of two >= max(n, 2), LDS: P*8 + P*4 + P*8 bytes.
+template <bool ACC_LDS>  // word values staged in LDS (P <= 4096) or worked on in place in outW
 __global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, int P,
                                                               const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
                                                               const double* __restrict__ w,
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, 
     extern __shared__ uint64_t alds[];
     uint64_t* keys = alds;
     uint32_t* pos = (uint32_t*)(alds + P);
+    double* accL = ACC_LDS ? (double*)(alds + P + P / 2) : outW;   // P >= 2
     __shared__ int wsum[kAggThreads / 64];
     __shared__ int sM;
     const int tid = threadIdx.x;
@@ -133,6 +135,8 @@ __global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, 
     bitonic_sort_lds(keys, P);
     const int m = sM;
     const int nw = boundaries_scan(keys, m, pos, wsum);
+    // the word values stay in LDS until they are final: the normalisation sum below is one thread walking them in
+    // map (word id) order, which from memory cost a load latency per addend (0.19 ms of this kernel's 0.2)
     for (int i = tid; i < m; i += kAggThreads) {
         if (i == 0 || pos[i] != pos[i - 1]) {
             int cnt = 1;
@@ -141,27 +145,35 @@ __global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, 
             double acc = wi;                     // addWeight: += in feature order (BowVector.cpp:34-46)
             if (tf) for (int k = 1; k < cnt; k++) acc += wi;
             outWord[pos[i]] = (uint32_t)(keys[i] >> 32);
-            outW[pos[i]] = acc;
+            accL[pos[i]] = acc;
         }
     }
     __syncthreads();
     if (tf && nw > 0 && !must) {
         const double nd = (double)nw;
-        for (int i = tid; i < nw; i += kAggThreads) outW[i] /= nd;
+        for (int i = tid; i < nw; i += kAggThreads) accL[i] /= nd;
         __syncthreads();
     }
     if (must) {  // BowVector::normalize: the sum runs in map (word id) order, sequentially
         __shared__ double sNorm;
         if (tid == 0) {
             double norm = 0.0;
-            if (!l2) { for (int i = 0; i < nw; i++) norm += fabs(outW[i]); }
-            else { for (int i = 0; i < nw; i++) norm += outW[i] * outW[i]; norm = sqrt(norm); }
+            if (!l2) {
+#pragma unroll 8
+                for (int i = 0; i < nw; i++) norm += fabs(accL[i]);
+            } else {
+#pragma unroll 8
+                for (int i = 0; i < nw; i++) norm += accL[i] * accL[i];
+                norm = sqrt(norm);
+            }
             sNorm = norm;
         }
         __syncthreads();
         const double norm = sNorm;
-        if (norm > 0.0) for (int i = tid; i < nw; i += kAggThreads) outW[i] /= norm;
+        if (norm > 0.0) for (int i = tid; i < nw; i += kAggThreads) accL[i] /= norm;
+        __syncthreads();
     }
+    if (ACC_LDS) for (int i = tid; i < nw; i += kAggThreads) outW[i] = accL[i];
     __syncthreads();
 
     // ---- FeatureVector: sort (node, feature); addFeature appends in feature order (:1159)

@@ -46,3 +46,30 @@ def frame_from_scene(canvas, w, h, t, stream=0):
 def make_frames(w, h, nframes, stream=0, t0=0):
     canvas = make_scene(w, h, stream)
     return np.stack([frame_from_scene(canvas, w, h, t0 + t, stream) for t in range(nframes)])
+
+
+def make_vocabulary(k, L, seed=7):
+    """A complete k-ary vocabulary tree of depth L in DBoW2's loadFromTextFile order (breadth first; the real ORBvoc.txt
+    -- k = 10, L = 6 -- is absent from the reference checkout): children are their parent's descriptor with a few bits
+    flipped.  Returns dict(parent, is_leaf, desc, weight, k, L) for ORBVocabulary / the oracle's Vocabulary."""
+    rng = np.random.default_rng(seed)
+    parent, desc, is_leaf = [], [], []
+    prev_ids = np.array([0])
+    prev_desc = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    next_id = 1
+    for lvl in range(1, L + 1):
+        n = len(prev_ids) * k
+        d = np.repeat(prev_desc, k, axis=0)
+        nflip = max(4, 60 >> (lvl - 1))
+        bits = rng.integers(0, 256, (n, nflip))
+        for j in range(nflip):
+            np.bitwise_xor.at(d, (np.arange(n), bits[:, j] >> 3), (1 << (bits[:, j] & 7)).astype(np.uint8))
+        parent.append(np.repeat(prev_ids, k))
+        desc.append(d)
+        is_leaf.append(np.full(n, lvl == L, np.uint8))
+        prev_ids = np.arange(next_id, next_id + n)
+        prev_desc = d
+        next_id += n
+    w = rng.uniform(0.1, 9.0, next_id - 1)
+    return dict(parent=np.concatenate(parent).astype(np.int32), is_leaf=np.concatenate(is_leaf), desc=np.concatenate(desc),
+                weight=w, k=k, L=L)
