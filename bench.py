@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--pool", type=int, default=16, help="distinct batches of stream frames resident in HBM, cycled by the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the (untimed) host-buffer entry measurements")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of two frames of the last timed step")
     ap.add_argument("--no-tracking-path", action="store_true", help="skip the (untimed) Tracking-shaped matcher measurements")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--no-replay", action="store_true", help="skip the untimed serialized replay (roofline.isolated); used under rocprofv3 so that its per-kernel averages are those of the timed launches")
@@ -455,6 +456,50 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
     return out
 
 
+def pin_to_gpu_numa(dev_index):
+    """Pin this rank to the cores of its GPU's NUMA node (os.sched_setaffinity): the HBM-resident headline does not
+    care, the host-fed entries on a two-socket box do (staging copies and pinned buffers on the far socket cross the
+    inter-socket link).  Returns what was done, for the record."""
+    if os.environ.get("ORBX_BENCH_EXTRACTOR") or os.environ.get("ORBX_BENCH_NO_PIN") == "1":
+        return {"pinned": False, "why": "disabled"}
+    from orbslamm_amd import _lib
+    node, cpus = _lib.numa_cpus_of_device(dev_index)
+    if not cpus:
+        return {"pinned": False, "why": "the platform names no NUMA node for the device"}
+    try:
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return {"pinned": False, "numa_node": node, "why": "none of the node's cores is in this process's cpuset"}
+        os.sched_setaffinity(0, allowed)
+        return {"pinned": True, "numa_node": node, "cores": len(allowed)}
+    except OSError as e:
+        return {"pinned": False, "numa_node": node, "why": repr(e)}
+
+
+def parity_check(ex, cfg, host_frames, frames_idx):
+    """`metric` says "bit-exact kp/desc vs CPU": checked here, in this very process, on frames of the LAST timed step --
+    keypoints (28-byte records), descriptors and the match table of each checked frame against the CPU oracle run on the
+    same input bytes.  host_frames[i] = the step's frame i on the host."""
+    import numpy as np
+    from oracle import binding as ob
+    oex = ob.Extractor(cfg["nfeat"], 1.2, 8, 20, 7)
+    ref = {}
+    for f in sorted(set(frames_idx) | {i - 1 for i in frames_idx}):
+        ref[f] = oex(host_frames[f])
+    bad = []
+    for f in frames_idx:
+        kps, desc = ex.download(f)
+        m, nm = ex.download_matches(f)
+        r, rp = ref[f], ref[f - 1]
+        wm, wn = ob.match_bruteforce(r["desc"], r["kps"]["angle"], rp["desc"], rp["kps"]["angle"], 0.7, 50, True)
+        ok = (len(kps) == len(r["kps"]) and kps.tobytes() == r["kps"].tobytes() and desc.tobytes() == r["desc"].tobytes()
+              and nm == wn and np.array_equal(m[:len(wm)], wm))
+        if not ok:
+            bad.append(int(f))
+    return {"frames": len(frames_idx), "ok": not bad, "mismatching_frames": bad, "checked": [int(f) for f in frames_idx],
+            "what": "keypoints, descriptors and match table of these frames of the last timed step, byte for byte against the CPU oracle on the same input"}
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     import numpy as np
@@ -494,6 +539,7 @@ def run_rank(args):
     B = args.batch
     stream_id = streams.stream_of_rank(rank)[0]  # this rank's camera stream
     pool = max(1, args.pool)
+    pin = pin_to_gpu_numa(dev_index) if distributed else {"pinned": False, "why": "single process: left to the caller's cpuset"}
     ex = make_extractor(cfg, B, dev_index)
     canvas = synth.make_scene(W, H, stream_id)
     dargs = []
@@ -576,7 +622,21 @@ def run_rank(args):
     # match statistics of the last frame; RCCL all_gather over xGMI (not on the data path)
     _, nmatch_last = ex.download_matches(B - 1)
     kps_last, _ = ex.download(B - 1)
-    gathered, dt_max = streams.gather_stats((B * args.steps, len(kps_last), nmatch_last, dt), world, device)
+    real = not os.environ.get("ORBX_BENCH_EXTRACTOR")
+    par = None
+    if real and not args.no_parity_check and B >= 3:
+        p_last = (args.warmup + args.steps - 1) % pool   # the batch the last timed step extracted
+        hf = {f: synth.frame_from_scene(canvas, W, H, p_last * B + f, stream_id) for f in (B - 3, B - 2, B - 1)}
+        par = parity_check(ex, cfg, hf, [B - 2, B - 1])
+        if not par["ok"]:
+            sys.stderr.write("bench.py: rank %d: frames %s of the last step differ from the CPU oracle\n" % (rank, par["mismatching_frames"]))
+    hp = None
+    if real and not args.no_host_path and hasattr(ex, "extract_match_host") and (world == 1 or distributed):
+        hp = host_path(ex, cfg, first_batch)
+    gathered, dt_max = streams.gather_stats((B * args.steps, len(kps_last), nmatch_last, dt,
+                                             -1.0 if par is None else float(par["ok"]),
+                                             0.0 if hp is None else hp.get("pipelined_fps", 0.0),
+                                             0.0 if hp is None else hp.get("b1_ms_median", 0.0)), world, device)
 
     # serialized replay (untimed): the same steps with every kernel alone on the GPU, to tell
     # kernel cost from overlap.  `value` above is NOT affected by it.
@@ -671,8 +731,16 @@ def run_rank(args):
         elif prof:
             out["roofline"] = roofline_of(prof, DOMINANT, steps_bracketed)  # --no-replay: the kernel named by the isolated runs so far
             out["roofline"]["overlapped_streams"] = True
-        if world == 1 and not args.no_host_path and hasattr(ex, "extract_match_host"):
-            out["host_path"] = host_path(ex, cfg, first_batch)
+        if hp is not None:
+            out["host_path"] = hp
+            if world > 1:  # every rank fed its own GPU at the same time, pinned to its NUMA node
+                out["host_path"]["per_rank_pipelined_fps"] = [g[5] for g in gathered]
+                out["host_path"]["per_rank_b1_ms_median"] = [g[6] for g in gathered]
+        out["numa"] = pin
+        if par is not None:
+            out["parity_check"] = par
+            if world > 1:
+                out["parity_check"]["per_rank_ok"] = [bool(g[4] > 0) for g in gathered]
         if world == 1 and not args.no_tracking_path and hasattr(ex, "extract_match_host"):
             out["tracking_path"] = tracking_path(ex, cfg, first_batch, dargs)
         if world == 1 and not args.no_cpu_baseline:
@@ -684,6 +752,8 @@ def run_rank(args):
             sys.stdout.write(line)
             sys.stdout.flush()
     streams.finalize(world)
+    if par is not None and not par["ok"]:
+        return 4  # the metric promises bit-exact results
     return 0
 
 

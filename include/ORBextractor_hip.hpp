@@ -41,17 +41,28 @@ struct PyramidLevel {
 
 // std::vector<cv::Mat> mvImagePyramid (ORBextractor.h:85) as a member that fills itself on first use after each
 // operator() call: the pyramid lives in HBM and only the stereo path ever reads it on the host, so the eight images
-// are not copied back per frame.  mvImagePyramid[l], .size(), and iteration work as on the vector.
+// are not copied back per frame.  mvImagePyramid[l] and .size() work as on the vector; with OpenCV an element IS a
+// cv::Mat (a header over the framed buffer, no copy), so the reference's only reader compiles unchanged:
+//   mpORBextractorLeft->mvImagePyramid[kpL.octave].rowRange(...).colRange(...)   and   ....cols   (Frame.cc:561,573,578)
 class LazyPyramid {
 public:
+#ifdef ORBSLAMM_WITH_OPENCV
+    typedef cv::Mat Level;
+#else
+    typedef PyramidLevel Level;
+#endif
     explicit LazyPyramid(ORBextractor* owner) : owner_(owner) {}
     size_t size() const;
-    PyramidLevel& operator[](size_t level);
+    Level& operator[](size_t level);
+    PyramidLevel& framed(size_t level);   // the level inside its 19 px frame, whatever Level is
     void invalidate() { valid_ = false; }
 private:
     void fill();
     ORBextractor* owner_;
     std::vector<PyramidLevel> levels_;
+#ifdef ORBSLAMM_WITH_OPENCV
+    std::vector<cv::Mat> mats_;
+#endif
     bool valid_ = false;
 };
 
@@ -146,10 +157,19 @@ protected:
 };
 
 inline size_t LazyPyramid::size() const { return (size_t)orbx_levels(owner_->handle()); }
-inline PyramidLevel& LazyPyramid::operator[](size_t level)
+inline PyramidLevel& LazyPyramid::framed(size_t level)
 {
     if (!valid_) fill();
     return levels_.at(level);
+}
+inline LazyPyramid::Level& LazyPyramid::operator[](size_t level)
+{
+    if (!valid_) fill();
+#ifdef ORBSLAMM_WITH_OPENCV
+    return mats_.at(level);
+#else
+    return levels_.at(level);
+#endif
 }
 inline void LazyPyramid::fill()
 {
@@ -174,6 +194,10 @@ inline void LazyPyramid::fill()
             for (int x = 1; x <= E; x++) { dst[-x] = src[refl(-x, w)]; dst[w - 1 + x] = src[refl(w - 1 + x, w)]; }
         }
     }
+#ifdef ORBSLAMM_WITH_OPENCV
+    mats_.clear();
+    for (PyramidLevel& P : levels_) mats_.push_back(P.mat());
+#endif
     valid_ = true;
 }
 

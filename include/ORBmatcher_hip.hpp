@@ -337,12 +337,24 @@ public:
     // second pass of SearchBySim3 (KF2's points into KF1)
     FlatCall last2;
 
-    // static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)   ORBmatcher.h:45
+    // static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)   ORBmatcher.h:45, ORBmatcher.cc:1649-1665
+    // ONE pair: eight xor + popcount on the host.  The reference calls this per pair from loops the device entries
+    // replace wholesale (MapPoint::ComputeDistinctiveDescriptors -> orbm_distinctive_descriptors, Frame::
+    // ComputeStereoMatches -> orbx_compute_stereo_matches); a caller that keeps such a loop must not pay two copies, a
+    // launch and a sync per pair, nor depend on which device some other thread's handle lives on.  (It is the
+    // reference's own arithmetic on 8 native-endian 32-bit words, no third-party code involved.)
     template <class Mat> static int DescriptorDistance(const Mat& a, const Mat& b)
     {
-        static thread_local std::unique_ptr<FlatMatcher> m;  // the reference's member is static: no instance to hang a handle on
-        if (!m) m.reset(new FlatMatcher());
-        return m->DescriptorDistance(a.template ptr<unsigned char>(0), b.template ptr<unsigned char>(0));
+        const unsigned char* pa = a.template ptr<unsigned char>(0);
+        const unsigned char* pb = b.template ptr<unsigned char>(0);
+        int dist = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t x, y;
+            std::memcpy(&x, pa + 4 * i, 4);
+            std::memcpy(&y, pb + 4 * i, 4);
+            dist += __builtin_popcount(x ^ y);
+        }
+        return dist;
     }
 
     // ---------------------------------------------------------------- SearchByProjection(Frame&, vector<MapPoint*>&, th)  :45-129

@@ -37,6 +37,9 @@ enum {
 const char* orbx_last_error(void);
 /* number of visible HIP devices (0 when none); never fails */
 int orbx_device_count(void);
+/* PCI bus id of a HIP device ("0000:c1:00.0", cap >= 16): /sys/bus/pci/devices/<id>/numa_node names the NUMA node whose
+ * cores and memory sit next to it (a rank that feeds host frames should be pinned there) */
+int orbx_device_pci_bus_id(int device, char* out, int cap);
 
 /* ---------------------------------------------------------------- extractor
  * replaces class ORBextractor (include/ORBextractor.h:45-111). */

@@ -113,7 +113,7 @@ int orc_compute_stereo_matches(const OrcKeyPoint* keysL, const uint8_t* descL, i
             float bestuR = mvScaleFactors[kpL->octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
             float disparity = (uL - bestuR);
             if (disparity >= 0 && disparity < maxD) {
-                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); } /* ref:611: `uL-0.01` is computed in double */
                 mvDepth[iL] = mbf / disparity;
                 mvuRight[iL] = bestuR;
                 vDistIdx[nDist].dist = bestSad; vDistIdx[nDist].idx = iL; nDist++;

@@ -58,7 +58,7 @@ class OrbmProjParams(C.Structure):
 
 # every symbol include/orbslamm_hip.h declares (tests check that all of them resolve)
 EXPORTS = [
-    "orbx_last_error", "orbx_device_count", "orbx_create", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
+    "orbx_last_error", "orbx_device_count", "orbx_device_pci_bus_id", "orbx_create", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
     "orbx_scale_tables", "orbx_features_per_level", "orbx_umax", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch", "orbx_submit_batch", "orbx_collect_view", "orbx_release", "orbx_collect_batch", "orbx_extract_match_batch",
     "orbx_host_alloc_frames", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_device_results", "orbx_download",
@@ -143,3 +143,22 @@ def check(rc):
 
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def numa_cpus_of_device(device):
+    """(numa node, cpu ids) next to a HIP device, from sysfs; (None, None) where the platform does not say"""
+    buf = C.create_string_buffer(32)
+    try:
+        if lib().orbx_device_pci_bus_id(int(device), buf, 32) != 0:
+            return None, None
+        bus = buf.value.decode().lower()
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        if node < 0:
+            return None, None
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        return node, cpus
+    except (OSError, ValueError):
+        return None, None

@@ -81,6 +81,26 @@ extern "C" int orbx_device_count(void)
     return n;
 }
 
+// PCI bus id ("0000:c1:00.0") of a device: lets a launcher pin a rank to the GPU's NUMA node (bench.py)
+extern "C" int orbx_device_pci_bus_id(int device, char* out, int cap)
+{
+    if (!out || cap < 16) return fail(ORBX_E_INVALID, "bad argument");
+    HIPCHK(hipDeviceGetPCIBusId(out, cap, device));
+    return ORBX_OK;
+}
+
+// spin-wait hint of the latency path's poll
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 static inline int cv_round(double v) { return (int)lrint(v); }  // cvRound: half to even
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -265,7 +285,8 @@ struct orbx_handle {
     int32_t* d_cellCount = nullptr;      // [maxB][cellsCap] survivors per FAST cell
     uint64_t* d_kept = nullptr; size_t keptCapFrame = 0;
     int32_t* d_keptCount = nullptr;
-    int32_t* d_err = nullptr;
+    int32_t* d_err = nullptr;            // [0] error flags of device-resident calls, [1] block counter of k_pack_host, [2] scratch word, [4 + slot] error flags of the host-fed batch in that slot
+    int32_t* d_errCur = nullptr;         // where the kernels launched right now report (a host-fed batch: its slot's word, consumed and cleared by its own k_pack_host)
     int maxKp = 0;                       // output slot capacity (fixed at create)
     OrbxKeyPointDev* d_kps = nullptr;    // [maxB+1][maxKp]  slot 0 = previous frame of the stream
     uint8_t* d_desc = nullptr;           // [maxB+1][maxKp][32]
@@ -720,7 +741,7 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     CRT(hipMalloc(&h->d_cellCount, B * h->cellsCap * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_kept, h->keptCapFrame * B * sizeof(uint64_t)));
     CRT(hipMalloc(&h->d_keptCount, B * ORBX_MAXL * sizeof(int32_t)));
-    CRT(hipMalloc(&h->d_err, 4 * sizeof(int32_t)));  // [0] error flags, [1] block counter of k_pack_host, [2] scratch word (stream warm-up)
+    CRT(hipMalloc(&h->d_err, 8 * sizeof(int32_t)));
     CRT(hipMalloc(&h->d_kps, 2 * (B + 1) * h->maxKp * sizeof(OrbxKeyPointDev)));
     CRT(hipMalloc(&h->d_desc, 2 * (B + 1) * (size_t)h->maxKp * 32));
     CRT(hipMalloc(&h->d_count, 2 * (B + 1) * sizeof(int32_t)));
@@ -733,7 +754,8 @@ extern "C" int orbx_create(const OrbxParams* params, int max_w, int max_h, int m
     h->xPitch = (int64_t)align_up(h->maxKp, orbm::kMfmaRowsPerBlock) * 256;
     CRT(hipMalloc(&h->d_xdesc, 2 * (B + 1) * (size_t)h->xPitch));
     CRT(hipMemset(h->d_xdesc, 0, 2 * (B + 1) * (size_t)h->xPitch));
-    CRT(hipMemset(h->d_err, 0, 4 * sizeof(int32_t)));
+    CRT(hipMemset(h->d_err, 0, 8 * sizeof(int32_t)));
+    h->d_errCur = h->d_err;
     CRT(hipMemset(h->d_count, 0, 2 * (B + 1) * sizeof(int32_t)));
     CRT(hipMemset(h->d_hist, 0, B * 32 * sizeof(int32_t)));
     CRT(hipMemset(h->d_nmatch, 0, 2 * B * sizeof(int32_t)));
@@ -902,10 +924,10 @@ struct Launcher {
         h->prof.begin(P_FAST, fs);
         if (h->tileStrideDw == 12)
             hipLaunchKernelGGL(k_fast<48>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
-                               h->d_cellCount, h->d_err, rows, cap, nb, cell0);
+                               h->d_cellCount, h->d_errCur, rows, cap, nb, cell0);
         else
             hipLaunchKernelGGL(k_fast<80>, dim3(ncells, xcd_grid_y(nb)), dim3(64), lds, fs, h->d_geom, h->d_cells, src, h->d_candRaw,
-                               h->d_cellCount, h->d_err, rows, cap, nb, cell0);
+                               h->d_cellCount, h->d_errCur, rows, cap, nb, cell0);
         h->prof.end(fs);
     }
     void dist(hipStream_t ds, int l0, int nl) const  // quadtree of levels [l0, l0 + nl)
@@ -917,11 +939,11 @@ struct Launcher {
         if (h->distInLds)
             hipLaunchKernelGGL(k_distribute<true>, dim3(nl, nb), dim3(kDistThreads), dl, ds, h->d_geom, h->d_candRaw,
                                h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept, h->d_keptCount,
-                               h->d_err, h->nodeCap, src.f0, (uint32_t*)nullptr, 0, l0);
+                               h->d_errCur, h->nodeCap, src.f0, (uint32_t*)nullptr, 0, l0);
         else
             hipLaunchKernelGGL(k_distribute<false>, dim3(nl, nb), dim3(kDistThreads), 0, ds, h->d_geom, h->d_candRaw,
                                h->d_candA, h->d_candB, h->d_cells, h->d_cellCount, h->d_candCount, h->d_kept, h->d_keptCount,
-                               h->d_err, h->nodeCap, src.f0, h->d_distScratch + (size_t)src.f0 * g.nlevels * (dl / 4), (int)(dl / 4), l0);
+                               h->d_errCur, h->nodeCap, src.f0, h->d_distScratch + (size_t)src.f0 * g.nlevels * (dl / 4), (int)(dl / 4), l0);
         h->prof.end(ds);
     }
     // done != nullptr: the event rides on the kernel's own dispatch packet (hipExtLaunchKernelGGL) -- a separate
@@ -1244,7 +1266,8 @@ static int ensure_slots(orbx_handle* h)
     }
     for (auto& sl : h->slot) {
         HIPCHK(hipHostMalloc(&sl.h_in, h->imgFrameBytes * B));
-        HIPCHK(hipHostMalloc(&sl.h_out, h->outBytes));
+        // polled by the host while the kernel that fills it is still running: explicitly coherent (fine-grained), whatever HIP_HOST_COHERENT says
+        HIPCHK(hipHostMalloc(&sl.h_out, h->outBytes, hipHostMallocCoherent));
         HIPCHK(hipMalloc(&sl.d_in, h->imgFrameBytes * B));
         for (hipEvent_t& e : sl.evUp) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.evOut, hipEventDisableTiming));
@@ -1332,11 +1355,12 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
     bool behind = false;  // another ticket is in flight: this batch's copies must not share a hardware queue with kernels
     for (const HostSlot& o : h->slot) behind |= o.state == 1;
     hipStream_t up = lat ? h->streamP[0] : (behind ? h->streamUpQ : h->streamUp);  // latency mode: the stream of the pyramid, the chain's first kernel
-    h->prof.begin(P_H2D, up);
     const bool pinned = is_pinned(imgs[0]);
     bool contiguous = true;  // frames back to back at a constant pitch of whole rows
     for (int f = 1; f < B && contiguous; f++) contiguous = imgs[f] == imgs[0] + (size_t)f * stride * hh;
-    if (pinned) for (int f = 1; f < B; f++) if (!is_pinned(imgs[f])) return fail(ORBX_E_INVALID, "frame %d is pageable, frame 0 pinned: one kind per batch", f);
+    for (int f = 1; f < B; f++)
+        if (is_pinned(imgs[f]) != pinned) return fail(ORBX_E_INVALID, "frame %d is %s, frame 0 %s: one kind per batch", f, pinned ? "pageable" : "pinned", pinned ? "pinned" : "pageable");
+    h->prof.begin(P_H2D, up);
     // Throughput mode uploads the batch in the parts run_extract cuts it into (same frame ranges), an event behind each:
     // sub-batch 0's kernels start when its half is there, and for pageable frames the staging of part p + 1 (host
     // threads) runs beside the DMA of part p.  Latency mode: one part, no event (the frames ride on the kernels' stream).
@@ -1371,7 +1395,13 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
     }
     h->prof.end(up);
 
-    if ((rc = run_extract(h, sl.d_in, B, w, hh, dstride, dpitch, lat ? nullptr : sl.evUp, lat ? up : nullptr))) return rc;
+    // this batch's kernels report scratch overflows in the slot's own word; its k_pack_host hands the word to the host
+    // and clears it (one sticky word for all batches would report an overflow of ticket n for n+1 and n+2 as well)
+    int32_t* const errWord = h->d_err + 4 + h->nextTicket % orbx_handle::kSlots;
+    h->d_errCur = errWord;
+    rc = run_extract(h, sl.d_in, B, w, hh, dstride, dpitch, lat ? nullptr : sl.evUp, lat ? up : nullptr);
+    h->d_errCur = h->d_err;
+    if (rc) return rc;
     const bool match = opts && opts->match_prev;
     const int set = h->curSet;
     int32_t* const dm = h->d_match + (size_t)set * h->maxB * h->maxKp;
@@ -1384,7 +1414,7 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
         if (match && (rc = match_prev_on(h, ps, opts->nnratio, opts->th_low, opts->check_ori, false))) return rc;
         PackArgs pa;
         pa.kps = (const uint32_t*)(r_kps(h, set) + h->maxKp); pa.desc = (const uint32_t*)(r_desc(h, set) + (size_t)h->maxKp * 32);
-        pa.count = r_count(h, set) + 1; pa.match = match ? dm : nullptr; pa.nmatch = match ? dnm : nullptr; pa.err = h->d_err;
+        pa.count = r_count(h, set) + 1; pa.match = match ? dm : nullptr; pa.nmatch = match ? dnm : nullptr; pa.err = errWord;
         pa.hKps = (uint32_t*)(sl.h_out + h->outOffKp); pa.hDesc = (uint32_t*)(sl.h_out + h->outOffDesc);
         pa.hN = (int32_t*)(sl.h_out + h->outOffN); pa.hMatch = (int32_t*)(sl.h_out + h->outOffMatch);
         pa.hNmatch = (int32_t*)(sl.h_out + h->outOffNm); pa.hErr = (int32_t*)sl.h_out; pa.maxKp = h->maxKp;
@@ -1407,7 +1437,7 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
         // consecutive copies: 0.55 ms per 64-frame batch, as long as the upload.  No flag here: the consumer waits for evOut.)
         PackArgs pa;
         pa.kps = (const uint32_t*)(r_kps(h, set) + h->maxKp); pa.desc = (const uint32_t*)(r_desc(h, set) + (size_t)h->maxKp * 32);
-        pa.count = r_count(h, set) + 1; pa.match = match ? dm : nullptr; pa.nmatch = match ? dnm : nullptr; pa.err = h->d_err;
+        pa.count = r_count(h, set) + 1; pa.match = match ? dm : nullptr; pa.nmatch = match ? dnm : nullptr; pa.err = errWord;
         pa.hKps = (uint32_t*)(sl.h_out + h->outOffKp); pa.hDesc = (uint32_t*)(sl.h_out + h->outOffDesc);
         pa.hN = (int32_t*)(sl.h_out + h->outOffN); pa.hMatch = (int32_t*)(sl.h_out + h->outOffMatch);
         pa.hNmatch = (int32_t*)(sl.h_out + h->outOffNm); pa.hErr = (int32_t*)sl.h_out; pa.maxKp = h->maxKp;
@@ -1448,7 +1478,7 @@ extern "C" int orbx_collect_view(orbx_t* h, int ticket, OrbxBatchView* view)
         // the pack kernel's last block writes ticket + 1 behind the results (system-scope release): polling the pinned
         // word saves the wake-up of an event wait on the one-frame-per-call path
         volatile int32_t* flag = (volatile int32_t*)sl->h_out + 1;
-        for (int spin = 0; spin < 400000 && !landed; spin++) { landed = *flag == ticket + 1; if (!landed) __builtin_ia32_pause(); }
+        for (int spin = 0; spin < 400000 && !landed; spin++) { landed = *flag == ticket + 1; if (!landed) cpu_relax(); }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     if (!landed) HIPCHK(hipEventSynchronize(sl->evOut));
@@ -1460,10 +1490,7 @@ extern "C" int orbx_collect_view(orbx_t* h, int ticket, OrbxBatchView* view)
     view->desc = sl->h_out + h->outOffDesc;
     view->match = sl->matched ? (const int32_t*)(sl->h_out + h->outOffMatch) : nullptr;
     view->nmatch = sl->matched ? (const int32_t*)(sl->h_out + h->outOffNm) : nullptr;
-    if (err) {
-        (void)hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->streamDown);
-        return fail(ORBX_E_CAPACITY, "device scratch overflow (flags 0x%x)", err);
-    }
+    if (err) return fail(ORBX_E_CAPACITY, "device scratch overflow (flags 0x%x)", err);  // (the pack kernel cleared the slot's word)
     return ORBX_OK;
 }
 
@@ -1490,11 +1517,11 @@ extern "C" int orbx_collect_batch(orbx_t* h, int ticket, OrbxKeyPoint* kps, uint
         if (nmatch) nmatch[f] = v.nmatch ? v.nmatch[f] : 0;
         if (v.n[f] > cap) over = 1;
     }
-    if (!over) {
+    {   // frames that fit are copied also when another one does not (E_CAPACITY below names the call, not every frame)
         const int mk = h->maxKp;
         h->pool.run(v.B, [=](int f) {
             const size_t n = (size_t)v.n[f];
-            if (!n) return;
+            if (!n || n > (size_t)cap) return;
             if (kps) memcpy(kps + (size_t)f * cap, v.kps + (size_t)f * mk, n * sizeof(OrbxKeyPoint));
             if (desc) memcpy(desc + (size_t)f * cap * 32, v.desc + (size_t)f * mk * 32, n * 32);
             if (match && v.match) memcpy(match + (size_t)f * cap, v.match + (size_t)f * mk, n * 4);

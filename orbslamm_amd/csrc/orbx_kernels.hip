@@ -1801,7 +1801,7 @@ __global__ __launch_bounds__(256) void k_roll_prev(const uint32_t* __restrict__ 
 // caller-visible pinned host buffer (device writes over PCIe) -- one launch instead of six copies of ~18 us each.
 struct PackArgs {
     const uint32_t* kps; const uint32_t* desc; const int32_t* count;   // first frame of the batch (slot 1 of the set)
-    const int32_t* match; const int32_t* nmatch; const int32_t* err;   // match / nmatch may be null
+    const int32_t* match; const int32_t* nmatch; int32_t* err;   // match / nmatch may be null; err: the batch's error word (read and cleared)
     uint32_t* hKps; uint32_t* hDesc; int32_t* hN; int32_t* hMatch; int32_t* hNmatch; int32_t* hErr;
     int32_t* hFlag; int32_t flagValue; int32_t* blocksDone;  // the last block to finish raises the host flag
     int maxKp;
@@ -1829,7 +1829,7 @@ __global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
     if (t == 0) {
         a.hN[f] = n;
         if (a.nmatch) a.hNmatch[f] = a.nmatch[f];
-        if (f == 0) *a.hErr = *a.err;
+        if (f == 0 && blockIdx.x == 0) *a.hErr = atomicExch(a.err, 0);  // the batch's own word: handed over and cleared
     }
     // Without a flag the consumer waits for the kernel's completion event, and the end of the kernel publishes: no
     // system-scope fence, no arrival count.
@@ -1958,7 +1958,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
                     float bestuR = __fmul_rn(a.sf[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestincR), deltaR));
                     float disparity = __fsub_rn(uL, bestuR);
                     if (disparity >= 0 && disparity < maxD) {
-                        if (disparity <= 0) { disparity = 0.01f; bestuR = __fsub_rn(uL, 0.01f); }
+                        if (disparity <= 0) { disparity = 0.01f; bestuR = (float)__dsub_rn((double)uL, 0.01); }  // Frame.cc:611: uL - 0.01 is a double subtraction
                         outD = __fdiv_rn(a.mbf, disparity);
                         outU = bestuR;
                         outSad = bestSad;

@@ -51,7 +51,7 @@ def make_frames(w, h, nframes, stream=0, t0=0):
 def make_vocabulary(k, L, seed=7):
     """A complete k-ary vocabulary tree of depth L in DBoW2's loadFromTextFile order (breadth first; the real ORBvoc.txt
     -- k = 10, L = 6 -- is absent from the reference checkout): children are their parent's descriptor with a few bits
-    flipped.  Returns dict(parent, is_leaf, desc, weight, k, L) for ORBVocabulary / the oracle's Vocabulary."""
+    flipped.  Returns dict(parent, is_leaf, desc, weight, k, L) in the layout orbv_create takes."""
     rng = np.random.default_rng(seed)
     parent, desc, is_leaf = [], [], []
     prev_ids = np.array([0])

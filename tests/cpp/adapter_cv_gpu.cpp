@@ -42,9 +42,18 @@ int main()
     EXPECT(mpORBextractorLeft->GetLevels() == 8 && mpORBextractorLeft->GetScaleFactor() == 1.2f);
     EXPECT(mpORBextractorLeft->GetScaleFactors().size() == 8 && mpORBextractorLeft->GetInverseScaleSigmaSquares().size() == 8);
     // mvImagePyramid[l] as a cv::Mat header over the 19 px framed buffer (Frame.cc:561,578 index it with negative offsets)
-    iORB_SLAM::PyramidLevel& P = mpORBextractorLeft->mvImagePyramid[1];
-    cv::Mat lvl = P.mat();
+    iORB_SLAM::PyramidLevel& P = mpORBextractorLeft->mvImagePyramid.framed(1);
+    cv::Mat& lvl = mpORBextractorLeft->mvImagePyramid[1];   // an element is a cv::Mat, as in std::vector<cv::Mat>
     EXPECT(lvl.cols == P.cols && lvl.rows == P.rows && lvl.data == P.data && lvl.data[-19 * (long)lvl.step - 19] == lvl.data[19 * (long)lvl.step + 19]);
+    {   // the reference's reader, verbatim in shape (Frame.cc:561, :573): a window around a keypoint near the image corner
+        const int w = 5;
+        const float scaledvL = 3.f, scaleduL = 2.f;   // the window reaches into the 19 px frame, like the reference's can
+        cv::Mat IL = mpORBextractorLeft->mvImagePyramid[1].rowRange(scaledvL - w, scaledvL + w + 1).colRange(scaleduL - w, scaleduL + w + 1);
+        EXPECT(IL.rows == 2 * w + 1 && IL.cols == 2 * w + 1 && IL.step == lvl.step);
+        EXPECT(IL.data == lvl.data + (ptrdiff_t)(3 - w) * (ptrdiff_t)lvl.step + (2 - w));
+        EXPECT(IL.data[0] == lvl.data[(ptrdiff_t)(w - 3) * (ptrdiff_t)lvl.step + (w - 2)]);   // BORDER_REFLECT_101: pixel (-3, -2) mirrors (3, 2)
+        EXPECT(mpORBextractorLeft->mvImagePyramid[1].cols == P.cols);
+    }
 
     // an empty image leaves the outputs untouched (:1046-1047)
     std::vector<cv::KeyPoint> keep = mvKeys;

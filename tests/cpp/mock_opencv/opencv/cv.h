@@ -31,6 +31,9 @@ public:
     }
     void release() { rows = cols = 0; step = 0; data = nullptr; own_.reset(); }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    // sub-matrix headers over the same memory (what Frame::ComputeStereoMatches asks of a pyramid level, Frame.cc:561,578)
+    Mat rowRange(int a, int b) const { Mat m(*this); m.data = data + (ptrdiff_t)a * (ptrdiff_t)step; m.rows = b - a; return m; }
+    Mat colRange(int a, int b) const { Mat m(*this); m.data = data + a; m.cols = b - a; return m; }
     int type() const { return CV_8UC1; }
 private:
     std::shared_ptr<std::vector<unsigned char> > own_;
