@@ -1,0 +1,3 @@
+// test infrastructure: see ../../opencv/cv.h
+#pragma once
+#include <opencv/cv.h>

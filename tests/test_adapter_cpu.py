@@ -56,3 +56,22 @@ def test_extractor_dropin_reference_signature_compiles(tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib"])
     syms = subprocess.check_output(["nm", "-C", exe]).decode()
     assert "iORB_SLAM::ORBextractor::operator()(cv::_InputArray const&, cv::_InputArray const&, std::vector<cv::KeyPoint" in syms
+
+
+def test_check_vs_opencv_compiles(tmp_path):
+    """tools/check_vs_opencv/check_vs_opencv.cpp -- the program that pins the oracle against a real OpenCV + the
+    reference's unmodified ORBextractor.cc wherever OpenCV exists -- at least parses and type-checks here: against
+    declaration-only cv:: headers (tests/cpp/mock_opencv) and, when the reference checkout is present, its own
+    include/ORBextractor.h.  Nothing is built or run (there is no OpenCV in this image); the exporter of the frames it
+    reads is run for real."""
+    import pytest
+    ref_inc = "/root/reference/SingleRobotScenario/include"
+    if not os.path.exists(os.path.join(ref_inc, "ORBextractor.h")):
+        pytest.skip("no reference checkout: the program includes the reference's own header")
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "tests", "cpp", "mock_opencv"), "-I", ref_inc,
+                           "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools", "check_vs_opencv", "check_vs_opencv.cpp")])
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "check_vs_opencv", "export_pgm.py"), str(tmp_path / "frames")])
+    names = os.listdir(tmp_path / "frames")
+    assert len(names) == 19 and all(n.endswith(".pgm") for n in names)
+    head = open(tmp_path / "frames" / "synth_1241x376_0.pgm", "rb").read(16)
+    assert head.startswith(b"P5\n1241 376\n255\n")
