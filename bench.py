@@ -413,23 +413,31 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
         from orbslamm_amd import ORBVocabulary, synth
         voc = synth.make_vocabulary(10, 6)
         G = ORBVocabulary(10, 6, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], device=ex.device)
-        mb = ORBmatcher(0.7, True, device=ex.device)
-        dk, dd, _, rcap = ex.device_results()   # the last extracted batch
-        nk = [len(ex.download(f)[0]) for f in (B - 2, B - 1)]
-        tt, ts_ = [], []
-        F0 = mb.frame_from_device(dk + (B - 2) * rcap * 28, dd + (B - 2) * rcap * 32, nk[0], K, D0, g)
-        mb.frame_compute_bow(F0, G, 4)
-        for _ in range(40):
+        # the frame set still holds the last batch in slots base .. base + B - 1 (search-only loop above: n = 199 -> odd half)
+        base = (199 & 1) * B
+        fs.compute_bow(G, base, B, 4)
+        fs.sync()
+        # b1: per frame, ComputeBoW of the new frame + SearchByBoW against the previous one, table on the host
+        tt = []
+        for i in range(60):
             t0 = time.perf_counter()
-            F1 = mb.frame_from_device(dk + (B - 1) * rcap * 28, dd + (B - 1) * rcap * 32, nk[1], K, D0, g)
-            t1 = time.perf_counter()
-            mb.frame_compute_bow(F1, G, 4)
-            t2 = time.perf_counter()
-            gm, gnb = mb.SearchByBoWFrames(F0, None, F1, None, True)
-            t3 = time.perf_counter()
-            tt.append(t2 - t1); ts_.append(t3 - t2)
-            mb.frame_destroy(F1)
-        mb.frame_destroy(F0)
+            fs.compute_bow(G, base + B - 1, 1, 4)
+            fs.search_by_bow([base + B - 2], [base + B - 1], 0.7, True)
+            gm, gnb = fs.bow_results()
+            tt.append(time.perf_counter() - t0)
+        gm, gnb = gm[0].copy(), int(gnb[0])
+        tt = np.array(tt[5:]) * 1e3
+        # batched: B frames per step
+        kfs = np.arange(base, base + B - 1)
+        curs = kfs + 1
+        for _ in range(3):
+            fs.compute_bow(G, base, B, 4); fs.search_by_bow(kfs, curs, 0.7, True)
+        fs.bow_results()
+        reps, t0 = 100, time.perf_counter()
+        for _ in range(reps):
+            fs.compute_bow(G, base, B, 4); fs.search_by_bow(kfs, curs, 0.7, True)
+        fs.bow_results()
+        dtb = (time.perf_counter() - t0) / reps
         O = ob.Vocabulary(10, 6, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
         t0 = time.perf_counter()
         for _ in range(3):
@@ -440,14 +448,13 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
         for _ in range(5):
             wm, wnb = ob.search_by_bow(dl, kl["angle"], None, fvl, dc, kc["angle"], None, fvc, 0.7, True, True)
         t3 = time.perf_counter()
-        tt, ts_ = np.array(tt[5:]) * 1e3, np.array(ts_[5:]) * 1e3
-        out["bow"] = {"compute_bow_ms_median": float(np.median(tt)), "compute_bow_ms_mean": float(tt.mean()),
-                      "search_by_bow_ms_median": float(np.median(ts_)), "search_by_bow_ms_mean": float(ts_.mean()), "matches": int(gnb),
+        out["bow"] = {"b1_ms_median": float(np.median(tt)), "b1_ms_mean": float(tt.mean()), "matches": gnb,
+                      "batched_frames_per_s": B / dtb, "batched_ms_per_step": dtb * 1e3, "batch": B,
                       "cpu_oracle": {"transform_ms": (t1 - t0) / 3 * 1e3, "search_by_bow_ms": (t3 - t2) / 5 * 1e3, "cores": 1, "kind": "port"},
-                      "parity_ok": bool(gnb == wnb and np.array_equal(gm, wm)),
-                      "what": "orbm_frame_compute_bow (vocabulary descent + BowVector/FeatureVector, BowVector to the host) and orbm_search_by_bow_frames "
-                              "(nnratio 0.7, rotation check) between two device-resident frames, per call; vocabulary: synthetic complete tree k=10, L=6 (1.1 M nodes)"}
-        mb.close()
+                      "parity_ok": bool(gnb == wnb and np.array_equal(gm[:len(kc)], wm)),
+                      "what": "orbm_frameset_compute_bow (vocabulary descent + BowVector/FeatureVector, all in HBM) + orbm_bow_frames (SearchByBoW(KeyFrame = previous "
+                              "frame, Frame), nnratio 0.7, rotation check) + orbm_bow_results (table in pinned host memory); b1 = one frame per call, batched = B frames "
+                              "and B - 1 pairs per step; vocabulary: synthetic complete tree k=10, L=6 (1.1 M nodes)"}
         G.close()
     except Exception as e:  # never lose the record over the secondary block
         out["bow"] = {"error": repr(e)}
@@ -724,6 +731,18 @@ def run_rank(args):
             out["roofline"]["pipeline_bytes_per_frame"] = bytes_frame
             out["roofline"]["pipeline_achieved_GBs"] = fps / world * bytes_frame / 1e9
             out["roofline"]["pipeline_frac"] = fps / world * bytes_frame / 1e9 / HBM_PEAK_GBS
+            # The one GEMM-shaped kernel gets the matrix-core yardstick: v_mfma_i32_32x32x32_i8 issued per step
+            # (query workgroups of 256 x 4 waves x train tiles of 32 x 16 MFMAs per tile and wave) x 65 536 ops each,
+            # over its time, against the dense int8 peak of the guide (>= 3944 TOPS).  An HBM fraction says nothing about it.
+            nkp = float(np.mean([g[1] for g in gathered]))
+            mfmas = B * int(np.ceil(nkp / 256.0)) * 4 * int(np.ceil(nkp / 32.0)) * 16
+            mm = {"kernel": "k_match_mfma", "bound": "mfma", "peak": 3944.0, "unit": "TOP/s", "mfma_per_step": mfmas, "ops_per_step": mfmas * 65536.0,
+                  "what": "exact +-1 int8 product = 256 - 2 Hamming; 2 x 32 x 32 x 32 ops per v_mfma_i32_32x32x32_i8"}
+            for tag, kms in (("isolated", iso["kernel_ms_per_step"]), ("overlapped", out["roofline"].get("kernel_ms_per_step_all_bracketed", {}))):
+                if kms.get("k_match_mfma"):
+                    a = mfmas * 65536.0 / (kms["k_match_mfma"] * 1e-3) / 1e12
+                    mm[tag] = {"ms_per_step": kms["k_match_mfma"], "achieved": a, "frac": a / 3944.0}
+            out["roofline"]["mfma"] = mm
             if sq_tab and args.config == "c3":
                 cyc, clk = sq_tab["cycles_per_valu_instr"], sq_tab["clock_ghz"] * 1e9
                 tot = sum(v["valu"] for v in sq_tab["kernels"].values()) * B / sq_tab["frames_per_step"]

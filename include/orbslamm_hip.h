@@ -442,6 +442,20 @@ int orbm_frame_compute_bow(orbm_frame_t* f, orbv_t* voc, int levelsup, uint32_t*
 int orbm_search_by_bow_frames(orbm_t* h, orbm_frame_t* q, const uint8_t* qvalid, orbm_frame_t* t, const uint8_t* tvalid,
                               float nnratio, int check_ori, int out_by_train, int32_t* match, int* nmatches);
 
+/* ---- the BoW side of the Tracking-shaped path on a frame set (round 3) ----
+ * orbm_frameset_compute_bow: void Frame::ComputeBoW() (src/Frame.cc:394-402: mpORBvocabulary->transform(vCurrentDesc, mBowVec,
+ *   mFeatVec, 4)) for slots (slot0 + i) % slots, i < n, in two launches; asynchronous.  FeatureVectors stay in HBM;
+ *   orbm_frameset_bow_vector hands one slot's mBowVec to the host (word id ascending, value).
+ * orbm_bow_frames: int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
+ *   src/ORBmatcher.cc:159-290 as Tracking::TrackReferenceKeyFrame calls it (src/Tracking.cc:805-812), for npairs
+ *   (KeyFrame slot, Frame slot) pairs in two launches; every KeyFrame feature counts as holding a good MapPoint.
+ *   Asynchronous.  orbm_bow_results as orbm_track_results: match[p*cap + t] = KeyFrame feature matched to Frame feature
+ *   t or -1, nmatches[p], in pinned host memory (two result sets in alternation). */
+int orbm_frameset_compute_bow(orbm_frameset_t* fs, orbv_t* voc, int slot0, int n, int levelsup);
+int orbm_frameset_bow_vector(orbm_frameset_t* fs, int slot, uint32_t* word_id, double* word_value, int cap, int* n_words);
+int orbm_bow_frames(orbm_frameset_t* fs, const int32_t* kf_slots, const int32_t* frame_slots, int npairs, float nnratio, int check_ori);
+int orbm_bow_results(orbm_frameset_t* fs, int back, const int32_t** match, const int32_t** nmatches, int* npairs, int* cap);
+
 /* orbm_window_best with a device-resident frame as train side (the KeyFrame of Fuse / Fuse(Scw) / SearchBySim3; mono) */
 int orbm_window_best_frame(orbm_t* h, const float* q_uvr, const int8_t* q_pred, const uint8_t* qdesc, const uint8_t* qvalid, int nq,
                            orbm_frame_t* train, const float* inv_sigma2, int nlevels, int chi2,

@@ -71,6 +71,7 @@ EXPORTS = [
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_transform",
     "orbm_last_search_stats", "orbm_frameset_create", "orbm_frameset_destroy", "orbm_frameset_build", "orbm_frameset_build_from_extractor",
     "orbm_frameset_sync", "orbm_frameset_download", "orbm_track_frames", "orbm_track_results", "orbm_track_stats",
+    "orbm_frameset_compute_bow", "orbm_frameset_bow_vector", "orbm_bow_frames", "orbm_bow_results",
 ]
 
 

@@ -499,10 +499,9 @@ __device__ __forceinline__ void top2_merge(uint32_t& k1, uint32_t& k2, uint32_t 
     k1 = lo;
 }
 
-__global__ __launch_bounds__(64) void k_bow_pairs(BowArgs a)
+__device__ __forceinline__ void bow_pair_body(const BowArgs& a, int nodeQ, int nodeT)
 {
     const int lane = threadIdx.x;
-    const int nodeQ = a.pairQ[blockIdx.x], nodeT = a.pairT[blockIdx.x];
     const int qs = a.qstart[nodeQ], qe = a.qstart[nodeQ + 1];
     const int ts = a.tstart[nodeT], te = a.tstart[nodeT + 1];
     if (qe - qs <= 64 && te - ts <= 64) {
@@ -592,6 +591,90 @@ __global__ __launch_bounds__(64) void k_bow_pairs(BowArgs a)
         }
         __syncthreads();  // matched[] visible to the whole wave before the next query
     }
+}
+
+__global__ __launch_bounds__(64) void k_bow_pairs(BowArgs a)
+{
+    bow_pair_body(a, a.pairQ[blockIdx.x], a.pairT[blockIdx.x]);
+}
+
+// SearchByBoW(KeyFrame = slot kf[p], Frame = slot fr[p]) for pairs of a frame set's slots, one launch: workgroup (b, p)
+// takes vocabulary node b of the KeyFrame's FeatureVector and looks its id up in the Frame's (the lock-step walk of the
+// two sorted maps, ORBmatcher.cc:180-266, as a binary search), so no node list visits the host.
+constexpr int kBowMaxPairs = 128;
+struct BowSetArgs {
+    const uint8_t* desc; const float* ang; const int32_t* n; int32_t cap;       // frame set: slot s at + s * cap (desc: * 32)
+    const uint32_t* fvNode; const int32_t* fvStart; const int32_t* fvIdx; const int32_t* counts;  // fvStart: + s * (cap + 1), counts: + 2 s + 1 = nodes
+    uint8_t* matched; int32_t* match; uint8_t* binOf; int32_t* hist;             // per pair p: + p * cap (hist: + p * 32); zero / -1 / - / zero on entry
+    float nnratio; int32_t thLow, checkOri;
+    int16_t kf[kBowMaxPairs], fr[kBowMaxPairs];
+};
+
+__global__ __launch_bounds__(64) void k_bow_set(BowSetArgs s)
+{
+    const int p = blockIdx.y, qs = s.kf[p], ts = s.fr[p];
+    const int nQ = s.counts[2 * qs + 1], nT = s.counts[2 * ts + 1];
+    const int nodeQ = blockIdx.x;
+    if (nodeQ >= nQ) return;
+    const int64_t C = s.cap;
+    const uint32_t id = s.fvNode[qs * C + nodeQ];
+    const uint32_t* tn = s.fvNode + ts * C;
+    int lo = 0, hi = nT;   // first train node with id >= ours (DBoW2's lower_bound, :255-263)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tn[mid] < id) lo = mid + 1; else hi = mid; }
+    if (lo >= nT || tn[lo] != id) return;
+    BowArgs a;
+    a.qdesc = s.desc + qs * C * 32; a.qang = s.ang + qs * C; a.qvalid = nullptr;
+    a.tdesc = s.desc + ts * C * 32; a.tang = s.ang + ts * C; a.tvalid = nullptr;
+    a.qstart = s.fvStart + (int64_t)qs * (C + 1); a.qidx = s.fvIdx + qs * C;
+    a.tstart = s.fvStart + (int64_t)ts * (C + 1); a.tidx = s.fvIdx + ts * C;
+    a.pairQ = nullptr; a.pairT = nullptr;
+    a.matched = s.matched + p * C; a.match = s.match + p * C; a.binOf = s.binOf + p * C; a.hist = s.hist + p * 32;
+    a.nnratio = s.nnratio; a.thLow = s.thLow; a.checkOri = s.checkOri; a.outByTrain = 1;
+    bow_pair_body(a, nodeQ, lo);
+}
+
+// three maxima + pruning of every pair's match table (k_prune_flat's rule), final table and count to `outMatch` / `outN`
+// (pinned host memory: every entry is written once)
+__global__ __launch_bounds__(256) void k_bow_prune_set(BowSetArgs s, int32_t* __restrict__ outMatch, int32_t* __restrict__ outN)
+{
+    __shared__ int sh[32];
+    __shared__ int sInd[3];
+    __shared__ int sCnt;
+    const int tid = threadIdx.x, p = blockIdx.x;
+    const int64_t C = s.cap;
+    const int n = min(s.n[s.fr[p]], s.cap);
+    int32_t* hist = s.hist + p * 32;
+    if (tid < 32) sh[tid] = hist[tid];
+    if (tid == 0) sCnt = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < kHistoLength; i++) {
+            const int v = sh[i];
+            if (v > max1) { max3 = max2; max2 = max1; max1 = v; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (v > max2) { max3 = max2; max2 = v; ind3 = ind2; ind2 = i; }
+            else if (v > max3) { max3 = v; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+    }
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < n; i += 256) {
+        int m = s.match[p * C + i];
+        if (m >= 0 && s.checkOri) {
+            const int bin = s.binOf[p * C + i];
+            if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) m = -1;
+        }
+        outMatch[p * C + i] = m;
+        local += m >= 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if ((tid & 63) == 0) atomicAdd(&sCnt, local);
+    __syncthreads();
+    if (tid == 0) outN[p] = sCnt;
 }
 
 // three maxima + pruning over a flat match array (same rule as k_match_prune), one workgroup

@@ -2762,6 +2762,7 @@ struct orbv_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     int k = 0, L = 0, scoring = 0, weighting = 0, nNodes = 0, nWords = 0;
+    std::vector<int> nodesAtLevel;   // [0 .. deepest]: how many nodes the tree has at each depth (root = 0)
     int32_t* d_childStart = nullptr; int32_t* d_childIdx = nullptr; uint8_t* d_desc = nullptr;
     int32_t* d_wordId = nullptr; double* d_weight = nullptr;
     void* d_buf[10] = {nullptr}; size_t d_cap[10] = {0};
@@ -2825,6 +2826,15 @@ extern "C" int orbv_create(int device, int k, int L, int scoring, int weighting,
         if ((childStart[i + 1] == childStart[i]) != (wordId[i] >= 0)) return fail(ORBX_E_INVALID, "node %d: leaf flag and children disagree", i);
     orbv_handle* h = new orbv_handle();
     h->device = device; h->k = k; h->L = L; h->scoring = scoring; h->weighting = weighting; h->nNodes = nNodes; h->nWords = nWords;
+    {
+        std::vector<int> depth(nNodes, 0);
+        h->nodesAtLevel.assign(1, 1);
+        for (int i = 0; i < n; i++) {
+            const int dpt = depth[i + 1] = depth[parent[i]] + 1;
+            if ((int)h->nodesAtLevel.size() <= dpt) h->nodesAtLevel.resize(dpt + 1, 0);
+            h->nodesAtLevel[dpt]++;
+        }
+    }
 #define VCRT(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { int r_ = fail(ORBX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); orbv_destroy(h); return r_; } } while (0)
     VCRT(hipSetDevice(device));
     VCRT(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -2982,3 +2992,5 @@ extern "C" int orbm_search_by_bow_frames(orbm_t* h, orbm_frame_t* q, const uint8
     const BowSide ts = {t->d_desc, t->d_ang, t->d_fvStart, t->d_fvIdx, t->fvNode.data(), t->fvNodes, t->n};
     return bow_core(h, qs, qvalid, ts, tvalid, nnratio, check_ori, out_by_train, match, nmatches);
 }
+
+#include "orbt_bow_host.inc"

@@ -102,12 +102,12 @@ __device__ __forceinline__ int boundaries_scan(const uint64_t* a, int m, uint32_
 
 // BowVector + FeatureVector of one descriptor set.  P = power of two >= max(n, 2), LDS: P*8 + P*4 + P*8 bytes.
 template <bool ACC_LDS>  // word values staged in LDS (P <= 4096) or worked on in place in outW
-__global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, int P,
-                                                              const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
-                                                              const double* __restrict__ w,
-                                                              uint32_t* __restrict__ outWord, double* __restrict__ outW,
-                                                              uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
-                                                              int32_t* __restrict__ fvIdx, int32_t* __restrict__ counts)
+__device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P,
+                                                   const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
+                                                   const double* __restrict__ w,
+                                                   uint32_t* __restrict__ outWord, double* __restrict__ outW,
+                                                   uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
+                                                   int32_t* __restrict__ fvIdx, int32_t* __restrict__ counts)
 {
     extern __shared__ uint64_t alds[];
     uint64_t* keys = alds;
@@ -187,6 +187,71 @@ __global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, 
         if (i == 0 || pos[i] != pos[i - 1]) { fvNode[pos[i]] = (uint32_t)(keys[i] >> 32); fvStart[pos[i]] = i; }
     }
     if (tid == 0) { fvStart[nf] = m; counts[0] = nw; counts[1] = nf; }
+}
+
+template <bool ACC_LDS>
+__global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, int P,
+                                                              const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
+                                                              const double* __restrict__ w,
+                                                              uint32_t* __restrict__ outWord, double* __restrict__ outW,
+                                                              uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
+                                                              int32_t* __restrict__ fvIdx, int32_t* __restrict__ counts)
+{
+    voc_aggregate_body<ACC_LDS>(v, n, P, word, node, w, outWord, outW, fvNode, fvStart, fvIdx, counts);
+}
+
+// ---- Frame::ComputeBoW for the frames of a frame set, one launch each: slot s of every array at + s * cap (fvStart:
+// + s * (cap + 1), counts: + 2 s); the feature count is read on the device
+struct VocSetArgs {
+    const uint8_t* desc; const int32_t* n; int32_t cap, slot0, slotMod, P;
+    uint32_t* word; uint32_t* node; double* w;                    // scratch of the descent
+    uint32_t* outWord; double* outW;                              // BowVector
+    uint32_t* fvNode; int32_t* fvStart; int32_t* fvIdx; int32_t* counts;  // FeatureVector as CSR, counts = {words, nodes}
+};
+
+__global__ void k_voc_descend_set(VocDev v, VocSetArgs a, int levelsup)
+{
+    const int slot = (a.slot0 + blockIdx.y) % a.slotMod;
+    const int n = min(a.n[slot], a.cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = (int64_t)slot * a.cap;
+    uint32_t q[8];
+    const uint32_t* qp = (const uint32_t*)(a.desc + (o + i) * 32);
+#pragma unroll
+    for (int k = 0; k < 8; k++) q[k] = qp[k];
+    const int nidLevel = v.L - levelsup;
+    uint32_t nid = 0;
+    int finalId = 0, level = 0;
+    do {  // as k_voc_descend
+        ++level;
+        const int cs = v.childStart[finalId], ce = v.childStart[finalId + 1];
+        finalId = v.childIdx[cs];
+        int best = ham256(q, (const uint32_t*)(v.desc + (int64_t)finalId * 32));
+        for (int c = cs + 1; c < ce; c++) {
+            const int id = v.childIdx[c];
+            const int d = ham256(q, (const uint32_t*)(v.desc + (int64_t)id * 32));
+            if (d < best) { best = d; finalId = id; }
+        }
+        if (level == nidLevel) nid = (uint32_t)finalId;
+    } while (v.childStart[finalId + 1] > v.childStart[finalId]);
+    a.word[o + i] = (uint32_t)v.wordId[finalId];
+    a.node[o + i] = nid;
+    a.w[o + i] = v.weight[finalId];
+}
+
+template <bool ACC_LDS>
+__global__ __launch_bounds__(kAggThreads) void k_voc_aggregate_set(VocDev v, VocSetArgs a)
+{
+    const int slot = (a.slot0 + blockIdx.x) % a.slotMod;
+    const int n = min(a.n[slot], a.cap);
+    const int64_t o = (int64_t)slot * a.cap;
+    if (n == 0 || v.L == 0) {
+        if (threadIdx.x == 0) { a.counts[2 * slot] = 0; a.counts[2 * slot + 1] = 0; a.fvStart[(int64_t)slot * (a.cap + 1)] = 0; }
+        return;
+    }
+    voc_aggregate_body<ACC_LDS>(v, n, a.P, a.word + o, a.node + o, a.w + o, a.outWord + o, a.outW + o, a.fvNode + o,
+                                a.fvStart + (int64_t)slot * (a.cap + 1), a.fvIdx + o, a.counts + 2 * slot);
 }
 
 }  // namespace orbv

@@ -376,6 +376,30 @@ class FrameSet:
         check(self._L.orbm_track_stats(self._h, int(pair), C.byref(r), C.byref(c)))
         return r.value, c.value
 
+    # ---- BoW side: Frame::ComputeBoW per slot, SearchByBoW(KeyFrame, Frame) per slot pair
+    def compute_bow(self, voc, slot0, n, levelsup=4):
+        check(self._L.orbm_frameset_compute_bow(self._h, voc._h, int(slot0), int(n), int(levelsup)))
+
+    def bow_vector(self, slot):
+        wid = np.zeros(self.cap, np.uint32)
+        wv = np.zeros(self.cap, np.float64)
+        n = C.c_int(0)
+        check(self._L.orbm_frameset_bow_vector(self._h, int(slot), ptr(wid), ptr(wv), self.cap, C.byref(n)))
+        return wid[:n.value].copy(), wv[:n.value].copy()
+
+    def search_by_bow(self, kf_slots, frame_slots, nnratio=0.7, check_ori=True):
+        ks = np.ascontiguousarray(kf_slots, dtype=np.int32)
+        fs = np.ascontiguousarray(frame_slots, dtype=np.int32)
+        check(self._L.orbm_bow_frames(self._h, ptr(ks), ptr(fs), ks.shape[0], C.c_float(nnratio), int(bool(check_ori))))
+
+    def bow_results(self, back=0):
+        a, n, cap, npairs = C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_int(0)
+        check(self._L.orbm_bow_results(self._h, int(back), C.byref(a), C.byref(n), C.byref(npairs), C.byref(cap)))
+        if npairs.value == 0:
+            return np.zeros((0, self.cap), np.int32), np.zeros(0, np.int32)
+        return (np.ctypeslib.as_array(C.cast(a, C.POINTER(C.c_int32)), shape=(npairs.value, cap.value)),
+                np.ctypeslib.as_array(C.cast(n, C.POINTER(C.c_int32)), shape=(npairs.value,)))
+
 
 def descriptors_to_text(desc):
     """MapSerializer's descriptor attribute (src/MapSerializer.cc:344-347, 429-431): `os << cv::Mat` of a CV_8U matrix"""

@@ -169,3 +169,50 @@ def test_frame_set_and_batched_tracking_search(gpu, oracle, w, h, nf, K, D):
     a1, n1 = fs.results()
     assert n1[0] == n2[0] and np.array_equal(a1[0, :len(host[3][0])], a2[0, :len(host[3][0])])
     fs.close(); fs2.close()
+
+
+def test_frame_set_bow_and_batched_search_by_bow(gpu, oracle):
+    """Frame::ComputeBoW for a batch of slots and SearchByBoW(KeyFrame, Frame) for a batch of slot pairs, all in HBM:
+    BowVectors (ids and float64 values, bit for bit), and every match table, against the oracle fed with the downloads"""
+    from orbslamm_amd import ORBextractor, ORBmatcher, ORBVocabulary, make_grid, synth
+    from vocab_cases import make_vocab
+    w, h, nf, B = 640, 480, 1000, 5
+    rng = np.random.default_rng(17)
+    for (k, L, levelsup), voc in (((10, 4, 2), make_vocab(rng, 10, 4)), ((9, 3, 4), make_vocab(rng, 9, 3, ragged=False))):
+        G = ORBVocabulary(k, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], device=0)
+        O = oracle.Vocabulary(k, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+        fr = synth.make_frames(w, h, B, stream=9)
+        gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=0)
+        gex.extract_batch_device(*gex.upload_frames(fr))
+        host = [gex.download(f) for f in range(B)]
+        m = ORBmatcher(0.7, True, device=0)
+        g = make_grid(0.0, 0.0, float(w), float(h))
+        fs = m.frame_set(B + 2, gex.max_keypoints, TUM_K, [0, 0, 0, 0, 0], g, [0.0, float(w), 0.0, float(h)], np.array(gex.GetScaleFactors(), np.float32))
+        fs.build_from_extractor(1, gex)            # frames 0..B-1 -> slots 1..B
+        fs.compute_bow(G, 1, B, levelsup)
+        fvs = []
+        for f in range(B):
+            keys, desc = host[f]
+            (owid, owval), ofv = O.transform(desc, levelsup)
+            wid, wval = fs.bow_vector(1 + f)
+            assert np.array_equal(wid, owid) and wval.tobytes() == owval.tobytes()
+            fvs.append(ofv)
+        kf = np.array([1, 2, 3, 4, 1])        # KeyFrame slots (the last pair: two frames apart)
+        cur = np.array([2, 3, 4, 5, 3])
+        for ratio, ori in ((0.7, True), (0.9, False)):
+            fs.search_by_bow(kf, cur, nnratio=ratio, check_ori=ori)
+            match, nm = fs.bow_results()
+            total = 0
+            for p in range(len(kf)):
+                (kq, dq), (kt, dt) = host[kf[p] - 1], host[cur[p] - 1]
+                want, wn = oracle.search_by_bow(dq, kq["angle"], None, fvs[kf[p] - 1], dt, kt["angle"], None, fvs[cur[p] - 1], ratio, ori, True)
+                assert nm[p] == wn, (p, nm[p], wn)
+                assert np.array_equal(match[p, :len(kt)], want)
+                total += wn
+            assert total > 100
+        # an empty slot (never built) has no words and matches nothing
+        fs.compute_bow(G, 0, 1, levelsup)
+        assert len(fs.bow_vector(0)[0]) == 0
+        fs.search_by_bow([0], [1], 0.7, True)
+        assert fs.bow_results()[1][0] == 0
+        fs.close(); m.close(); G.close()
