@@ -277,6 +277,23 @@ def host_path(ex, cfg, frames, seconds=1.5):
         dt = time.perf_counter() - t0
         out.update(pipelined_fps=n / dt, pipelined_what="orbx_submit_batch / orbx_collect_view + orbx_release, depth 3, B=%d pageable host frames per ticket, results in the pinned host buffer" % B,
                    pcie_gbs=n / dt * (W * H + 0.0) / 1e9)
+        # results straight into caller-owned pinned arrays (orbx_submit_batch_into / orbx_collect): what a drop-in with
+        # containers of its own does -- no second pass on the host
+        if hasattr(ex, "submit_host_into"):
+            outs = [ex.alloc_pinned_results(B) for _ in range(3)]
+            ex.reset_stream()
+            n = 0
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                tickets.append(ex.submit_host_into(batch, outs[(n // B) % 3]))
+                if len(tickets) > 2:
+                    ex.collect_into(tickets.pop(0))
+                n += B
+            while tickets:
+                ex.collect_into(tickets.pop(0))
+            dt = time.perf_counter() - t0
+            out.update(pipelined_into_fps=n / dt, pipelined_into_what="orbx_submit_batch_into / orbx_collect, depth 3, B=%d pageable host frames per ticket, "
+                       "keypoints + descriptors + match tables written by the device straight into the caller's own pinned arrays" % B)
         # the same from pinned frames in the device layout (orbx_host_alloc_frames), results read in place (orbx_collect_view)
         if hasattr(ex, "alloc_pinned_frames"):
             pins = [ex.alloc_pinned_frames(B, W, H) for _ in range(3)]

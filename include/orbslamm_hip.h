@@ -135,6 +135,22 @@ int orbx_collect_batch(orbx_t* h, int ticket, OrbxKeyPoint* kps, uint8_t* desc, 
 int orbx_extract_match_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int h_, int stride,
                              const OrbxStreamOpts* opts, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n_out,
                              int32_t* match, int* nmatch);
+/* Results straight into the CALLER'S containers, no second pass on the host: the result kernel writes exactly n records
+ * per frame into kps[B*cap], desc[B*cap*32], n[B] (and match[B*cap], nmatch[B] with match_prev) over the link.  The
+ * arrays must be memory the device can address: from orbx_host_alloc, or registered once with orbx_host_register
+ * (a std::vector<cv::KeyPoint>'s storage can be registered after reserve()).  A frame with more than cap keypoints
+ * gets its first cap written, n[] holds the true count, orbx_collect returns ORBX_E_CAPACITY.  orbx_collect waits for
+ * the ticket and releases it. */
+typedef struct {
+    OrbxKeyPoint* kps; uint8_t* desc; int32_t* n;
+    int32_t* match; int32_t* nmatch;   /* may be NULL without match_prev */
+    int32_t cap;
+} OrbxBatchOut;
+int orbx_submit_batch_into(orbx_t* h, const uint8_t* const* imgs, int B, int w, int h_, int stride,
+                           const OrbxStreamOpts* opts, const OrbxBatchOut* out, int* ticket);
+int orbx_collect(orbx_t* h, int ticket);
+/* pinned (device-addressable, coherent) host memory for such arrays; orbx_host_free releases it */
+int orbx_host_alloc(orbx_t* h, size_t bytes, void** p);
 /* pinned host frames in the device layout (a cv::Mat can wrap them: cv::Mat(h, w, CV_8UC1, ptr, stride)) */
 int orbx_host_alloc_frames(orbx_t* h, int B, int w, int h_, uint8_t** frames, int* stride, size_t* pitch);
 int orbx_host_free(orbx_t* h, void* p);

@@ -43,6 +43,10 @@ class OrbxBatchView(C.Structure):
                 ("match", C.c_void_p), ("nmatch", C.c_void_p)]
 
 
+class OrbxBatchOut(C.Structure):
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_void_p), ("match", C.c_void_p), ("nmatch", C.c_void_p), ("cap", C.c_int32)]
+
+
 class OrbmFeatVec(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("start", C.c_void_p), ("idx", C.c_void_p)]
 
@@ -60,7 +64,7 @@ class OrbmProjParams(C.Structure):
 EXPORTS = [
     "orbx_last_error", "orbx_device_count", "orbx_device_pci_bus_id", "orbx_create", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
     "orbx_scale_tables", "orbx_features_per_level", "orbx_umax", "orbx_max_keypoints", "orbx_extract",
-    "orbx_extract_batch", "orbx_submit_batch", "orbx_collect_view", "orbx_release", "orbx_collect_batch", "orbx_extract_match_batch",
+    "orbx_extract_batch", "orbx_submit_batch", "orbx_submit_batch_into", "orbx_collect", "orbx_host_alloc", "orbx_collect_view", "orbx_release", "orbx_collect_batch", "orbx_extract_match_batch",
     "orbx_host_alloc_frames", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_device_results", "orbx_download",
     "orbx_pyramid_level", "orbx_compute_stereo_matches", "orbx_level_candidates", "orbx_sync", "orbx_device_alloc", "orbx_device_free", "orbx_upload", "orbx_match_prev_batch_device",
     "orbx_device_matches", "orbx_download_matches", "orbx_reset_stream", "orbx_set_serial", "orbx_profile_enable",

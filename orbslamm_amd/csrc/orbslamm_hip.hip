@@ -225,6 +225,7 @@ struct HostSlot {
     bool lat = false;           // results written by k_pack_host: h_out[1] holds ticket + 1 once they are all there
     int ticket = -1, B = 0;
     bool matched = false;
+    bool into = false; const int32_t* intoN = nullptr; int intoCap = 0;   // orbx_submit_batch_into: results went to the caller's arrays
 };
 
 // ------------------------------------------------------------------ handle
@@ -1302,6 +1303,15 @@ extern "C" int orbx_host_alloc_frames(orbx_t* h, int B, int w, int hh, uint8_t**
     return ORBX_OK;
 }
 
+extern "C" int orbx_host_alloc(orbx_t* h, size_t bytes, void** p)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    if (!p || bytes == 0) return fail(ORBX_E_INVALID, "bad argument");
+    HIPCHK(hipHostMalloc(p, bytes, hipHostMallocCoherent));  // read by the host behind an event or a flag: coherent
+    return ORBX_OK;
+}
+
 extern "C" int orbx_host_free(orbx_t* h, void* p)
 {
     int rc = check_device(h);
@@ -1329,11 +1339,21 @@ extern "C" int orbx_host_unregister(orbx_t* h, void* p)
     return ORBX_OK;
 }
 
-extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int hh, int stride,
-                                 const OrbxStreamOpts* opts, int* ticket)
+static int slot_of(orbx_handle* h, int ticket, int want, HostSlot** out);
+
+static int submit_core(orbx_t* h, const uint8_t* const* imgs, int B, int w, int hh, int stride,
+                       const OrbxStreamOpts* opts, const OrbxBatchOut* into, int* ticket)
 {
     int rc = check_device(h);
     if (rc) return rc;
+    if (into) {
+        // results straight into the caller's arrays: the result kernel writes them over the link, so they must be
+        // memory the device can address (orbx_host_alloc, or any buffer registered once with orbx_host_register)
+        if (!into->kps || !into->desc || !into->n || into->cap < 1) return fail(ORBX_E_INVALID, "bad output arrays");
+        if (opts && opts->match_prev && (!into->match || !into->nmatch)) return fail(ORBX_E_INVALID, "match tables requested without arrays for them");
+        const void* ptrs[] = {into->kps, into->desc, into->n, into->match, into->nmatch};
+        for (const void* q : ptrs) if (q && !is_pinned(q)) return fail(ORBX_E_INVALID, "output arrays must be pinned: allocate them with orbx_host_alloc or register them once with orbx_host_register");
+    }
     if (!imgs || B < 1 || !ticket) return fail(ORBX_E_INVALID, "no frames");
     if (B > h->maxB) return fail(ORBX_E_INVALID, "batch %d exceeds %d", B, h->maxB);
     if (w < 1 || hh < 1) return fail(ORBX_E_INVALID, "empty frame");
@@ -1417,7 +1437,8 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
         pa.count = r_count(h, set) + 1; pa.match = match ? dm : nullptr; pa.nmatch = match ? dnm : nullptr; pa.err = errWord;
         pa.hKps = (uint32_t*)(sl.h_out + h->outOffKp); pa.hDesc = (uint32_t*)(sl.h_out + h->outOffDesc);
         pa.hN = (int32_t*)(sl.h_out + h->outOffN); pa.hMatch = (int32_t*)(sl.h_out + h->outOffMatch);
-        pa.hNmatch = (int32_t*)(sl.h_out + h->outOffNm); pa.hErr = (int32_t*)sl.h_out; pa.maxKp = h->maxKp;
+        pa.hNmatch = (int32_t*)(sl.h_out + h->outOffNm); pa.hErr = (int32_t*)sl.h_out; pa.maxKp = h->maxKp; pa.hostPitch = h->maxKp;
+        if (into) { pa.hKps = (uint32_t*)into->kps; pa.hDesc = (uint32_t*)into->desc; pa.hN = into->n; pa.hMatch = into->match; pa.hNmatch = into->nmatch; pa.hostPitch = into->cap; }
         pa.hFlag = (int32_t*)sl.h_out + 1; pa.flagValue = h->nextTicket + 1; pa.blocksDone = h->d_err + 1;
         ((volatile int32_t*)sl.h_out)[1] = 0;
         h->prof.begin(P_D2H, ps);
@@ -1440,7 +1461,8 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
         pa.count = r_count(h, set) + 1; pa.match = match ? dm : nullptr; pa.nmatch = match ? dnm : nullptr; pa.err = errWord;
         pa.hKps = (uint32_t*)(sl.h_out + h->outOffKp); pa.hDesc = (uint32_t*)(sl.h_out + h->outOffDesc);
         pa.hN = (int32_t*)(sl.h_out + h->outOffN); pa.hMatch = (int32_t*)(sl.h_out + h->outOffMatch);
-        pa.hNmatch = (int32_t*)(sl.h_out + h->outOffNm); pa.hErr = (int32_t*)sl.h_out; pa.maxKp = h->maxKp;
+        pa.hNmatch = (int32_t*)(sl.h_out + h->outOffNm); pa.hErr = (int32_t*)sl.h_out; pa.maxKp = h->maxKp; pa.hostPitch = h->maxKp;
+        if (into) { pa.hKps = (uint32_t*)into->kps; pa.hDesc = (uint32_t*)into->desc; pa.hN = into->n; pa.hMatch = into->match; pa.hNmatch = into->nmatch; pa.hostPitch = into->cap; }
         pa.hFlag = nullptr; pa.flagValue = 0; pa.blocksDone = nullptr;  // the consumer waits for evOut: the kernel's end publishes
         h->prof.begin(P_D2H, dn);
         // two workgroups per frame: the kernel is bound by the link (8 MB at ~45 GB/s), more waves only sit on the CUs
@@ -1453,7 +1475,45 @@ extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, i
     h->evOutOfSet[set] = sl.evOut;
     h->outStream[set] = outS;
     sl.state = 1; sl.B = B; sl.matched = match; sl.ticket = h->nextTicket; sl.lat = lat;
+    sl.into = into != nullptr; sl.intoN = into ? into->n : nullptr; sl.intoCap = into ? into->cap : 0;
     *ticket = h->nextTicket++;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_submit_batch(orbx_t* h, const uint8_t* const* imgs, int B, int w, int hh, int stride,
+                                 const OrbxStreamOpts* opts, int* ticket)
+{
+    return submit_core(h, imgs, B, w, hh, stride, opts, nullptr, ticket);
+}
+
+extern "C" int orbx_submit_batch_into(orbx_t* h, const uint8_t* const* imgs, int B, int w, int hh, int stride,
+                                      const OrbxStreamOpts* opts, const OrbxBatchOut* out, int* ticket)
+{
+    if (!out) return fail(ORBX_E_INVALID, "null output");
+    return submit_core(h, imgs, B, w, hh, stride, opts, out, ticket);
+}
+
+// waits for a ticket of orbx_submit_batch_into: its results are in the caller's arrays; releases the ticket
+extern "C" int orbx_collect(orbx_t* h, int ticket)
+{
+    int rc = check_device(h);
+    if (rc) return rc;
+    HostSlot* sl;
+    if ((rc = slot_of(h, ticket, 1, &sl))) return rc;
+    if (!sl->into) return fail(ORBX_E_INVALID, "ticket %d was not submitted with output arrays: use orbx_collect_view / orbx_collect_batch", ticket);
+    bool landed = false;
+    if (sl->lat) {
+        volatile int32_t* flag = (volatile int32_t*)sl->h_out + 1;
+        for (int spin = 0; spin < 400000 && !landed; spin++) { landed = *flag == ticket + 1; if (!landed) cpu_relax(); }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (!landed) HIPCHK(hipEventSynchronize(sl->evOut));
+    const int32_t err = *(const int32_t*)sl->h_out;
+    int over = 0;
+    for (int f = 0; f < sl->B; f++) over |= sl->intoN[f] > sl->intoCap;
+    sl->state = 0;
+    if (err) return fail(ORBX_E_CAPACITY, "device scratch overflow (flags 0x%x)", err);
+    if (over) return fail(ORBX_E_CAPACITY, "a frame produced more keypoints than cap=%d (n[] holds the true counts, the arrays the first cap)", sl->intoCap);
     return ORBX_OK;
 }
 
@@ -1473,6 +1533,7 @@ extern "C" int orbx_collect_view(orbx_t* h, int ticket, OrbxBatchView* view)
     HostSlot* sl;
     if ((rc = slot_of(h, ticket, 1, &sl))) return rc;
     if (!view) return fail(ORBX_E_INVALID, "null view");
+    if (sl->into) return fail(ORBX_E_INVALID, "ticket %d was submitted with output arrays: use orbx_collect", ticket);
     bool landed = false;
     if (sl->lat) {
         // the pack kernel's last block writes ticket + 1 behind the results (system-scope release): polling the pinned

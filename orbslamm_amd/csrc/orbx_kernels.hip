@@ -1804,14 +1804,16 @@ struct PackArgs {
     const int32_t* match; const int32_t* nmatch; int32_t* err;   // match / nmatch may be null; err: the batch's error word (read and cleared)
     uint32_t* hKps; uint32_t* hDesc; int32_t* hN; int32_t* hMatch; int32_t* hNmatch; int32_t* hErr;
     int32_t* hFlag; int32_t flagValue; int32_t* blocksDone;  // the last block to finish raises the host flag
-    int maxKp;
+    int maxKp;       // pitch (records per frame) of the device arrays
+    int hostPitch;   // and of the host arrays: the slot's own block (= maxKp) or the caller's (orbx_submit_batch_into)
 };
 __global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
 {
     const int f = blockIdx.y;
-    const int n = a.count[f];
+    const int nAll = a.count[f];
+    const int n = min(nAll, a.hostPitch);   // never past the caller's row; hN carries the true count
     const int t = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
-    const int64_t o = (int64_t)f * a.maxKp;
+    const int64_t o = (int64_t)f * a.maxKp, oh = (int64_t)f * a.hostPitch;
     // 16 bytes per lane where the frame's slot is 16-byte aligned (maxKp a multiple of 4): a wave instruction then writes
     // a contiguous KiB towards the host
     auto copy_words = [&](uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int nw) {
@@ -1823,11 +1825,11 @@ __global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
         }
         for (int i = i0 + t; i < nw; i += step) dst[i] = src[i];
     };
-    copy_words(a.hKps + o * 7, a.kps + o * 7, 7 * n);
-    copy_words(a.hDesc + o * 8, a.desc + o * 8, 8 * n);
-    if (a.match) copy_words((uint32_t*)a.hMatch + o, (const uint32_t*)a.match + o, n);
+    copy_words(a.hKps + oh * 7, a.kps + o * 7, 7 * n);
+    copy_words(a.hDesc + oh * 8, a.desc + o * 8, 8 * n);
+    if (a.match) copy_words((uint32_t*)a.hMatch + oh, (const uint32_t*)a.match + o, n);
     if (t == 0) {
-        a.hN[f] = n;
+        a.hN[f] = nAll;
         if (a.nmatch) a.hNmatch[f] = a.nmatch[f];
         if (f == 0 && blockIdx.x == 0) *a.hErr = atomicExch(a.err, 0);  // the batch's own word: handed over and cleared
     }

@@ -31,6 +31,9 @@ class ORBextractor:
             for d in getattr(self, "_dev_bufs", []):
                 self._L.orbx_device_free(self._h, d)
             self._dev_bufs = []
+            for p in getattr(self, "_pinned_results", []):
+                self._L.orbx_host_free(self._h, p)
+            self._pinned_results = []
             self._L.orbx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -172,6 +175,41 @@ class ORBextractor:
         nm = np.zeros(B, dtype=np.int32)
         check(self._L.orbx_collect_batch(self._h, int(ticket), ptr(kps), ptr(desc), cap, ptr(n), ptr(m), ptr(nm)))
         return kps, desc, n, m, nm
+
+    def alloc_pinned_results(self, B):
+        """caller-owned PINNED result arrays (orbx_host_alloc) for submit_host_into: (kps, desc, n, match, nmatch) as numpy
+        views; they live until close()"""
+        cap = self._cap
+        sizes = [B * cap * 28, B * cap * 32, B * 4, B * cap * 4, B * 4]
+        offs = np.cumsum([0] + [(x + 63) // 64 * 64 for x in sizes])
+        p = C.c_void_p()
+        check(self._L.orbx_host_alloc(self._h, C.c_size_t(int(offs[-1])), C.byref(p)))
+        self._pinned_results = getattr(self, "_pinned_results", []) + [p]
+
+        def view(off, dtype, shape):
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            buf = (C.c_uint8 * n).from_address(p.value + int(off))
+            return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+        return (view(offs[0], KP_DTYPE, (B, cap)), view(offs[1], np.uint8, (B, cap, 32)), view(offs[2], np.int32, (B,)),
+                view(offs[3], np.int32, (B, cap)), view(offs[4], np.int32, (B,)))
+
+    def submit_host_into(self, images, out, match=True, nnratio=0.7, th_low=50, check_ori=True):
+        """orbx_submit_batch_into: the results of the batch land in `out` (from alloc_pinned_results) -- no copy on collect"""
+        keep, arr, B, w, h, stride = self._frame_ptrs(images)
+        kps, desc, n, m, nm = out
+        o = _lib.OrbxBatchOut(kps.ctypes.data, desc.ctypes.data, n.ctypes.data, m.ctypes.data, nm.ctypes.data, kps.shape[1])
+        t = C.c_int(-1)
+        opts = self._opts(match, nnratio, th_low, check_ori)
+        check(self._L.orbx_submit_batch_into(self._h, arr, B, w, h, stride, C.byref(opts), C.byref(o), C.byref(t)))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[t.value] = (keep, out)
+        return t.value
+
+    def collect_into(self, ticket):
+        """orbx_collect: waits; the arrays given to submit_host_into hold the results"""
+        self._inflight.pop(ticket, None)
+        check(self._L.orbx_collect(self._h, int(ticket)))
 
     def alloc_pinned_frames(self, B, w, h):
         """orbx_host_alloc_frames: pinned host frames in the device layout, as a PinnedFrames (numpy view in .array)"""

@@ -184,3 +184,39 @@ def test_soak_random_tickets(gpu, oracle):
             _check(ref[o + f], kps[f], desc[f], int(n[f]), m[f], int(nm[f]))
         o += b
     assert o == sum(sizes)
+
+
+def test_results_straight_into_caller_arrays(gpu, oracle):
+    """orbx_submit_batch_into / orbx_collect: keypoints, descriptors and match tables land in the caller's own pinned
+    arrays, exactly n records per frame, pipelined three deep -- equal to the oracle and to the copy-out entry"""
+    from orbslamm_amd import ORBextractor, OrbError, synth
+    w, h, nf, B = 640, 480, 1000, 4
+    fr = synth.make_frames(w, h, 3 * B, stream=6)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=0)
+    outs = [ex.alloc_pinned_results(B) for _ in range(3)]
+    for o in outs:
+        o[0]["x"][:] = -7.0   # stale content must not survive where records are written
+    tickets = [ex.submit_host_into(fr[i * B:(i + 1) * B], outs[i]) for i in range(3)]
+    for t in tickets:
+        ex.collect_into(t)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    prev = None
+    for i in range(3):
+        kps, desc, n, m, nm = outs[i]
+        for f in range(B):
+            r = oex(fr[i * B + f])
+            assert n[f] == len(r["kps"]) and kps[f, :n[f]].tobytes() == r["kps"].tobytes() and desc[f, :n[f]].tobytes() == r["desc"].tobytes()
+            assert kps[f, n[f]]["x"] == -7.0   # nothing past the n-th record
+            if prev is not None:
+                wm, wn = oracle.match_bruteforce(r["desc"], r["kps"]["angle"], prev["desc"], prev["kps"]["angle"], 0.7, 50, True)
+                assert nm[f] == wn and np.array_equal(m[f, :n[f]], wm)
+            prev = r
+    # pageable output arrays are refused (the device could not write them), and the ticket kinds do not mix
+    ex2 = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=0)
+    bad = tuple(np.zeros_like(a) for a in outs[0])
+    with pytest.raises(OrbError):
+        ex2.submit_host_into(fr[:B], bad)
+    t = ex2.submit_host(fr[:B])
+    with pytest.raises(OrbError):
+        ex2.collect_into(t)
+    ex2.collect_host(t)
