@@ -2958,7 +2958,7 @@ static int voc_transform_device(orbv_handle* h, const uint8_t* d_desc, int n, in
     hipLaunchKernelGGL(orbv::k_voc_descend, dim3((n + 63) / 64), dim3(64), 0, s, v, d_desc, n, levelsup,
                        (uint32_t*)h->d_buf[SV_WORD], (uint32_t*)h->d_buf[SV_NODE], (double*)h->d_buf[SV_W]);
     const bool accLds = P <= 4096;
-    const size_t lds = (size_t)P * (accLds ? 20 : 12);
+    const size_t lds = (size_t)P * (accLds ? 36 : 12);
     auto kern = accLds ? orbv::k_voc_aggregate<true> : orbv::k_voc_aggregate<false>;
     if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(1), dim3(orbv::kAggThreads), lds, s, v, n, P, (const uint32_t*)h->d_buf[SV_WORD],

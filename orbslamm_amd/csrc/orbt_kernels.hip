@@ -407,8 +407,21 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
         const uint2 e = list[k];
         list[k].x = e.x | ((uint32_t)hamming_rows(P.qdesc, e.y, P.tdesc, e.x & 0xFFFF) << 20);
     }
-    if (!staged) return;
     __syncthreads();
+    if (!staged) {
+        // the distance cut in place, inside the query's own segment of the arena (order kept; what is left behind the
+        // survivors is marked dead: the resolve walks the whole chunk)
+        if (lc == 0 && qtot > 0 && dMax < 256) {
+            int keep = 0;
+            for (int k = qoff; k < qoff + qtot; k++) {
+                const uint2 e = list[k];
+                if ((int)(e.x >> 20) <= dMax) list[qoff + keep++] = e;
+            }
+            for (int k = qoff + keep; k < qoff + qtot; k++) list[k].x = 0xFFFFFFFFu;
+            P.candCnt[q] = keep;
+        }
+        return;
+    }
     // compaction: each lane takes a quarter of its query's list
     const int seg = (qtot + kCandLanes - 1) / kCandLanes;
     const int k0 = qoff + min(lc * seg, qtot), k1 = qoff + min((lc + 1) * seg, qtot);
@@ -439,14 +452,15 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
 // commits.  A thread-per-query walk of the lists costs every wave its longest list, a chain of dependent LDS reads per
 // entry, in every round; the flat loop keeps all lanes busy and its reads independent.
 // LDS (dynamic): occBy, minUnd[2], winner (4 * tCap dwords) | per query: offset, best, second, result (4 * qCap dwords)
-// | candidates (ldsCand dwords) | their queries (ldsCand halves) | per query: state byte (qCap bytes).
+// | candidates (ldsCand dwords) | their queries (ldsCand halves) | two live lists (2 * ldsCand halves) | per query: state
+// byte (qCap bytes).
 // L = false: the per-query tables and the lists stay in memory (more queries or candidates than the LDS plan holds).
 constexpr uint8_t kQDecided = 1, kQBlocking = 2;
 
 template <bool L>
 __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const ProjCommon& c, int nq, int nt, int total,
                                                    int32_t* occBy, int32_t* minUnd0, int32_t* winner, int32_t* qtab, int* hist,
-                                                   int* sPending, int* sInd, int* sCount)
+                                                   int* sPending, int* sInd, int* sCount, int* sLive)
 {
     const int tid = threadIdx.x;
     const bool useRot = c.checkOri && (c.mode == 4 || c.mode == 5);
@@ -455,13 +469,15 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     // distance); in the other modes a candidate farther than the acceptance threshold can never be taken: skipped.
     const int dMax = c.mode == 3 ? 256 : c.thDist;
     int32_t *qoff, *best1, *best2, *qres;
-    uint32_t* candL = nullptr; uint16_t* ownL = nullptr; uint8_t* qst;
+    uint32_t* candL = nullptr; uint16_t* ownL = nullptr; uint16_t* live0 = nullptr; uint8_t* qst;
     if constexpr (L) {
         qoff = qtab; best1 = qtab + c.qCap; best2 = qtab + 2 * c.qCap; qres = qtab + 3 * c.qCap;
         candL = (uint32_t*)(qtab + 4 * c.qCap);
         ownL = (uint16_t*)(candL + c.ldsCand);
-        qst = (uint8_t*)(ownL + c.ldsCand);
-        for (int k = tid; k < total; k += kThreads) { const uint2 e = P.cand[k]; candL[k] = e.x; ownL[k] = (uint16_t)e.y; }
+        live0 = ownL + c.ldsCand;
+        qst = (uint8_t*)(live0 + 2 * c.ldsCand);
+        for (int k = tid; k < total; k += kThreads) { const uint2 e = P.cand[k]; candL[k] = e.x; ownL[k] = (uint16_t)e.y; live0[k] = (uint16_t)k; }
+        if (tid == 0) { sLive[0] = total; sLive[1] = 0; }
     } else {
         qoff = P.candOff; best1 = P.qscr; best2 = P.qscr + nq; qres = P.qres; qst = (uint8_t*)(P.qscr + 2 * nq);
     }
@@ -479,20 +495,55 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     for (;; round++) {
         int32_t* minUnd = minUnd0 + (round & 1) * c.tCap;
         int32_t* idle = minUnd0 + ((round + 1) & 1) * c.tCap;
+        if constexpr (L) {
+            // over the LIVE entries only (those of undecided queries whose train feature is still free for them -- both
+            // conditions are final once false), compacting the list for the next round on the way: a round costs what is
+            // still open, not what was listed
+            const uint16_t* lv = live0 + (round & 1) * c.ldsCand;
+            uint16_t* nx = live0 + ((round + 1) & 1) * c.ldsCand;
+            const int nLive = sLive[round & 1];
+            for (int i0 = 0; i0 < nLive; i0 += kThreads) {
+                const int i = i0 + tid;
+                bool keep = false;
+                int k = 0;
+                if (i < nLive) {
+                    k = lv[i];
+                    const uint32_t ex = candL[k];
+                    const int q = ownL[k], d = (int)(ex >> 20), t = (int)(ex & 0xFFFF);
+                    const uint8_t st = qst[q];
+                    keep = !(st & kQDecided) && d <= dMax && occBy[t] >= q;
+                    if (keep) {
+                        if ((st & kQBlocking) && d <= c.thDist) atomicMin(&minUnd[t], q);
+                        atomicMin(&best1[q], (d << 22) | (k - qoff[q]));
+                    }
+                }
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(keep);
+                if (bal) {
+                    int base = 0;
+                    if ((tid & 63) == 0) base = atomicAdd(&sLive[(round + 1) & 1], __popcll(bal));
+                    base = __shfl(base, 0);
+                    if (keep) nx[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))] = (uint16_t)k;
+                }
+            }
+        } else {
         for (int k = tid; k < total; k += kThreads) {
-            const uint2 e = entry(k);
-            const int q = (int)e.y, d = (int)(e.x >> 20), t = (int)(e.x & 0xFFFF);
-            const uint8_t st = qst[q];
-            if ((st & kQDecided) || d > dMax) continue;
-            if (occBy[t] < q) continue;  // taken before this query's turn (or occupied on entry)
-            // a query without observations takes nothing away from anybody; nobody can take what is beyond the threshold
-            if ((st & kQBlocking) && d <= c.thDist) atomicMin(&minUnd[t], q);
-            atomicMin(&best1[q], (d << 22) | (k - qoff[q]));
+                const uint2 e = entry(k);
+                const int q = (int)e.y, d = (int)(e.x >> 20), t = (int)(e.x & 0xFFFF);
+                const uint8_t st = qst[q];
+                if ((st & kQDecided) || d > dMax) continue;
+                if (occBy[t] < q) continue;  // taken before this query's turn (or occupied on entry)
+                // a query without observations takes nothing away from anybody; nobody can take what is beyond the threshold
+                if ((st & kQBlocking) && d <= c.thDist) atomicMin(&minUnd[t], q);
+                atomicMin(&best1[q], (d << 22) | (k - qoff[q]));
+            }
         }
         if (tid == 0) sPending[(round + 1) % 3] = 0;  // three counters in rotation: the one being read after a round's last barrier is not reset before the round after next
         __syncthreads();
         if (c.mode == 3) {  // the runner-up: the best of what is left (ORBmatcher.cc:102-114)
-            for (int k = tid; k < total; k += kThreads) {
+            const int nIt = L ? sLive[(round + 1) & 1] : total;
+            for (int i = tid; i < nIt; i += kThreads) {
+                int k = i;
+                if constexpr (L) k = (live0 + ((round + 1) & 1) * c.ldsCand)[i];
                 const uint2 e = entry(k);
                 const int q = (int)e.y, t = (int)(e.x & 0xFFFF);
                 if ((qst[q] & kQDecided) || occBy[t] < q) continue;
@@ -524,6 +575,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
             qres[q] = t1;
         }
         for (int t = tid; t < nt; t += kThreads) idle[t] = kFree;
+        if (L && tid == 0) sLive[round & 1] = 0;   // read in this round's first pass, filled again by the next round's
         if (pend) atomicAdd(&sPending[round % 3], pend);
         __syncthreads();
         if (sPending[round % 3] == 0) break;
@@ -592,6 +644,7 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
     __shared__ int sPending[3];
     __shared__ int sInd[3];
     __shared__ int sCount;
+    __shared__ int sLive[2];
     int32_t* occBy = tl;                   // kFree, -1 (occupied on entry) or the blocking query that took the feature
     int32_t* minUnd0 = occBy + c.tCap;     // two copies, used by alternate rounds (the idle one is cleared meanwhile)
     int32_t* winner = occBy + 3 * c.tCap;  // last query (in query order) that took the feature in this call
@@ -614,8 +667,8 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
         if (tid == 0) { *P.total = 0; *P.nmatch = -total - 1; if (P.stats) { P.stats[0] = 0; P.stats[1] = total; } }
         return;
     }
-    if (total <= c.ldsCand && nq <= c.qCap) proj_resolve_rounds<true>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount);
-    else proj_resolve_rounds<false>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount);
+    if (total <= c.ldsCand && nq <= c.qCap) proj_resolve_rounds<true>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount, sLive);
+    else proj_resolve_rounds<false>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount, sLive);
 }
 
 __global__ __launch_bounds__(kCandThreads) void k_proj_candidates(const ProjPair* __restrict__ pairs, ProjCommon c)

@@ -9,6 +9,13 @@
 
 namespace orbv {
 
+#ifdef ORBT_PHASE_TIMING  // tools/proj_phases.sh
+__device__ unsigned long long g_orbvPhase[16];
+#define ORBV_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_orbvPhase[i] = wall_clock64(); } while (0)
+#else
+#define ORBV_MARK(i) do { } while (0)
+#endif
+
 struct VocDev {
     const int32_t* childStart;  // n_nodes + 1
     const int32_t* childIdx;    // children in push_back order
@@ -100,7 +107,66 @@ __device__ __forceinline__ int boundaries_scan(const uint64_t* a, int m, uint32_
     return tot;
 }
 
-// BowVector + FeatureVector of one descriptor set.  P = power of two >= max(n, 2), LDS: P*8 + P*4 + P*8 bytes.
+// BowVector + FeatureVector of one descriptor set.  P = power of two >= max(n, 2), LDS: P * 36 bytes (ACC_LDS: keys, group
+// index, word values, bucket-sort scratch) or P * 12.
+// Sort of the valid keys (everything but ~0) of keys[0..P): a bucket sort instead of the bitonic network's 66 barrier
+// steps (50 us of this kernel's 123 each time).  A key is (id << 32 | feature); compressed to (id - idMin) * 8192 + feature
+// the keys of a frame are spread nearly evenly, so a linear map onto P buckets leaves about one key per bucket: histogram,
+// scan, scatter, a short insertion sort per bucket -- six barriers.  tmp: P keys, cnt / cur: P ints each.
+__device__ __forceinline__ void bucket_sort_lds(uint64_t* keys, uint64_t* tmp, int* cnt, int* cur, int P, int m, int* wsum, uint32_t* sMinMax)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { sMinMax[0] = 0xFFFFFFFFu; sMinMax[1] = 0u; }
+    for (int i = tid; i < P; i += kAggThreads) { cnt[i] = 0; cur[i] = 0; }
+    __syncthreads();
+    for (int i = tid; i < P; i += kAggThreads) {
+        const uint64_t k = keys[i];
+        if (k != ~0ull) { atomicMin(&sMinMax[0], (uint32_t)(k >> 32)); atomicMax(&sMinMax[1], (uint32_t)(k >> 32)); }
+    }
+    __syncthreads();
+    const uint32_t idMin = sMinMax[0];
+    const double scale = (double)P / ((double)(sMinMax[1] - idMin + 1u) * 8192.0);
+    auto bucket = [&](uint64_t k) {
+        const double c = (double)((uint64_t)((uint32_t)(k >> 32) - idMin) * 8192ull + (uint32_t)k);
+        return min((int)(c * scale), P - 1);   // monotone in the key
+    };
+    for (int i = tid; i < P; i += kAggThreads) { const uint64_t k = keys[i]; if (k != ~0ull) atomicAdd(&cnt[bucket(k)], 1); }
+    __syncthreads();
+    int carry = 0;
+    for (int base = 0; base < P; base += kAggThreads) {  // exclusive scan of cnt
+        const int i = base + tid;
+        const int v = i < P ? cnt[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int k = 0; k < kAggThreads / 64; k++) { if (k < wave) woff += wsum[k]; tot += wsum[k]; }
+        if (i < P) cnt[i] = carry + woff + incl - v;
+        carry += tot;
+    }
+    __syncthreads();
+    for (int i = tid; i < P; i += kAggThreads) {
+        const uint64_t k = keys[i];
+        if (k != ~0ull) { const int b = bucket(k); tmp[cnt[b] + atomicAdd(&cur[b], 1)] = k; }
+    }
+    __syncthreads();
+    for (int b = tid; b < P; b += kAggThreads) {
+        const int s0 = cnt[b], e0 = s0 + cur[b];
+        for (int i = s0 + 1; i < e0; i++) {
+            const uint64_t x = tmp[i];
+            int j = i - 1;
+            while (j >= s0 && tmp[j] > x) { tmp[j + 1] = tmp[j]; j--; }
+            tmp[j + 1] = x;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < P; i += kAggThreads) keys[i] = i < m ? tmp[i] : ~0ull;
+    __syncthreads();
+}
+
 template <bool ACC_LDS>  // word values staged in LDS (P <= 4096) or worked on in place in outW
 __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P,
                                                    const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
@@ -113,8 +179,12 @@ __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P
     uint64_t* keys = alds;
     uint32_t* pos = (uint32_t*)(alds + P);
     double* accL = ACC_LDS ? (double*)(alds + P + P / 2) : outW;   // P >= 2
+    uint64_t* tmp = alds + 2 * P + P / 2;       // ACC_LDS only: the bucket sort's scratch (P keys + 2 P ints)
+    int* bcnt = (int*)(tmp + P);
+    int* bcur = bcnt + P;
     __shared__ int wsum[kAggThreads / 64];
     __shared__ int sM;
+    __shared__ uint32_t sMinMax[2];
     const int tid = threadIdx.x;
     const bool tf = v.weighting == 0 || v.weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
     const bool must = v.scoring != 5;                       // DotProductScoring does not normalise
@@ -132,8 +202,11 @@ __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P
         for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
         if ((tid & 63) == 0) atomicAdd(&sM, c);
     }
-    bitonic_sort_lds(keys, P);
+    __syncthreads();
+    ORBV_MARK(0);
     const int m = sM;
+    if (ACC_LDS) bucket_sort_lds(keys, tmp, bcnt, bcur, P, m, wsum, sMinMax); else bitonic_sort_lds(keys, P);
+    ORBV_MARK(1);
     const int nw = boundaries_scan(keys, m, pos, wsum);
     // the word values stay in LDS until they are final: the normalisation sum below is one thread walking them in
     // map (word id) order, which from memory cost a load latency per addend (0.19 ms of this kernel's 0.2)
@@ -154,6 +227,7 @@ __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P
         for (int i = tid; i < nw; i += kAggThreads) accL[i] /= nd;
         __syncthreads();
     }
+    ORBV_MARK(2);
     if (must) {  // BowVector::normalize: the sum runs in map (word id) order, sequentially
         __shared__ double sNorm;
         if (tid == 0) {
@@ -176,17 +250,21 @@ __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P
     if (ACC_LDS) for (int i = tid; i < nw; i += kAggThreads) outW[i] = accL[i];
     __syncthreads();
 
+    ORBV_MARK(3);
     // ---- FeatureVector: sort (node, feature); addFeature appends in feature order (:1159)
     for (int i = tid; i < P; i += kAggThreads)
         keys[i] = (i < n && w[i] > 0) ? (((uint64_t)node[i] << 32) | (uint32_t)i) : ~0ull;
     __syncthreads();
-    bitonic_sort_lds(keys, P);
+    ORBV_MARK(4);
+    if (ACC_LDS) bucket_sort_lds(keys, tmp, bcnt, bcur, P, m, wsum, sMinMax); else bitonic_sort_lds(keys, P);
+    ORBV_MARK(5);
     const int nf = boundaries_scan(keys, m, pos, wsum);
     for (int i = tid; i < m; i += kAggThreads) {
         fvIdx[i] = (int32_t)(uint32_t)keys[i];
         if (i == 0 || pos[i] != pos[i - 1]) { fvNode[pos[i]] = (uint32_t)(keys[i] >> 32); fvStart[pos[i]] = i; }
     }
     if (tid == 0) { fvStart[nf] = m; counts[0] = nw; counts[1] = nf; }
+    ORBV_MARK(6);
 }
 
 template <bool ACC_LDS>

@@ -3,3 +3,4 @@
 # gpurun: bash tools/proj_phases.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
 ORBSLAMM_HIP_LIB=$R/build_ub/libT.so python $R/tools/proj_phases.py
+ORBSLAMM_HIP_LIB=$R/build_ub/libT.so python $R/tools/bow_phases.py
