@@ -104,14 +104,20 @@ __device__ __forceinline__ void undistort_point(const UndistArgs& a, float& px, 
 
 // One workgroup per frame: mvKeysUn, the angle column, a private copy of the descriptors and mGrid as CSR
 // (cell-major ix*rows+iy, ascending feature index inside a cell = the reference's push_back order, Frame.cc:236-244).
-// LDS: 2 * ncell ints (counts -> starts, fill cursors) + cap uint16 (the cell lists, sorted in place before they go out).
+// LDS: 2 * ncell ints (counts -> starts, fill cursors) + cap uint16 (the cell lists, sorted in place before they go out)
+// + cap x {x, y, octave} (12 bytes): every later phase reads the keys from LDS, not back from memory -- the kernel is a
+// chain of short phases and a memory round trip per phase was most of its 31 us.
 __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
 {
     extern __shared__ int32_t gl[];
     __shared__ int wsum[kWaves];
+    const int capE = (a.fs.cap + 1) & ~1;
     int32_t* cnt = gl;
     int32_t* cur = gl + a.fs.ncell;
-    uint16_t* lst = (uint16_t*)(gl + 2 * a.fs.ncell);
+    float* kx = (float*)(gl + 2 * a.fs.ncell);
+    float* ky = kx + capE;
+    int32_t* ko = (int32_t*)(ky + capE);
+    uint16_t* lst = (uint16_t*)(ko + capE);
     const int tid = threadIdx.x;
     const int src = blockIdx.x;
     const int slot = (a.slot0 + src) % a.slotMod;
@@ -129,6 +135,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
         if (a.undistort) undistort_point(a.und, kp.x, kp.y);
         dk[i] = kp;
         da[i] = kp.angle;
+        kx[i] = kp.x; ky[i] = kp.y; ko[i] = kp.octave;
         int px, py;
         if (orbm::pos_in_grid(a.grid, kp.x, kp.y, px, py)) atomicAdd(&cnt[px * a.grid.rows + py], 1);
     }
@@ -150,9 +157,8 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
     if (tid == 0) { cs[a.fs.ncell] = carry; a.fs.n[slot] = n; }
     __syncthreads();
     for (int i = tid; i < n; i += kThreads) {
-        const KeyDev kp = dk[i];  // written by this very thread
         int px, py;
-        if (orbm::pos_in_grid(a.grid, kp.x, kp.y, px, py)) {
+        if (orbm::pos_in_grid(a.grid, kx[i], ky[i], px, py)) {
             const int c = px * a.grid.rows + py;
             lst[cnt[c] + atomicAdd(&cur[c], 1)] = (uint16_t)i;
         }
@@ -170,9 +176,8 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
     __syncthreads();
     for (int j = tid; j < carry; j += kThreads) {
         const int i = lst[j];
-        const KeyDev& kp = dk[i];
         ci[j] = i;
-        rec[j] = make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), (uint32_t)i | ((uint32_t)kp.octave << 24), 0u);
+        rec[j] = make_uint4(__float_as_uint(kx[i]), __float_as_uint(ky[i]), (uint32_t)i | ((uint32_t)ko[i] << 24), 0u);
     }
 }
 
