@@ -66,7 +66,7 @@ def test_product_never_imports_oracle():
     for base in ("orbslamm_amd", "include"):
         for dp, _, files in os.walk(os.path.join(ROOT, base)):
             for f in files:
-                if f.endswith((".py", ".hip", ".hpp", ".h")):
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".inc")):
                     txt = open(os.path.join(dp, f), errors="replace").read()
                     assert "oracle" not in txt.lower().replace("no cpu fallback", ""), os.path.join(dp, f)
 
