@@ -90,6 +90,11 @@ def test_projection_degenerate_shapes(gpu, oracle):
     _both(oracle, 3, 100, 0.8, True, dict(c, occ=np.ones(50, np.uint8)), 50)
     c1 = make_proj_case(rng, 1, 1)
     _both(oracle, 4, 100, 0.9, True, c1, 1)
+    # more queries than the resolve keeps per-query tables for in LDS (a local map's worth of MapPoints): same rounds, from memory
+    big_q = make_proj_case(rng, 6000, 1500)
+    for mode, th, ratio in ((3, 100, 0.8), (4, 100, 0.9)):
+        wn, _ = _both(oracle, mode, th, ratio, True, big_q, 1500)
+        assert wn > 500
     m = ORBmatcher(0.9, True, device=0)
     g = make_grid(0.0, 0.0, 1241.0, 376.0)
     a, occ, n = m.SearchByProjection(4, 100, np.zeros((0, 3), np.float32), np.zeros((0, 2), np.int8), np.zeros((0, 32), np.uint8),
