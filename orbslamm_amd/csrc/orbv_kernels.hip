@@ -119,9 +119,15 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* keys, uint64_t* tmp, i
     if (tid == 0) { sMinMax[0] = 0xFFFFFFFFu; sMinMax[1] = 0u; }
     for (int i = tid; i < P; i += kAggThreads) { cnt[i] = 0; cur[i] = 0; }
     __syncthreads();
-    for (int i = tid; i < P; i += kAggThreads) {
-        const uint64_t k = keys[i];
-        if (k != ~0ull) { atomicMin(&sMinMax[0], (uint32_t)(k >> 32)); atomicMax(&sMinMax[1], (uint32_t)(k >> 32)); }
+    {   // id range: per wave first (two thousand atomics on one LDS word serialise)
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int i = tid; i < P; i += kAggThreads) {
+            const uint64_t k = keys[i];
+            if (k != ~0ull) { lo = min(lo, (uint32_t)(k >> 32)); hi = max(hi, (uint32_t)(k >> 32)); }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d)); }
+        if (lane == 0) { atomicMin(&sMinMax[0], lo); atomicMax(&sMinMax[1], hi); }
     }
     __syncthreads();
     const uint32_t idMin = sMinMax[0];
@@ -232,12 +238,28 @@ __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P
         __shared__ double sNorm;
         if (tid == 0) {
             double norm = 0.0;
+            // one thread, map order (BowVector.cpp:60-79): 64 values per step come in with 32 wide LDS reads issued
+            // together, then the dependent adds run from registers
+            const double2* a2 = (const double2*)accL;
+            int i = 0;
             if (!l2) {
-#pragma unroll 8
-                for (int i = 0; i < nw; i++) norm += fabs(accL[i]);
+                for (; i + 64 <= nw; i += 64) {
+                    double2 v[32];
+#pragma unroll
+                    for (int k = 0; k < 32; k++) v[k] = a2[(i >> 1) + k];
+#pragma unroll
+                    for (int k = 0; k < 32; k++) { norm += fabs(v[k].x); norm += fabs(v[k].y); }
+                }
+                for (; i < nw; i++) norm += fabs(accL[i]);
             } else {
-#pragma unroll 8
-                for (int i = 0; i < nw; i++) norm += accL[i] * accL[i];
+                for (; i + 64 <= nw; i += 64) {
+                    double2 v[32];
+#pragma unroll
+                    for (int k = 0; k < 32; k++) v[k] = a2[(i >> 1) + k];
+#pragma unroll
+                    for (int k = 0; k < 32; k++) { norm += v[k].x * v[k].x; norm += v[k].y * v[k].y; }
+                }
+                for (; i < nw; i++) norm += accL[i] * accL[i];
                 norm = sqrt(norm);
             }
             sNorm = norm;
