@@ -38,7 +38,7 @@ constexpr int kMaxQueryIters = 32;  // decided-bit per (thread, iteration): nq <
 
 #ifdef ORBT_PHASE_TIMING  // tools/proj_phases.sh: where a workgroup of k_proj_fused spends its time (100 MHz wall clock)
 __device__ unsigned long long g_orbtPhase[16];
-#define ORBT_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_orbtPhase[i] = wall_clock64(); } while (0)
+#define ORBT_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_orbtPhase[i] = wall_clock64(); } while (0)
 #else
 #define ORBT_MARK(i) do { } while (0)
 #endif
@@ -320,6 +320,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
     const int nq = min(P.nqPtr ? *P.nqPtr : P.nq, kMaxQueryIters * kThreads);
     if (nt <= 0 || slice * kCandQueries >= nq) return;
+    ORBT_MARK(4);
     const int ncell = min(P.grid.cols * P.grid.rows, c.cellCap - 1);
     for (int ci = tid; ci <= ncell; ci += kCandThreads) cst[ci] = (uint16_t)P.cellStart[ci];
     const int ngrid = min(P.cellStart[ncell], nt);
@@ -358,6 +359,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
         for (int pi = 0; pi < kCandPasses; pi++) { const int ix = w.x0 + pi * kCandLanes + lc; if (ix <= w.x1) f(pi, ix); }
     };
     __syncthreads();
+    ORBT_MARK(5);
     int cnt[kCandPasses] = {0, 0, 0, 0};
     my_columns([&](int pi, int ix) {
         int n = 0;
@@ -365,6 +367,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
 #pragma unroll
         for (int k = 0; k < kCandPasses; k++) if (k == pi) cnt[k] += n;
     });
+    ORBT_MARK(6);
     // a query's list: pass by pass, inside a pass lane by lane (= column by column)
     int off[kCandPasses], qtot = 0;
 #pragma unroll
@@ -393,6 +396,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
         if (q < nq && lc == 0) { P.candOff[q] = base + qoff; P.candCnt[q] = fits ? qtot : 0; }
         if (!fits) return;
     }
+    ORBT_MARK(7);
     uint2* list = staged ? stage : P.cand + base;
     int wrun = off[0];  // wide: lane 0 walks all columns one after the other, positions simply continue
     my_columns([&](int pi, int ix) {
@@ -408,6 +412,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
         wrun = pos - qoff;
     });
     __syncthreads();
+    ORBT_MARK(8);
     for (int k = tid; k < tot; k += kCandThreads) {
         const uint2 e = list[k];
         list[k].x = e.x | ((uint32_t)hamming_rows(P.qdesc, e.y, P.tdesc, e.x & 0xFFFF) << 20);
@@ -427,6 +432,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
         }
         return;
     }
+    ORBT_MARK(9);
     // compaction: each lane takes a quarter of its query's list
     const int seg = (qtot + kCandLanes - 1) / kCandLanes;
     const int k0 = qoff + min(lc * seg, qtot), k1 = qoff + min((lc + 1) * seg, qtot);
@@ -442,11 +448,13 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     const bool fits = base + ktot <= P.candCap;
     if (q < nq && lc == 0) { P.candOff[q] = base + kex; P.candCnt[q] = fits ? qkeep : 0; }
     if (!fits) return;
+    ORBT_MARK(10);
     int pos = base + kex + kofs;
     for (int k = k0; k < k1; k++) {
         const uint2 e = stage[k];
         if ((int)(e.x >> 20) <= dMax) P.cand[pos++] = e;
     }
+    ORBT_MARK(11);
 }
 
 // The sequential part, in parallel rounds (see the head of this file).  One workgroup of 1024 per pair.

@@ -30,5 +30,9 @@ for th in (15.0, 30.0):
         if rep >= 5:
             acc += np.array(list(us))
     acc /= 15
+    us2 = (C.c_double * 11)()
+    L.orbm_debug_phase_times(us2, 11)
+    cn = ["stage grid", "count walk", "scans", "list walk", "hamming", "compact count+alloc", "write"]
+    print("  candidates workgroup (0,0): " + ", ".join("%s %.1f" % (k, v) for k, v in zip(cn, list(us2)[4:11])) + " us")
     r, cands = fs.stats(0)
     print("th=%g: %d matches, %d rounds, %d candidates | " % (th, n[0], r, cands) + ", ".join("%s %.1f us" % (k, v) for k, v in zip(names, acc)) + " | total %.1f us" % acc.sum())
