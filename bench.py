@@ -381,14 +381,14 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         step(n)
-        if n:
-            fs.results(back=1)  # the consumer reads step n-1's tables while step n runs
+        if n > 1:
+            fs.results(back=2)  # the consumer reads step n-2's tables while steps n-1 and n are in flight
         n += 1
     a, k = fs.results()
     ex.sync()
     dt = time.perf_counter() - t0
     out["batched"] = {"pairs_per_s": n * B / dt, "ms_per_step": dt / n * 1e3, "batch": B, "steps": n, "matches_mean": float(np.mean(k)),
-                      "what": "per step: orbx_extract_batch_device(B) + frame-set build + orbm_track_frames(B pairs), tables read one step behind"}
+                      "what": "per step: orbx_extract_batch_device(B) + frame-set build + orbm_track_frames(B pairs), tables read two steps behind"}
     # the tracking kernels alone on the last extracted batch (k_frame_build + k_track_fused, both B workgroups)
     for _ in range(3):
         step(0, extract=False)

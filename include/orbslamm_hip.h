@@ -388,9 +388,9 @@ int orbm_last_search_stats(orbm_t* h, int* rounds, int* candidates);
  *     mvKeysUn[i].pt, skipped outside `bounds` (:1375-1378), radius = th * mvScaleFactors[octave], octave window
  *     [octave-1, octave+1] (:1381-1392) -- SURVEY.md 8(d)'s grid-windowed variant.  A caller with a pose uses
  *     orbm_search_by_projection_frame on the same data.  pp->mode must be 4.  Asynchronous.
- *   orbm_track_results: waits for the last (back = 0) or the last but one (back = 1) orbm_track_frames; assign[p*cap + t] =
+ *   orbm_track_results: waits for the last (back = 0) or an earlier (back = 1 .. 3) orbm_track_frames; assign[p*cap + t] =
  *     LastFrame feature index held by CurrentFrame feature t (or -1), nmatches[p]; both point into pinned host memory the
- *     kernel wrote (two result sets in alternation: valid until the call after next).
+ *     kernel wrote (four result sets in rotation: valid until three more calls have been issued).
  * bounds = mnMinX, mnMaxX, mnMinY, mnMaxY (Frame::ComputeImageBounds); scale_factors = mvScaleFactors. */
 typedef struct orbm_frameset orbm_frameset_t;
 int orbm_frameset_create(orbm_t* h, int slots, int cap, const float K[4], const float D[5], const OrbmGrid* grid,
@@ -466,7 +466,7 @@ int orbm_search_by_bow_frames(orbm_t* h, orbm_frame_t* q, const uint8_t* qvalid,
  *   src/ORBmatcher.cc:159-290 as Tracking::TrackReferenceKeyFrame calls it (src/Tracking.cc:805-812), for npairs
  *   (KeyFrame slot, Frame slot) pairs in two launches; every KeyFrame feature counts as holding a good MapPoint.
  *   Asynchronous.  orbm_bow_results as orbm_track_results: match[p*cap + t] = KeyFrame feature matched to Frame feature
- *   t or -1, nmatches[p], in pinned host memory (two result sets in alternation). */
+ *   t or -1, nmatches[p], in pinned host memory (four result sets in rotation). */
 int orbm_frameset_compute_bow(orbm_frameset_t* fs, orbv_t* voc, int slot0, int n, int levelsup);
 int orbm_frameset_bow_vector(orbm_frameset_t* fs, int slot, uint32_t* word_id, double* word_value, int cap, int* n_words);
 int orbm_bow_frames(orbm_frameset_t* fs, const int32_t* kf_slots, const int32_t* frame_slots, int npairs, float nnratio, int check_ori);
