@@ -499,53 +499,106 @@ __device__ __forceinline__ void top2_merge(uint32_t& k1, uint32_t& k2, uint32_t 
     k1 = lo;
 }
 
+// minimum over the 64 lanes without touching LDS: four DPP steps reduce every row of 16, row_bcast15 / row_bcast31 carry
+// the row minima to the last lane (identity 0xFFFFFFFF where a lane has no source)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#define ORBM_DPP_MIN(ctrl, rows) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, ctrl, rows, 0xF, false))
+    ORBM_DPP_MIN(0xB1, 0xF);    // quad_perm [1, 0, 3, 2]
+    ORBM_DPP_MIN(0x4E, 0xF);    // quad_perm [2, 3, 0, 1]
+    ORBM_DPP_MIN(0x141, 0xF);   // row_half_mirror
+    ORBM_DPP_MIN(0x140, 0xF);   // row_mirror
+    ORBM_DPP_MIN(0x142, 0xA);   // row_bcast15 into rows 1 and 3
+    ORBM_DPP_MIN(0x143, 0xC);   // row_bcast31 into rows 2 and 3
+#undef ORBM_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ void bow_pair_body(const BowArgs& a, int nodeQ, int nodeT)
 {
     const int lane = threadIdx.x;
     const int qs = a.qstart[nodeQ], qe = a.qstart[nodeQ + 1];
     const int ts = a.tstart[nodeT], te = a.tstart[nodeT + 1];
-    if (qe - qs <= 64 && te - ts <= 64) {
-        // The common case (a vocabulary node holds a few dozen features of a frame): lane l keeps train feature l AND
-        // query l of the node in registers -- descriptor, angle, flags -- so everything is loaded once, up front and
-        // in parallel, and the sequential walk over the queries (:205-211) is register work: the query's descriptor is
-        // broadcast lane to lane, the "already matched" flag lives with the lane that owns the train feature.
-        const bool hasT = lane < te - ts, hasQ = lane < qe - qs;
-        const int t = hasT ? a.tidx[ts + lane] : 0, q = hasQ ? a.qidx[qs + lane] : 0;
-        uint32_t tw[8], qw[8];
-        const uint32_t* tp = (const uint32_t*)(a.tdesc + (int64_t)t * 32);
-        const uint32_t* qp = (const uint32_t*)(a.qdesc + (int64_t)q * 32);
+    constexpr int kPer = 4;  // features of a node per lane on either side
+    if (qe - qs <= 64 * kPer && te - ts <= 64 * kPer) {
+        // The common case (a vocabulary node holds a few dozen features of a frame, seldom more than a hundred): lane l
+        // keeps train features l, l + 64, .. AND queries l, l + 64, .. of the node in registers -- descriptor, angle,
+        // flags -- so everything is loaded once, up front and in parallel, and the sequential walk over the queries
+        // (:205-211) is register work: the query's descriptor goes lane -> scalar registers (v_readlane), the two minima
+        // through DPP, the "already matched" flag lives with the lane that owns the train feature.
+        const int ntj = (te - ts + 63) >> 6, nqj = (qe - qs + 63) >> 6;
+        int t[kPer], q[kPer];
+        uint32_t tw[kPer][8], qw[kPer][8];
+        float tang[kPer], qang[kPer];
+        bool tfree[kPer], qok[kPer];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { tw[i] = tp[i]; qw[i] = qp[i]; }
-        const float tang = a.checkOri ? a.tang[t] : 0.f, qang = a.checkOri ? a.qang[q] : 0.f;
-        bool tfree = hasT && !a.matched[t] && !(a.tvalid && !a.tvalid[t]);
-        const bool qok = hasQ && !(a.qvalid && !a.qvalid[q]);
-        for (int iq = 0; iq < qe - qs; iq++) {
-            if (!__shfl((int)qok, iq)) continue;  // wave-uniform
-            int d = 0;
+        for (int j = 0; j < kPer; j++) {
+            const bool hasT = j < ntj && lane + 64 * j < te - ts, hasQ = j < nqj && lane + 64 * j < qe - qs;
+            t[j] = hasT ? a.tidx[ts + lane + 64 * j] : 0;
+            q[j] = hasQ ? a.qidx[qs + lane + 64 * j] : 0;
+            tfree[j] = hasT; qok[j] = hasQ;
+        }
 #pragma unroll
-            for (int i = 0; i < 8; i++) d += __popc(tw[i] ^ (uint32_t)__shfl((int)qw[i], iq));
-            // key = dist << 22 | scan position (= lane)
-            uint32_t k1 = tfree ? (((uint32_t)d << 22) | (uint32_t)lane) : 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        for (int j = 0; j < kPer; j++) {
+            if (j < ntj) {
+                const uint32_t* tp = (const uint32_t*)(a.tdesc + (int64_t)t[j] * 32);
 #pragma unroll
-            for (int dd = 32; dd >= 1; dd >>= 1) {
-                const uint32_t o1 = __shfl_xor(k1, dd), o2 = __shfl_xor(k2, dd);
-                top2_merge(k1, k2, o1, o2);
+                for (int i = 0; i < 8; i++) tw[j][i] = tp[i];
+                tang[j] = a.checkOri ? a.tang[t[j]] : 0.f;
+                tfree[j] = tfree[j] && !a.matched[t[j]] && !(a.tvalid && !a.tvalid[t[j]]);
             }
-            const int best1 = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 22);
-            const int best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 22);
-            if (best1 <= a.thLow && (float)best1 < __fmul_rn(a.nnratio, (float)best2)) {
-                const int win = (int)(k1 & 0x3FFFFFu);
-                const int qi = __shfl(q, iq);
-                const float qa = __shfl(qang, iq);
-                if (lane == win) {
-                    tfree = false;
-                    a.matched[t] = 1;
-                    const int o = a.outByTrain ? t : qi;
-                    a.match[o] = a.outByTrain ? qi : t;
-                    if (a.checkOri) {
-                        const int bin = rot_bin(qa, tang);
-                        a.binOf[o] = (uint8_t)bin;
-                        atomicAdd(&a.hist[bin], 1);
+            if (j < nqj) {
+                const uint32_t* qp = (const uint32_t*)(a.qdesc + (int64_t)q[j] * 32);
+#pragma unroll
+                for (int i = 0; i < 8; i++) qw[j][i] = qp[i];
+                qang[j] = a.checkOri ? a.qang[q[j]] : 0.f;
+                qok[j] = qok[j] && !(a.qvalid && !a.qvalid[q[j]]);
+            }
+        }
+#pragma unroll
+        for (int jq = 0; jq < kPer; jq++) {
+            if (jq >= nqj) break;
+            const uint64_t qokMask = __builtin_amdgcn_ballot_w64(qok[jq]);
+            const int nHere = min(64, qe - qs - 64 * jq);
+            for (int iq = 0; iq < nHere; iq++) {
+                if (!((qokMask >> iq) & 1)) continue;  // wave-uniform
+                uint32_t sq[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) sq[i] = (uint32_t)__builtin_amdgcn_readlane((int)qw[jq][i], iq);
+                // key = dist << 22 | scan position (lane + 64 j): unique per (lane, j)
+                uint32_t key[kPer];
+                uint32_t kmin = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < kPer; j++) {
+                    key[j] = 0xFFFFFFFFu;
+                    if (j < ntj) {
+                        int d = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) d += __popc(tw[j][i] ^ sq[i]);
+                        if (tfree[j]) key[j] = ((uint32_t)d << 22) | (uint32_t)(lane + 64 * j);
+                        kmin = min(kmin, key[j]);
+                    }
+                }
+                const uint32_t k1 = wave_min_u32(kmin);
+                uint32_t kmin2 = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < kPer; j++) if (j < ntj && key[j] != k1) kmin2 = min(kmin2, key[j]);
+                const uint32_t k2 = wave_min_u32(kmin2);
+                const int best1 = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 22);
+                const int best2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 22);
+                if (best1 <= a.thLow && (float)best1 < __fmul_rn(a.nnratio, (float)best2)) {
+                    const int win = (int)(k1 & 0x3FFFFFu);
+                    const int qi = __builtin_amdgcn_readlane(q[jq], iq);
+                    const float qa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qang[jq]), iq));
+#pragma unroll
+                    for (int j = 0; j < kPer; j++) {
+                        if (j < ntj && lane + 64 * j == win) {
+                            tfree[j] = false;
+                            a.matched[t[j]] = 1;
+                            const int o = a.outByTrain ? t[j] : qi;
+                            a.match[o] = a.outByTrain ? qi : t[j];
+                            if (a.checkOri) a.binOf[o] = (uint8_t)rot_bin(qa, tang[j]);  // the histogram is counted by the pruning kernel, in LDS
+                        }
                     }
                 }
             }
@@ -582,11 +635,7 @@ __device__ __forceinline__ void bow_pair_body(const BowArgs& a, int nodeQ, int n
                 a.matched[t] = 1;
                 const int o = a.outByTrain ? t : q;
                 a.match[o] = a.outByTrain ? q : t;
-                if (a.checkOri) {
-                    const int bin = rot_bin(a.qang[q], a.tang[t]);
-                    a.binOf[o] = (uint8_t)bin;
-                    atomicAdd(&a.hist[bin], 1);
-                }
+                if (a.checkOri) a.binOf[o] = (uint8_t)rot_bin(a.qang[q], a.tang[t]);
             }
         }
         __syncthreads();  // matched[] visible to the whole wave before the next query
@@ -613,15 +662,27 @@ struct BowSetArgs {
 __global__ __launch_bounds__(64) void k_bow_set(BowSetArgs s)
 {
     const int p = blockIdx.y, qs = s.kf[p], ts = s.fr[p];
-    const int nQ = s.counts[2 * qs + 1], nT = s.counts[2 * ts + 1];
-    const int nodeQ = blockIdx.x;
-    if (nodeQ >= nQ) return;
+    const int nodeQ = blockIdx.x, lane = threadIdx.x;
     const int64_t C = s.cap;
-    const uint32_t id = s.fvNode[qs * C + nodeQ];
+    // first round trip: both node counts, this workgroup's node id, the KeyFrame node's feature range
+    const int nQ = s.counts[2 * qs + 1], nT = s.counts[2 * ts + 1];
+    const uint32_t* qn = s.fvNode + qs * C;
     const uint32_t* tn = s.fvNode + ts * C;
-    int lo = 0, hi = nT;   // first train node with id >= ours (DBoW2's lower_bound, :255-263)
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tn[mid] < id) lo = mid + 1; else hi = mid; }
-    if (lo >= nT || tn[lo] != id) return;
+    const uint32_t id = qn[min(nodeQ, (int)C - 1)];
+    if (nodeQ >= nQ) return;
+    // second: the Frame's node with the same id (the lock-step walk of the two sorted maps, :180-266).  Up to 128 nodes are
+    // looked at by all lanes at once -- a binary search is seven dependent loads
+    int lo = -1;
+    if (nT <= 128) {
+        const uint32_t t0 = lane < nT ? tn[lane] : 0xFFFFFFFFu, t1 = lane + 64 < nT ? tn[lane + 64] : 0xFFFFFFFFu;
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(lane < nT && t0 == id), m1 = __builtin_amdgcn_ballot_w64(lane + 64 < nT && t1 == id);
+        if (m0) lo = __ffsll((long long)m0) - 1; else if (m1) lo = 64 + __ffsll((long long)m1) - 1;
+    } else {
+        int a0 = 0, hi = nT;   // first train node with id >= ours (DBoW2's lower_bound, :255-263)
+        while (a0 < hi) { const int mid = (a0 + hi) >> 1; if (tn[mid] < id) a0 = mid + 1; else hi = mid; }
+        if (a0 < nT && tn[a0] == id) lo = a0;
+    }
+    if (lo < 0) return;
     BowArgs a;
     a.qdesc = s.desc + qs * C * 32; a.qang = s.ang + qs * C; a.qvalid = nullptr;
     a.tdesc = s.desc + ts * C * 32; a.tang = s.ang + ts * C; a.tvalid = nullptr;
@@ -643,9 +704,13 @@ __global__ __launch_bounds__(256) void k_bow_prune_set(BowSetArgs s, int32_t* __
     const int tid = threadIdx.x, p = blockIdx.x;
     const int64_t C = s.cap;
     const int n = min(s.n[s.fr[p]], s.cap);
-    int32_t* hist = s.hist + p * 32;
-    if (tid < 32) sh[tid] = hist[tid];
+    // the rotation histogram (:238-248) is counted here, in LDS: a few hundred matches of a pair fall into two or three
+    // bins, and as global atomics on those few words they took longer than the search itself
+    if (tid < 32) sh[tid] = 0;
     if (tid == 0) sCnt = 0;
+    __syncthreads();
+    if (s.checkOri)
+        for (int i = tid; i < n; i += 256) if (s.match[p * C + i] >= 0) atomicAdd(&sh[s.binOf[p * C + i]], 1);
     __syncthreads();
     if (tid == 0) {
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -686,8 +751,11 @@ __global__ __launch_bounds__(256) void k_prune_flat(int32_t* __restrict__ match,
     __shared__ int sInd[3];
     __shared__ int sCnt;
     const int tid = threadIdx.x;
-    if (tid < 32) { sh[tid] = hist[tid]; hist[tid] = 0; }
+    if (tid < 32) sh[tid] = 0;   // (`hist` is no longer an input: the bins are counted here, in LDS, from binOf)
     if (tid == 0) sCnt = 0;
+    __syncthreads();
+    if (checkOri)
+        for (int i = tid; i < n; i += 256) if (match[i] >= 0) atomicAdd(&sh[binOf[i]], 1);
     __syncthreads();
     if (tid == 0) {
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
