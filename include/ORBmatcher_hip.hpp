@@ -79,8 +79,68 @@ private:
     orbm_frame_t* f_;
 };
 
+// A set of device-resident frames and the searches Tracking runs per frame over pairs of them, batched: orbm_frameset_*,
+// orbm_track_*, orbm_bow_* (include/orbslamm_hip.h).  Slots are filled straight from an extractor's device results
+// (the tail of Frame::Frame for the whole batch in one launch); match tables are read in place from pinned host memory.
+class FrameSet {
+public:
+    FrameSet(orbm_t* matcher, int slots, int cap, const float K[4], const float D[5], const OrbmGrid& grid, const float bounds[4],
+             const std::vector<float>& scaleFactors)
+        : cap_(cap)
+    {
+        if (orbm_frameset_create(matcher, slots, cap, K, D, &grid, bounds, scaleFactors.data(), (int)scaleFactors.size(), &fs_) != ORBX_OK)
+            throw std::runtime_error(std::string("FrameSet: ") + orbx_last_error());
+    }
+    ~FrameSet() { orbm_frameset_destroy(fs_); }
+    FrameSet(const FrameSet&) = delete;
+    FrameSet& operator=(const FrameSet&) = delete;
+    int capacity() const { return cap_; }
+    // the frames of the extractor's last batch into slots slot0, slot0 + 1, .. (ring); no host sync
+    void build(int slot0, orbx_t* extractor) { check(orbm_frameset_build_from_extractor(fs_, slot0, extractor)); }
+    // mvKeysUn / mDescriptors of a slot for the host side of Tracking
+    int download(int slot, std::vector<OrbxKeyPoint>& keysUn, std::vector<uint8_t>& descriptors)
+    {
+        keysUn.resize((size_t)cap_); descriptors.resize((size_t)cap_ * 32);
+        int n = 0;
+        check(orbm_frameset_download(fs_, slot, keysUn.data(), descriptors.data(), cap_, &n));
+        keysUn.resize((size_t)n); descriptors.resize((size_t)n * 32);
+        return n;
+    }
+    // SearchByProjection(CurrentFrame, LastFrame, th, bMono = true) (ORBmatcher.cc:1330) for every (cur, last) slot pair;
+    // asynchronous.  results(): assign[p * capacity() + t] = LastFrame feature held by CurrentFrame feature t, or -1.
+    void track(const std::vector<int32_t>& cur, const std::vector<int32_t>& last, float th, float nnratio = 0.9f, bool checkOri = true, int thDist = 100)
+    {
+        OrbmProjParams pp = {4, nnratio, checkOri ? 1 : 0, thDist};
+        check(orbm_track_frames(fs_, &pp, th, cur.data(), last.data(), (int)cur.size()));
+    }
+    int results(const int32_t*& assign, const int32_t*& nmatches, int back = 0)
+    {
+        int npairs = 0;
+        check(orbm_track_results(fs_, back, &assign, &nmatches, &npairs, nullptr));
+        return npairs;
+    }
+    // Frame::ComputeBoW (Frame.cc:394) for n slots, then SearchByBoW(KeyFrame, Frame) (ORBmatcher.cc:159) for slot pairs
+    void computeBoW(orbv_t* vocabulary, int slot0, int n, int levelsup = 4) { check(orbm_frameset_compute_bow(fs_, vocabulary, slot0, n, levelsup)); }
+    void searchByBoW(const std::vector<int32_t>& keyFrames, const std::vector<int32_t>& frames, float nnratio = 0.7f, bool checkOri = true)
+    {
+        check(orbm_bow_frames(fs_, keyFrames.data(), frames.data(), (int)keyFrames.size(), nnratio, checkOri ? 1 : 0));
+    }
+    int bowResults(const int32_t*& match, const int32_t*& nmatches, int back = 0)
+    {
+        int npairs = 0;
+        check(orbm_bow_results(fs_, back, &match, &nmatches, &npairs, nullptr));
+        return npairs;
+    }
+    orbm_frameset_t* get() const { return fs_; }
+private:
+    static void check(int rc) { if (rc != ORBX_OK) throw std::runtime_error(std::string("FrameSet: ") + orbx_last_error()); }
+    orbm_frameset_t* fs_ = nullptr;
+    int cap_ = 0;
+};
+
 class FlatMatcher {
 public:
+    orbm_t* handle() { return h_; }
     static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;  // ORBmatcher.cc:37-39
 
     FlatMatcher(float nnratio = 0.6f, bool checkOri = true, int device = 0)

@@ -96,6 +96,41 @@ int main()
         EXPECT(std::memcmp(f12.data(), of12.data(), (size_t)n * 4) == 0);
         std::printf("device frames: %d / %d features, %d init matches\n", n, n2, nf);
     }
+    // FrameSet: two consecutive extractions into two slots, SearchByProjection(Cur, Last) with the identity pose on the
+    // device, against the oracle's sequential loop on the downloaded arrays
+    {
+        const float K[4] = {517.3f, 516.5f, 318.6f, 255.3f}, D0[5] = {0, 0, 0, 0, 0}, bounds[4] = {0.f, (float)W, 0.f, (float)H};
+        iORB_SLAM::FrameSet fs(m.handle(), 2, orbx_max_keypoints(ex.handle()), K, D0, g, bounds, ex.GetScaleFactors());
+        std::vector<OrbxKeyPoint> ka, kb; std::vector<uint8_t> da, db;
+        ex(img.data(), W, H, W, ka, da);
+        fs.build(0, ex.handle());
+        std::vector<uint8_t> img2 = img;
+        for (size_t i = 1; i < img2.size(); i += 5) img2[i] = (uint8_t)(img2[i] ^ (rng() & 3));
+        ex(img2.data(), W, H, W, kb, db);
+        fs.build(1, ex.handle());
+        std::vector<OrbxKeyPoint> un; std::vector<uint8_t> dd2;
+        EXPECT(fs.download(1, un, dd2) == (int)kb.size() && std::memcmp(un.data(), kb.data(), kb.size() * 28) == 0 && dd2 == db);
+        fs.track({1}, {0}, 15.f);
+        const int32_t* assign = nullptr; const int32_t* nmv = nullptr;
+        EXPECT(fs.results(assign, nmv) == 1);
+        const int na = (int)ka.size(), nb = (int)kb.size();
+        std::vector<float> uvr((size_t)na * 3); std::vector<int8_t> lvl((size_t)na * 2); std::vector<float> ang((size_t)na);
+        const std::vector<float> sf = ex.GetScaleFactors();
+        for (int i = 0; i < na; i++) {
+            uvr[3 * i] = ka[i].x; uvr[3 * i + 1] = ka[i].y; uvr[3 * i + 2] = 15.f * sf[(size_t)ka[i].octave];
+            lvl[2 * i] = (int8_t)(ka[i].octave - 1); lvl[2 * i + 1] = (int8_t)(ka[i].octave + 1);
+            ang[i] = ka[i].angle;
+        }
+        std::vector<int32_t> cs3(64 * 48 + 1), ci3(nb), want(nb, -1);
+        std::vector<uint8_t> occ(nb, 0);
+        orc_grid_build(&og, (const OrcKeyPoint*)kb.data(), nb, cs3.data(), ci3.data());
+        OrcProjParams opp = {4, 0.9f, 1, 100};
+        const int wn = orc_search_by_projection(&opp, uvr.data(), lvl.data(), da.data(), ang.data(), nullptr, nullptr, na, &og,
+                                                (const OrcKeyPoint*)kb.data(), cs3.data(), ci3.data(), db.data(), nb, occ.data(), want.data());
+        EXPECT(nmv[0] == wn && wn > 100);
+        EXPECT(std::memcmp(assign, want.data(), (size_t)nb * 4) == 0);
+        std::printf("frame set: %d / %d features, %d projection matches\n", na, nb, wn);
+    }
     // mvImagePyramid (ORBextractor.h:85): a public member again, filled on first use after operator(), each level inside
     // a 19 px BORDER_REFLECT_101 frame like ComputePyramid leaves it (ORBextractor.cc:1107-1132)
     {
