@@ -17,8 +17,8 @@ __device__ unsigned long long g_orbvPhase[16];
 #endif
 
 struct VocDev {
-    const int32_t* childStart;  // n_nodes + 1
-    const int32_t* childIdx;    // children in push_back order
+    const int32_t* childStart;  // n_nodes + 1: the children of node i are the nodes [childStart[i], childStart[i + 1]) (breadth-first numbering, orbv_create)
+    const int32_t* childIdx;    // origId: the file's id of node i (what the FeatureVector is keyed by)
     const uint8_t* desc;        // n_nodes x 32
     const int32_t* wordId;      // -1 for inner nodes
     const double* weight;
@@ -49,14 +49,13 @@ __global__ void k_voc_descend(VocDev v, const uint8_t* __restrict__ desc, int n,
     do {
         ++level;
         const int cs = v.childStart[finalId], ce = v.childStart[finalId + 1];
-        finalId = v.childIdx[cs];
-        int best = ham256(q, (const uint32_t*)(v.desc + (int64_t)finalId * 32));
+        finalId = cs;
+        int best = ham256(q, (const uint32_t*)(v.desc + (int64_t)cs * 32));
         for (int c = cs + 1; c < ce; c++) {
-            const int id = v.childIdx[c];
-            const int d = ham256(q, (const uint32_t*)(v.desc + (int64_t)id * 32));
-            if (d < best) { best = d; finalId = id; }
+            const int d = ham256(q, (const uint32_t*)(v.desc + (int64_t)c * 32));
+            if (d < best) { best = d; finalId = c; }
         }
-        if (level == nidLevel) nid = (uint32_t)finalId;
+        if (level == nidLevel) nid = (uint32_t)v.childIdx[finalId];
     } while (v.childStart[finalId + 1] > v.childStart[finalId]);
     word[i] = (uint32_t)v.wordId[finalId];
     node[i] = nid;
@@ -326,14 +325,13 @@ __global__ void k_voc_descend_set(VocDev v, VocSetArgs a, int levelsup)
     do {  // as k_voc_descend
         ++level;
         const int cs = v.childStart[finalId], ce = v.childStart[finalId + 1];
-        finalId = v.childIdx[cs];
-        int best = ham256(q, (const uint32_t*)(v.desc + (int64_t)finalId * 32));
+        finalId = cs;
+        int best = ham256(q, (const uint32_t*)(v.desc + (int64_t)cs * 32));
         for (int c = cs + 1; c < ce; c++) {
-            const int id = v.childIdx[c];
-            const int d = ham256(q, (const uint32_t*)(v.desc + (int64_t)id * 32));
-            if (d < best) { best = d; finalId = id; }
+            const int d = ham256(q, (const uint32_t*)(v.desc + (int64_t)c * 32));
+            if (d < best) { best = d; finalId = c; }
         }
-        if (level == nidLevel) nid = (uint32_t)finalId;
+        if (level == nidLevel) nid = (uint32_t)v.childIdx[finalId];
     } while (v.childStart[finalId + 1] > v.childStart[finalId]);
     a.word[o + i] = (uint32_t)v.wordId[finalId];
     a.node[o + i] = nid;
