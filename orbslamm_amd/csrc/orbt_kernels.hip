@@ -1,27 +1,27 @@
-// orbt_kernels.hip -- the Tracking-shaped searches as ONE launch per call, batched over frame pairs (round 3).
+// orbt_kernels.hip -- the Tracking-shaped searches, batched over frames and frame pairs (round 3).
 //
 // Reference: /root/reference/SingleRobotScenario/src
 //   Frame::Frame tail: UndistortKeyPoints + AssignFeaturesToGrid   Frame.cc:196-210, 404-434, 230-245  -> k_frame_build
 //   ORBmatcher::SearchByProjection x4                              ORBmatcher.cc:45-129, 292-405, 1330-1472, 1474-1601
-//                                                                                                      -> k_proj_fused
+//                                                   -> k_proj_candidates + k_proj_resolve (k_track_*: frame-set pairs)
 // What Tracking runs per frame is SearchByProjection(CurrentFrame, LastFrame, th, bMono) (Tracking.cc:925-936).  Its
 // queries are resolved one after the other in the reference: a query skips the train features that an EARLIER query
-// (whose MapPoint has observations) took.  k_proj_fused keeps that order-dependent result exactly, without walking
+// (whose MapPoint has observations) took.  The resolve kernel keeps that order-dependent result exactly, without walking
 // the queries serially:
 //   * a query's outcome depends only on which of ITS candidates lower-indexed blocking queries have taken;
 //   * so query q may decide as soon as, for the candidate(s) that determine its decision (the best one; best and second
 //     in mode 3), no lower-indexed undecided blocking query lists that candidate -- nothing can take it away any more,
 //     and everything ranked better is already taken for good (occupancy only grows);
-//   * rounds: every undecided blocking query posts its index on its free candidates (LDS atomicMin), then every
-//     undecided query evaluates its top-2 among the candidates free FOR IT and commits if they are posted by nobody
-//     lower.  The lowest undecided query always commits, windows are local, so a frame pair takes a handful of rounds.
+//   * rounds: every live candidate entry posts its query on its train feature and itself on its query (LDS atomicMin),
+//     then every undecided query reads its best among the candidates free FOR IT and commits if nobody lower is posted
+//     on it.  The lowest undecided query always commits, windows are local, so a frame pair takes ten to twenty rounds.
 //   * "free for q" carries a time stamp: a feature taken by blocker b is occupied only for queries > b -- a
 //     non-blocking query (MapPoint without observations, ORBmatcher.cc:87-89, 1405-1407) decides late but must see the
 //     occupancy of its own turn.  assign[t] is the LAST writer in query order = the maximum index (atomicMax).
-// One workgroup of 1024 threads per frame pair, grid = pairs.  The train frame's grid (positions, octaves, cell starts)
-// is staged in LDS; candidates (distance | octave | index, in the reference's scan order) are listed once, in LDS when
-// they fit behind the tables, else in a per-pair arena whose size is fixed up front (overflow is reported through
-// nmatch < 0, never written past).
+// Candidates come from k_*_candidates: workgroups of 128 queries (four lanes each) walk the train frame's grid, staged in
+// LDS, list what lies in the windows in the reference's scan order, fill in the Hamming distances with a flat loop and
+// hand what is within the acceptance threshold to a per-pair arena whose size is fixed up front (overflow is reported
+// through nmatch < 0, never written past).  k_*_resolve: one workgroup of 1024 threads per frame pair.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -36,7 +36,7 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kFree = 0x7FFFFFFF;
 constexpr int kMaxQueryIters = 32;  // decided-bit per (thread, iteration): nq <= 32 * 1024
 
-#ifdef ORBT_PHASE_TIMING  // tools/proj_phases.sh: where a workgroup of k_proj_fused spends its time (100 MHz wall clock)
+#ifdef ORBT_PHASE_TIMING  // tools/proj_phases.sh: where a workgroup of the resolve / candidates kernels spends its time (100 MHz wall clock)
 __device__ unsigned long long g_orbtPhase[16];
 #define ORBT_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_orbtPhase[i] = wall_clock64(); } while (0)
 #else
