@@ -171,9 +171,9 @@ __global__ __launch_bounds__(256) void k_expand_desc(MatchIO io, int slot0, int 
     uint4 o = make_uint4(0, 0, 0, 0);
     if (kp < n) {
         const uint32_t bits = *(const uint16_t*)(io.desc + (int64_t)slot * io.descPitch + (int64_t)kp * 32 + 2 * c);
-        auto pm1 = [](uint32_t b4) {  // 4 bits -> 4 bytes, set = +1, clear = -1
+        auto pm1 = [](uint32_t b4) {  // 4 bits -> 4 bytes, set = +32, clear = -32
             const uint32_t x = (b4 * 0x00204081u) & 0x01010101u;
-            return x | ((x ^ 0x01010101u) * 0xFFu);
+            return (x * 0x20u) | ((x ^ 0x01010101u) * 0xE0u);
         };
         o.x = pm1(bits & 15); o.y = pm1((bits >> 4) & 15); o.z = pm1((bits >> 8) & 15); o.w = pm1(bits >> 12);
     }
@@ -187,20 +187,45 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int kMfmaRowsPerBlock = 256;  // 4 waves x 2 query blocks of 32
 
 // One workgroup = 256 queries of one frame pair; the train side streams through LDS in tiles of 32 features
-// (8 KiB, double buffered, one barrier per tile); each wave holds two query blocks in registers (64 VGPRs) and
-// keeps, per lane and accumulator element, the running (best, second) keys of "its" train residue class.
-// key = Hamming << 16 | j - 2^23 (one v_lshl_add from the negated dot product), so signed min = best with the
-// lowest index on ties (the reference scans j ascending with strict <) and med3(best, key, second) = new second.
+// (8 KiB, ring of 8 filled by LDS-direct loads, one barrier per two tiles); each wave holds two query blocks in registers (64 VGPRs).
+//
+// The product is taken with the TRAIN tile as the A side and the queries as the B side: accumulator element r of lane l
+// is then train row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the tile against query l & 31 -- every lane's sixteen
+// elements belong to ONE query and arrive in ascending train index, tile after tile.  So the running (best, second) of
+// a query are two registers of its lane (and of lane + 32, merged once at the end) instead of two per accumulator
+// element, and the key needs no instruction at all: descriptors are expanded to +-32 bytes and the queries negated,
+// so a . b = 1024 (2 H - 256) exactly in int32, and the accumulators start from the constants r = 0..15:
+//     acc[r] = 1024 (2 H - 256) + r.
+// Before a tile is folded 16 is subtracted from both running keys, so a key of d tiles ago carries -16 d + r in its
+// low field: signed min = smallest H, then the EARLIEST tile, then the lowest row -- the reference's scan with its
+// strict < (ORBmatcher.cc:214-226 form).  -16 d + r > -1024 holds for 64 tiles; every 64 tiles the keys are decoded
+// to H << 16 | j and merged into absolute ones.  Per pair: v_min_i32 + v_med3_i32 (med3(best, key, second) = the new
+// second), nothing else.  The fold of tile t is written beside the products of tile t + 1 (two accumulator sets):
+// the VALU work of a wave sits in the shadow of its own MFMAs.
 // Few frames (the one-frame-per-call entry): gridDim.y > 1 cuts the train side into chunks of whole tiles, one
 // workgroup each, which leave their (k1, k2) keys in `partial` for k_match_accept to merge -- 9 workgroups walking
 // 63 tiles each become 72 walking 8.
+constexpr int kMfmaEmpty = 0x7FFFFFFF;
+constexpr int kMfmaRing = 8;  // train tiles in LDS (64 KB)
+constexpr int kMfmaAhead = 6; // tiles in flight ahead of the one being multiplied
+__device__ __forceinline__ int mfma_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// relative key (low field -16 d + r, d = tiles before `tileNow`) -> H << 16 | j; anything that is not a product (the
+// initial value, a masked row) stays "empty"
+__device__ __forceinline__ int mfma_key_abs(int k, int tileNow, int half)
+{
+    if (k >= (1 << 29)) return kMfmaEmpty;
+    const int v = k + 1008, low = v & 1023, r = low & 15;
+    const int H = ((v >> 10) + 256) >> 1;
+    const int j = (tileNow - (63 - (low >> 4))) * 32 + mfma_row_of(r, half);
+    return (H << 16) | j;
+}
 __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict__ xdesc, int64_t xPitch,
                                                       AcceptArgs acc, int nqb, int nframes,
                                                       uint2* __restrict__ partial, int64_t partialPitch)
 {
     const int32_t* __restrict__ count = acc.q.count;  // q.count and t.count index the same slot table here
     const int qslot0 = acc.qslot0, tslot0 = acc.tslot0;
-    __shared__ uint4 tileB[3][512];
+    __shared__ uint4 tileB[kMfmaRing][512];
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, so the query blocks of one frame
     // pair are given to one XCD and share that frame's train tiles in its L2
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -209,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
     const int nq = count[qslot0 + f], nt = count[tslot0 + f];
     const int q0 = (k % nqb) * kMfmaRowsPerBlock;
     if (q0 >= nq) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
     const int nchunks = gridDim.y, chunk = blockIdx.y;
     const int tilesPer = (((nt + 31) >> 5) + nchunks - 1) / nchunks;
     const int tile0 = chunk * tilesPer;                                  // this workgroup's first train tile
@@ -223,106 +248,131 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
     const uint4* tsrc = (const uint4*)(xdesc + (int64_t)(tslot0 + f) * xPitch) + (int64_t)tile0 * 512;
     const int qblk0 = (q0 >> 5) + wave * 2;
 
-    v4i A[2][8];
+    v4i Q[2][8];
 #pragma unroll
     for (int qb = 0; qb < 2; qb++)
 #pragma unroll
-        for (int s = 0; s < 8; s++) A[qb][s] = *(const v4i*)(qx + (int64_t)(qblk0 + qb) * 8192 + s * 1024 + lane * 16);
+        for (int s = 0; s < 8; s++) Q[qb][s] = *(const v4i*)(qx + (int64_t)(qblk0 + qb) * 8192 + s * 1024 + lane * 16);
 
-    int best[2][16], second[2][16];
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) best[qb][r] = second[qb][r] = 0x7FFFFFFF;
-
-    // train tiles: prefetch distance 2 through registers (ga: even tiles, gb: odd tiles), LDS ring of 3.  The
-    // loads and their counted waits are inline asm: hipcc cannot count vmcnt across the loop back-edge and
-    // would drain the newest prefetch with vmcnt(0) at every LDS store.  Every step issues exactly two loads
-    // (past the end: the last tile again), so "vmcnt(2)" always means "everything but the newest pair".
-    v4i ga0, ga1, gb0, gb1;
-    auto fetch = [&](int tile, v4i& r0, v4i& r1) {
-        const uint4* p = tsrc + (int64_t)min(tile, max(ntiles - 1, 0)) * 512 + tid;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r0) : "v"(p) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r1) : "v"(p + 256) : "memory");
+    // train tiles go from memory straight into the LDS ring (global_load_lds_dwordx4: the wave's 64 lanes fill one
+    // contiguous KiB at M0; wave w owns KiB 2w and 2w + 1 of a tile), kMfmaAhead tiles ahead: a tile's first reader
+    // in an XCD waits for HBM, and at 0.7 us per tile two tiles of distance did not cover that (the kernel ran at
+    // the speed of its loads: 88 us with them, 66 without).  The loads and their counted waits are inline asm --
+    // hipcc would drain the queue at every barrier.  Every step issues exactly two loads (past the end: the last tile
+    // again; four per pair of tiles), so "vmcnt(2 (kMfmaAhead - 2))" always means "the next two tiles have landed".
+    const uint32_t ldsWave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&tileB[0][wave * 128]);
+    auto issue = [&](int tile) {
+        const uint4* p = tsrc + (int64_t)min(tile, ntiles - 1) * 512 + wave * 128 + lane;
+        const uint32_t dst = ldsWave + (uint32_t)(tile % kMfmaRing) * 8192u;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
     };
-    // (tied to the last key of the tile so that the wait stays behind the tile's arithmetic)
-    auto landed = [&](v4i& r0, v4i& r1, int& after) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(r0), "+v"(r1), "+v"(after) :: "memory"); };
-    if (ntiles > 0) { tileB[0][tid] = tsrc[tid]; tileB[0][tid + 256] = tsrc[tid + 256]; }
-    // queries negated (+-1 bytes: x ^ 0xFE), so the accumulator is -(a . b) = 2 * Hamming - 256 and the key is one
-    // v_lshl_add; using the fragments here also retires their loads before the asm loads start counting
+    // (tied to the last key of the step so that the wait stays behind the step's arithmetic)
+    auto landed = [&](int& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(2 * (kMfmaAhead - 2)) : "memory"); };
+    // queries negated (+-32 bytes: x ^ 0xC0): the accumulator is -(a . b); using the fragments here also retires
+    // their loads before the asm loads start counting
 #pragma unroll
     for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-        for (int s = 0; s < 8; s++) A[qb][s] ^= (int)0xFEFEFEFE;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fetch(1, gb0, gb1);
-    __syncthreads();
-
-    auto tile_step = [&](int t, int slot) {
-        const v4i* bt = (const v4i*)tileB[slot];
-        v4i Bf[8];
-#pragma unroll
-        for (int s = 0; s < 8; s++) Bf[s] = bt[s * 64 + lane];
-        v16i acc0 = {}, acc1 = {};
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], Bf[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], Bf[s], acc1, 0, 0, 0);
+            Q[qb][s] ^= (int)0xC0C0C0C0;
+            asm volatile("" : "+v"(Q[qb][s]));  // pinned here: sunk below the tile loads, hipcc's own wait for Q would drain them
         }
-        const int j = (tile0 + t) * 32 + (lane & 31);
-        const int jv = j < nt ? j : 0x3FFFFFFF;  // rows past the end decode to a distance >= 256: never taken
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const v16i rowIdx = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+    int b0 = kMfmaEmpty, s0 = kMfmaEmpty, b1 = kMfmaEmpty, s1 = kMfmaEmpty;      // keys relative to the tile folded last
+    int B0 = kMfmaEmpty, S0 = kMfmaEmpty, B1 = kMfmaEmpty, S1 = kMfmaEmpty;      // H << 16 | j, of the epochs flushed so far
+    int nfold = 0;
+    auto products = [&](int slot, v16i& a0, v16i& a1) {
+        const v4i* bt = (const v4i*)tileB[slot];
+        v4i T[8];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            // compiler-visible VALU op on the accumulator: hipcc pads the MFMA -> VALU read hazard itself
-            // (an inline-asm consumer would read the accumulator too early)
-            const int k0 = (acc0[r] << 15) + jv, k1 = (acc1[r] << 15) + jv;
-            second[0][r] = med3i(best[0][r], k0, second[0][r]);
-            best[0][r] = min(best[0][r], k0);
-            second[1][r] = med3i(best[1][r], k1, second[1][r]);
-            best[1][r] = min(best[1][r], k1);
+        for (int s = 0; s < 8; s++) T[s] = bt[s * 64 + lane];
+        a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[0], Q[0][0], rowIdx, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[0], Q[1][0], rowIdx, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 8; s++) {
+            a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[s], Q[0][s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[s], Q[1][s], a1, 0, 0, 0);
         }
     };
-    int slot = 0;  // ring slot of tile t
-    for (int t = 0; t < ntiles; t += 2) {
-        // even tile t: fetch t+2 into ga, compute t, park t+1 (gb) in the ring
-        fetch(t + 2, ga0, ga1);
-        tile_step(t, slot);
-        const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-        landed(gb0, gb1, second[1][15]);
-        ((v4i*)tileB[s1])[tid] = gb0; ((v4i*)tileB[s1])[tid + 256] = gb1;
+    auto flush = [&]() {  // relative keys of this epoch -> absolute, merged behind the earlier epochs (which win ties)
+        const int now = tile0 + nfold - 1;
+        const int cb0 = mfma_key_abs(b0, now, half), cs0 = mfma_key_abs(s0, now, half);
+        const int cb1 = mfma_key_abs(b1, now, half), cs1 = mfma_key_abs(s1, now, half);
+        S0 = min(max(B0, cb0), min(S0, cs0)); B0 = min(B0, cb0);
+        S1 = min(max(B1, cb1), min(S1, cs1)); B1 = min(B1, cb1);
+        b0 = s0 = b1 = s1 = kMfmaEmpty;
+    };
+    auto fold = [&](const v16i& a0, const v16i& a1) {
+        // compiler-visible VALU ops on the accumulator: hipcc pads the MFMA -> VALU read hazard itself
+        // (an inline-asm consumer would read the accumulator too early)
+        b0 -= 16; s0 -= 16; b1 -= 16; s1 -= 16;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            s0 = med3i(b0, a0[r], s0);
+            b0 = min(b0, a0[r]);
+            s1 = med3i(b1, a1[r], s1);
+            b1 = min(b1, a1[r]);
+        }
+        if ((++nfold & 63) == 0) flush();
+    };
+    auto fold_last = [&](const v16i& a0, const v16i& a1) {  // the last tile may hold rows past the end of the frame
+        b0 -= 16; s0 -= 16; b1 -= 16; s1 -= 16;
+        const int jrow = (tile0 + ntiles - 1) * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const bool in = jrow + (r & 3) + 8 * (r >> 2) < nt;
+            const int k0 = in ? a0[r] : kMfmaEmpty, k1 = in ? a1[r] : kMfmaEmpty;
+            s0 = med3i(b0, k0, s0);
+            b0 = min(b0, k0);
+            s1 = med3i(b1, k1, s1);
+            b1 = min(b1, k1);
+        }
+        nfold++;
+        flush();
+    };
+
+    if (ntiles > 0) {
+        v16i accE0, accE1, accO0, accO1;
+#pragma unroll
+        for (int t = 0; t < kMfmaAhead; t++) issue(t);
+        landed(s1);
         __syncthreads();
-        if (t + 1 >= ntiles) break;
-        // odd tile t+1: fetch t+3 into gb, compute t+1, park t+2 (ga)
-        fetch(t + 3, gb0, gb1);
-        tile_step(t + 1, s1);
-        landed(ga0, ga1, second[1][15]);
-        ((v4i*)tileB[s2])[tid] = ga0; ((v4i*)tileB[s2])[tid + 256] = ga1;
-        __syncthreads();
-        slot = s2;
+        // two tiles per barrier: tile a's products into one accumulator set while the other (tile a - 1) is folded,
+        // then the same with the sets exchanged
+        auto pair_step = [&](int a, auto first) {
+            issue(a + kMfmaAhead);
+            issue(a + kMfmaAhead + 1);
+            products(a % kMfmaRing, accE0, accE1);
+            if (!decltype(first)::value) fold(accO0, accO1);
+            if (a + 1 < ntiles) {
+                products((a + 1) % kMfmaRing, accO0, accO1);
+                fold(accE0, accE1);
+            }
+            landed(s1);
+            __syncthreads();
+        };
+        pair_step(0, std::true_type());
+        for (int a = 2; a < ntiles; a += 2) pair_step(a, std::false_type());
+        if (ntiles & 1) fold_last(accE0, accE1); else fold_last(accO0, accO1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // merge the 32 residue classes of every query row (lanes of one half-wave); lane l keeps the row of
-    // (query block (l >> 4) & 1, accumulator element l & 15), so the acceptance rule runs once, on all 64 lanes
-    int myB = 0x7FFFFFFF, myS = 0x7FFFFFFF;
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int b = best[qb][r], s2 = second[qb][r];
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) {
-                const int ob = __shfl_xor(b, m), os = __shfl_xor(s2, m);
-                s2 = min(max(b, ob), min(s2, os));
-                b = min(b, ob);
-            }
-            if ((lane & 31) == qb * 16 + r) { myB = b; myS = s2; }
-        }
+    // the two halves of the wave hold the two halves of every tile's rows: merge lane l with lane l ^ 32; then the
+    // lower half-wave takes the rows of query block 0, the upper that of block 1, and the acceptance rule runs on all
+    // 64 lanes
     {
-        const int qb = (lane >> 4) & 1, r = lane & 15;
-        const int qi = q0 + wave * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int oB0 = __shfl_xor(B0, 32), oS0 = __shfl_xor(S0, 32), oB1 = __shfl_xor(B1, 32), oS1 = __shfl_xor(S1, 32);
+        const int mS0 = min(max(B0, oB0), min(S0, oS0)), mB0 = min(B0, oB0);
+        const int mS1 = min(max(B1, oB1), min(S1, oS1)), mB1 = min(B1, oB1);
+        const int myB = half ? mB1 : mB0, myS = half ? mS1 : mS0;
+        const int qi = q0 + wave * 64 + lane;  // = block (lane >> 5), row lane & 31
         if (qi < nq) {
-            const uint32_t h1 = ((uint32_t)myB + (1u << 23)) >> 16, h2 = ((uint32_t)myS + (1u << 23)) >> 16;  // unsigned: an empty train slot leaves 0x7FFFFFFF
+            const uint32_t h1 = (uint32_t)myB >> 16, h2 = (uint32_t)myS >> 16;  // empty: 0x7FFF
             const uint32_t k1 = h1 >= 256u ? 0xFFFFFFFFu : ((h1 << 20) | ((uint32_t)myB & 0xFFFFu));
             const uint32_t k2 = ((h2 >= 256u ? 256u : h2) << 20) | 0xFFFFFu;
             if (nchunks > 1) partial[((int64_t)f * nchunks + chunk) * partialPitch + qi] = make_uint2(k1, k2);
