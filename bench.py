@@ -754,7 +754,7 @@ def run_rank(args):
             nkp = float(np.mean([g[1] for g in gathered]))
             mfmas = B * int(np.ceil(nkp / 256.0)) * 4 * int(np.ceil(nkp / 32.0)) * 16
             mm = {"kernel": "k_match_mfma", "bound": "mfma", "peak": 3944.0, "unit": "TOP/s", "mfma_per_step": mfmas, "ops_per_step": mfmas * 65536.0,
-                  "what": "exact +-1 int8 product = 256 - 2 Hamming; 2 x 32 x 32 x 32 ops per v_mfma_i32_32x32x32_i8"}
+                  "what": "exact +-32 int8 product = 1024 (256 - 2 Hamming), the accumulator IS the match key; 2 x 32 x 32 x 32 ops per v_mfma_i32_32x32x32_i8"}
             for tag, kms in (("isolated", iso["kernel_ms_per_step"]), ("overlapped", out["roofline"].get("kernel_ms_per_step_all_bracketed", {}))):
                 if kms.get("k_match_mfma"):
                     a = mfmas * 65536.0 / (kms["k_match_mfma"] * 1e-3) / 1e12

@@ -6,7 +6,7 @@
 // 256-bit descriptors are 8 dwords; distance = 8 x (v_xor + v_bcnt) in the windowed searches (one lane owns one
 // query and keeps (best, second, index); the train descriptor is wave-uniform and comes in through scalar loads).
 // The all-pairs scan of the stream matcher runs on the matrix cores instead (k_expand_desc + k_match_mfma): with
-// +-1 bytes a . b = 256 - 2 * Hamming exactly.
+// +-32 bytes a . b = 1024 (256 - 2 * Hamming) exactly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -152,7 +152,7 @@ __device__ __forceinline__ void accept_one(const AcceptArgs& a, int f, int qi, u
 }
 
 // ------------------------------------------------------------------ brute-force scan on the matrix cores
-// The scan is a binary GEMM: with descriptors expanded to +-1 bytes, a . b = 256 - 2 * Hamming(a, b), exactly, in
+// The scan is a binary GEMM: with descriptors expanded to +-32 bytes, a . b = 1024 (256 - 2 * Hamming(a, b)), exactly, in
 // int32.  The popcount formulation above is bound by the v_bcnt issue rate (tools/ubench/valu_rate.hip); the
 // v_mfma_i32_32x32x32_i8 formulation leaves three VALU ops per pair (key, min, med3).
 //
@@ -207,7 +207,8 @@ constexpr int kMfmaRowsPerBlock = 256;  // 4 waves x 2 query blocks of 32
 // 63 tiles each become 72 walking 8.
 constexpr int kMfmaEmpty = 0x7FFFFFFF;
 constexpr int kMfmaRing = 8;  // train tiles in LDS (64 KB)
-constexpr int kMfmaAhead = 6; // tiles in flight ahead of the one being multiplied
+constexpr int kMfmaGroup = 2; // tiles per barrier (even)
+constexpr int kMfmaAhead = kMfmaRing - kMfmaGroup; // a group's loads are issued this many tiles ahead of its first tile
 __device__ __forceinline__ int mfma_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 // relative key (low field -16 d + r, d = tiles before `tileNow`) -> H << 16 | j; anything that is not a product (the
 // initial value, a masked row) stays "empty"
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
                      "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
     };
     // (tied to the last key of the step so that the wait stays behind the step's arithmetic)
-    auto landed = [&](int& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(2 * (kMfmaAhead - 2)) : "memory"); };
+    auto landed = [&](int& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(2 * (kMfmaAhead - kMfmaGroup)) : "memory"); };
     // queries negated (+-32 bytes: x ^ 0xC0): the accumulator is -(a . b); using the fragments here also retires
     // their loads before the asm loads start counting
 #pragma unroll
@@ -344,20 +345,22 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
         __syncthreads();
         // two tiles per barrier: tile a's products into one accumulator set while the other (tile a - 1) is folded,
         // then the same with the sets exchanged
-        auto pair_step = [&](int a, auto first) {
-            issue(a + kMfmaAhead);
-            issue(a + kMfmaAhead + 1);
+        auto group_step = [&](int a, auto first) {
+#pragma unroll
+            for (int i = 0; i < kMfmaGroup; i++) issue(a + kMfmaAhead + i);
             products(a % kMfmaRing, accE0, accE1);
             if (!decltype(first)::value) fold(accO0, accO1);
-            if (a + 1 < ntiles) {
-                products((a + 1) % kMfmaRing, accO0, accO1);
-                fold(accE0, accE1);
+#pragma unroll
+            for (int i = 1; i < kMfmaGroup; i++) {
+                if (a + i >= ntiles) break;
+                if (i & 1) { products((a + i) % kMfmaRing, accO0, accO1); fold(accE0, accE1); }
+                else       { products((a + i) % kMfmaRing, accE0, accE1); fold(accO0, accO1); }
             }
             landed(s1);
             __syncthreads();
         };
-        pair_step(0, std::true_type());
-        for (int a = 2; a < ntiles; a += 2) pair_step(a, std::false_type());
+        group_step(0, std::true_type());
+        for (int a = kMfmaGroup; a < ntiles; a += kMfmaGroup) group_step(a, std::false_type());
         if (ntiles & 1) fold_last(accE0, accE1); else fold_last(accO0, accO1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

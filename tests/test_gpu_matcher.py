@@ -76,6 +76,30 @@ def test_bruteforce_tile_boundaries(gm, oracle, nq, nt):
         assert n == nw and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("nq,nt", [(300, 2048), (70, 2049), (257, 4097), (40, 5000), (33, 65535)])
+def test_bruteforce_more_than_sixty_four_tiles(gm, oracle, nq, nt):
+    """the scan's running keys carry the tile as an offset that lasts 64 tiles; beyond that they are decoded and merged
+    epoch by epoch: duplicates planted across the epoch edges (the lowest index wins, an equal second blocks the ratio
+    test), best and second in different epochs"""
+    rng = np.random.default_rng(nq + nt)
+    t = random_descriptors(rng, nt)
+    q = noisy_copies(rng, t[rng.integers(0, nt, nq)], 9)
+    t[nt - 1] = t[7]                 # first and last epoch
+    q[0] = t[7]
+    if nt > 2100:
+        t[2050] = t[2040]            # either side of the first epoch edge
+        q[1] = t[2040]; q[1, 5] ^= 16
+        q[2] = t[nt - 3]; q[2, 0] ^= 3    # best in the last epoch, second elsewhere
+    qa = rng.uniform(0, 360, nq).astype(np.float32)
+    ta = rng.uniform(0, 360, nt).astype(np.float32)
+    from orbslamm_amd import ORBmatcher
+    for ori in (True, False):
+        got, n = ORBmatcher(0.7, ori, device=0).match_bruteforce(q, qa, t, ta)
+        want, nw = oracle.match_bruteforce(q, qa, t, ta, 0.7, 50, ori)
+        assert n == nw and np.array_equal(got, want)
+    assert got[0] == -1 and (nt <= 2100 or (got[1] == -1 and got[2] == nt - 3))  # (without the rotation check)
+
+
 def test_bruteforce_wide_train_fallback(gm, oracle):
     """more than 65535 train features: the popcount scan (k_match_best2) takes over"""
     rng = np.random.default_rng(77)

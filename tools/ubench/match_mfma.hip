@@ -19,7 +19,7 @@ int main()
     orbm::AcceptArgs aa = {io, io, 1, 0, 0.7f, 50, 1, d_match, (int64_t)maxKp, d_bin, d_hist};
     std::vector<uint8_t> hx((B + 1) * xPitch);
     uint32_t s = 12345;
-    for (auto& b : hx) { s = s * 1664525u + 1013904223u; b = (s >> 24) & 1 ? 0x01 : 0xFF; }
+    for (auto& b : hx) { s = s * 1664525u + 1013904223u; b = (s >> 24) & 1 ? 0x20 : 0xE0; }
     CK(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
     std::vector<int32_t> hc(B + 1, n);
     CK(hipMemcpy(d_count, hc.data(), (B + 1) * 4, hipMemcpyHostToDevice));
