@@ -327,19 +327,36 @@ template <int TSB> __device__ __forceinline__ void ring_load(const uint8_t* __re
     r[12] = p[RingOff<TSB, 12>::v]; r[13] = p[RingOff<TSB, 13>::v]; r[14] = p[RingOff<TSB, 14>::v]; r[15] = p[RingOff<TSB, 15>::v];
 }
 
-// one side only: sgn = +1 dark arcs (d = v - p), -1 bright arcs (d = p - v)
-template <int TSB> __device__ __forceinline__ int fast_S_side(const uint8_t* __restrict__ p, int sgn)
+__device__ __forceinline__ int arc_min_of_max(const int (&d)[16])
 {
-    int r[16], d[16];
-    ring_load<TSB>(p, r);
-    const int sv = sgn * (int)p[0], ns = -sgn;
+    int m3[16], m9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++)  // d = sgn * (v - r): one full-rate VOP3 op (the compiler splits it into mul + sub)
-        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d[k]) : "v"(r[k]), "v"(ns), "v"(sv));
-    return max(arc_max_of_min(d), 0);
+    for (int k = 0; k < 16; k++) m3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m9[k] = max3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+    int a5[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a5[k] = min3i(m9[3 * k], m9[3 * k + 1], m9[3 * k + 2]);
+    return min(min3i(a5[0], a5[1], a5[2]), min3i(a5[3], a5[4], m9[15]));
 }
 
-// both sides (the rare pixel that passes the compass test on both)
+// one side only, on the ring's raw bytes (no difference per ring pixel):
+//   dark arcs   S = max_arc min_k (v - p_k) = v - min_arc max_k p_k
+//   bright arcs S = max_arc min_k (p_k - v) = max_arc min_k p_k - v
+template <int TSB> __device__ __forceinline__ int fast_S_dark(const uint8_t* __restrict__ p)
+{
+    int r[16];
+    ring_load<TSB>(p, r);
+    return max((int)p[0] - arc_min_of_max(r), 0);
+}
+template <int TSB> __device__ __forceinline__ int fast_S_bright(const uint8_t* __restrict__ p)
+{
+    int r[16];
+    ring_load<TSB>(p, r);
+    return max(arc_max_of_min(r) - (int)p[0], 0);
+}
+
+// both sides (the cell whose one-sided lists would not fit)
 template <int TSB> __device__ __forceinline__ int fast_S(const uint8_t* __restrict__ p)
 {
     int r[16], d[16];
@@ -447,9 +464,12 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             for (int i = lane; i < ch * (TSD / 2); i += 64) sm64[i] = make_uint2(0u, 0u);
             __syncthreads();
         }
-        // stage 1: list entries are (side << 14 | y << 7 | x), side 1 = bright.  Ballots are taken of
-        // bare compares and combined on the scalar unit (a ballot of a derived bool costs two VALU ops).
-        int nA = 0, nB = 0;
+        // stage 1: two lists of (y << 7 | x) entries -- the pixels that pass the compass test on the dark side grow one up
+        // from the bottom of the buffer, those that pass on the bright side one down from its top (the few that pass on both
+        // are in both: a pixel is a corner on one side at most, so its two visits never both write).  Ballots are taken of
+        // bare compares and combined on the scalar unit (a ballot of a derived bool costs two VALU ops).  Lists that
+        // meet in the middle overwrite each other -- inside the buffer -- and are thrown away below.
+        int nD = 0, nBt = 0;
         for (int xb = 0; xb < dw; xb += 32) {
             const int x4 = xb + 4 * (lane & 7);
             uint64_t mX[4];
@@ -470,70 +490,66 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                     const int hi = min(max(pn, ps), max(pw, pe));   // bright: hi - v > th
                     const int lo = max(min(pn, ps), min(pw, pe));   // dark:   v - lo > th
                     const bool br = hi - v > th, dk = v - lo > th;
-                    const uint64_t mIn = mX[k] & mY, mBr = ballot64(br), mDk = ballot64(dk);
-                    const uint64_t balA = (mBr ^ mDk) & mIn, balB = mBr & mDk & mIn;
+                    const uint64_t mIn = mX[k] & mY, mBr = ballot64(br) & mIn, mDk = ballot64(dk) & mIn;
                     const bool in = rowOk && x4 + k < dw;
                     const int e = (y << 7) | (x4 + k);
-                    if (balA) {
-                        if (in && br != dk) list[nA + lanes_below(balA)] = (uint16_t)(e | (br ? 0x4000 : 0));
-                        nA += __popcll(balA);
+                    if (mDk) {
+                        if (in && dk) list[nD + lanes_below(mDk)] = (uint16_t)e;
+                        nD += __popcll(mDk);
                     }
-                    if (balB) {
-                        if (in && br && dk) list[listCap - 1 - nB - lanes_below(balB)] = (uint16_t)e;
-                        nB += __popcll(balB);
+                    if (mBr) {
+                        if (in && br) list[listCap - 1 - nBt - lanes_below(mBr)] = (uint16_t)e;
+                        nBt += __popcll(mBr);
                     }
                 }
             }
         }
         __syncthreads();
 #ifdef ORBX_FAST_STATS
-        if (lane == 0) { atomicAdd(&g_fastStats[0 + 4 * pass], 1ull); atomicAdd(&g_fastStats[1 + 4 * pass], (unsigned long long)(nA + 2 * nB)); atomicAdd(&g_fastStats[8], (unsigned long long)(dw * dh)); }
+        if (lane == 0) { atomicAdd(&g_fastStats[0 + 4 * pass], 1ull); atomicAdd(&g_fastStats[1 + 4 * pass], (unsigned long long)(nD + nBt)); atomicAdd(&g_fastStats[8], (unsigned long long)(dw * dh)); }
 #endif
-        if (nA + nB == 0) { if (last) break; else continue; }
+        if (nD + nBt == 0) { if (last) break; else continue; }
 
-        // stage 2: exact score on the dense lists; pixels with S > th (the corners of this pass)
-        // are compacted in place: writes land at or below entries already consumed
+        // stage 2: exact score on the dense lists, each with the arithmetic of its side; pixels with S > th (the corners of
+        // this pass) are compacted in place: writes land at or below entries already consumed (the bright list is read in
+        // ascending addresses and starts at listCap - nBt >= nD)
         int nC = 0;
-        if (nA + 2 * nB <= listCap) {
-            // one stream of one-sided entries: the A list, then the B list taken once as dark and once as bright (a pixel
-            // is a corner on one side at most, so the two visits never both write).  The in-place compaction cannot reach
-            // the B entries while they are still to be read: nC <= nA + nB <= listCap - nB.
-            const int nV = nA + 2 * nB;
-            for (int i0 = 0; i0 < nV; i0 += 64) {
+        if (nD + nBt <= listCap) {
+            for (int i0 = 0; i0 < nD; i0 += 64) {
                 const int i = i0 + lane;
-                const bool act = i < nV;
-                int e = 0;
-                if (act) {
-                    if (i < nA) e = list[i];
-                    else { const int j = i - nA; e = j < nB ? list[listCap - nB + j] : (list[listCap - nB + (j - nB)] | 0x4000); }
-                }
-                const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
-                const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
+                const bool act = i < nD;
+                const int e = act ? list[i] : 0;
+                const int pos = pos0 + (e >> 7) * TSB + (e & 0x7F);
+                const int Sx = fast_S_dark<TSB>(tb + pos);
                 const bool corner = act && Sx > th;
-                const uint64_t bal = ballot64(Sx > th) & tail_mask(nV - i0);
-                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
+                const uint64_t bal = ballot64(Sx > th) & tail_mask(nD - i0);
+                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+                nC += __popcll(bal);
+            }
+            for (int i0 = 0; i0 < nBt; i0 += 64) {
+                const int i = i0 + lane;
+                const bool act = i < nBt;
+                const int e = act ? list[listCap - nBt + i] : 0;
+                const int pos = pos0 + (e >> 7) * TSB + (e & 0x7F);
+                const int Sx = fast_S_bright<TSB>(tb + pos);
+                const bool corner = act && Sx > th;
+                const uint64_t bal = ballot64(Sx > th) & tail_mask(nBt - i0);
+                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
                 nC += __popcll(bal);
             }
         } else {
-            for (int i0 = 0; i0 < nA; i0 += 64) {
+            // the lists ran into each other (a texture of saddle points: nearly every pixel passes on both sides): every
+            // detection pixel is scored on both sides instead -- the compass test is pruning, S > th decides
+            const int npx = dw * dh;
+            for (int i0 = 0; i0 < npx; i0 += 64) {
                 const int i = i0 + lane;
-                const bool act = i < nA;
-                const int e = act ? list[i] : 0;
-                const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
-                const int Sx = fast_S_side<TSB>(tb + pos, (e & 0x4000) ? -1 : 1);
-                const bool corner = act && Sx > th;
-                const uint64_t bal = ballot64(Sx > th) & tail_mask(nA - i0);
-                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)(e & 0x3FFF); }
-                nC += __popcll(bal);
-            }
-            for (int i0 = 0; i0 < nB; i0 += 64) {  // ascending addresses, see above
-                const int i = i0 + lane;
-                const bool act = i < nB;
-                const int e = act ? list[listCap - nB + i] : 0;
-                const int pos = pos0 + ((e >> 7) & 0x7F) * TSB + (e & 0x7F);
+                const bool act = i < npx;
+                const int y = act ? i / dw : 0, x = act ? i - y * dw : 0;
+                const int e = (y << 7) | x;
+                const int pos = pos0 + y * TSB + x;
                 const int Sx = fast_S<TSB>(tb + pos);
                 const bool corner = act && Sx > th;
-                const uint64_t bal = ballot64(Sx > th) & tail_mask(nB - i0);
+                const uint64_t bal = ballot64(Sx > th) & tail_mask(npx - i0);
                 if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
                 nC += __popcll(bal);
             }
