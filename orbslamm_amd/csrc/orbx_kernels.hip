@@ -401,6 +401,13 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
     int stride;
     const uint8_t* base = level_ptr(g, src, f, level, stride);
 
+#ifdef ORBX_FAST_STATS
+    unsigned long long tk0 = wall_clock64(), tk1;
+    const bool statCell = lane == 0 && (blockIdx.x & 63) == 0;  // one cell in 64: atomics on one address from every cell throttle the kernel they measure
+#define FAST_TICK(i) do { tk1 = wall_clock64(); if (statCell) atomicAdd(&g_fastStats[i], tk1 - tk0); tk0 = tk1; } while (0)
+#else
+#define FAST_TICK(i) do { } while (0)
+#endif
     uint32_t* tile = lds;                                           // [tileRows][TSD] dwords (+ slack)
     uint8_t* smap = (uint8_t*)(lds + tileRows * TSD + 4);           // same geometry, bytes
     uint16_t* list = (uint16_t*)(lds + 2 * (tileRows * TSD + 4));   // listCap entries
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
         for (int i = lane; i < ch * (TSD / 2); i += 64) sm64[i] = make_uint2(0u, 0u);
     }
     __syncthreads();
+    FAST_TICK(9);
 
     const int dw = cw - 6, dh = ch - 6;  // detection area
     const int th1 = g->iniTh < 0 ? 0 : (g->iniTh > 255 ? 255 : g->iniTh);
@@ -505,8 +513,9 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             }
         }
         __syncthreads();
+        FAST_TICK(10);
 #ifdef ORBX_FAST_STATS
-        if (lane == 0) { atomicAdd(&g_fastStats[0 + 4 * pass], 1ull); atomicAdd(&g_fastStats[1 + 4 * pass], (unsigned long long)(nD + nBt)); atomicAdd(&g_fastStats[8], (unsigned long long)(dw * dh)); }
+        if (statCell) { atomicAdd(&g_fastStats[0 + 4 * pass], 1ull); atomicAdd(&g_fastStats[1 + 4 * pass], (unsigned long long)(nD + nBt)); atomicAdd(&g_fastStats[8], (unsigned long long)(dw * dh)); }
 #endif
         if (nD + nBt == 0) { if (last) break; else continue; }
 
@@ -555,8 +564,9 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             }
         }
         __syncthreads();
+        FAST_TICK(11);
 #ifdef ORBX_FAST_STATS
-        if (lane == 0) atomicAdd(&g_fastStats[2 + 4 * pass], (unsigned long long)nC);
+        if (statCell) atomicAdd(&g_fastStats[2 + 4 * pass], (unsigned long long)nC);
 #endif
         if (nC == 0) { if (last) break; else continue; }
 
@@ -584,6 +594,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             }
             total += __popcll(bal);
         }
+        FAST_TICK(12);
         if (total > 0 || last) break;
     }
     if (lane == 0) *myCount = total;
