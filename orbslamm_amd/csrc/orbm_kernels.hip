@@ -184,7 +184,12 @@ __global__ __launch_bounds__(256) void k_expand_desc(MatchIO io, int slot0, int 
 __device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-constexpr int kMfmaRowsPerBlock = 256;  // 4 waves x 2 query blocks of 32
+#ifndef ORBM_MFMA_WAVES
+#define ORBM_MFMA_WAVES 4
+#endif
+constexpr int kMfmaWaves = ORBM_MFMA_WAVES;            // waves of a k_match_mfma workgroup (4 or 8), two query blocks of 32 each
+constexpr int kMfmaThreads = 64 * kMfmaWaves;
+constexpr int kMfmaRowsPerBlock = 64 * kMfmaWaves;
 
 // One workgroup = 256 queries of one frame pair; the train side streams through LDS in tiles of 32 features
 // (8 KiB, ring of 8 filled by LDS-direct loads, one barrier per two tiles); each wave holds two query blocks in registers (64 VGPRs).
@@ -206,7 +211,10 @@ constexpr int kMfmaRowsPerBlock = 256;  // 4 waves x 2 query blocks of 32
 // workgroup each, which leave their (k1, k2) keys in `partial` for k_match_accept to merge -- 9 workgroups walking
 // 63 tiles each become 72 walking 8.
 constexpr int kMfmaEmpty = 0x7FFFFFFF;
-constexpr int kMfmaRing = 8;  // train tiles in LDS (64 KB)
+constexpr int kMfmaRing = 2 * kMfmaWaves;             // train tiles in LDS: 64 KB per four waves, the CU's waves share 128 KB
+constexpr int kMfmaLdsBytes = kMfmaRing * 8192;
+constexpr int kMfmaLoads = 8 / kMfmaWaves;             // global_load_lds_dwordx4 (1 KiB) per wave and tile
+static_assert(kMfmaWaves == 4 || kMfmaWaves == 8, "a tile is 8 KiB: two or one KiB per wave");
 constexpr int kMfmaGroup = 2; // tiles per barrier (even)
 constexpr int kMfmaAhead = kMfmaRing - kMfmaGroup; // a group's loads are issued this many tiles ahead of its first tile
 __device__ __forceinline__ int mfma_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -220,13 +228,13 @@ __device__ __forceinline__ int mfma_key_abs(int k, int tileNow, int half)
     const int j = (tileNow - (63 - (low >> 4))) * 32 + mfma_row_of(r, half);
     return (H << 16) | j;
 }
-__global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict__ xdesc, int64_t xPitch,
+__global__ __launch_bounds__(kMfmaThreads, kMfmaWaves == 4 ? 2 : 1) void k_match_mfma(const uint8_t* __restrict__ xdesc, int64_t xPitch,
                                                       AcceptArgs acc, int nqb, int nframes,
                                                       uint2* __restrict__ partial, int64_t partialPitch)
 {
     const int32_t* __restrict__ count = acc.q.count;  // q.count and t.count index the same slot table here
     const int qslot0 = acc.qslot0, tslot0 = acc.tslot0;
-    __shared__ uint4 tileB[kMfmaRing][512];
+    extern __shared__ uint4 tileB[];  // [kMfmaRing][512]
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, so the query blocks of one frame
     // pair are given to one XCD and share that frame's train tiles in its L2
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -261,17 +269,23 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
     // the speed of its loads: 88 us with them, 66 without).  The loads and their counted waits are inline asm --
     // hipcc would drain the queue at every barrier.  Every step issues exactly two loads (past the end: the last tile
     // again; four per pair of tiles), so "vmcnt(2 (kMfmaAhead - 2))" always means "the next two tiles have landed".
-    const uint32_t ldsWave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&tileB[0][wave * 128]);
+    constexpr int kPerWave = 512 / kMfmaWaves;  // 16-byte items of a tile per wave
+    const uint32_t ldsWave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&tileB[wave * kPerWave]);
     auto issue = [&](int tile) {
-        const uint4* p = tsrc + (int64_t)min(tile, ntiles - 1) * 512 + wave * 128 + lane;
+        const uint4* p = tsrc + (int64_t)min(tile, ntiles - 1) * 512 + wave * kPerWave + lane;
         const uint32_t dst = ldsWave + (uint32_t)(tile % kMfmaRing) * 8192u;
         uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+        if constexpr (kMfmaLoads == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
     };
     // (tied to the last key of the step so that the wait stays behind the step's arithmetic)
-    auto landed = [&](int& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(2 * (kMfmaAhead - kMfmaGroup)) : "memory"); };
+    auto landed = [&](int& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(kMfmaLoads * (kMfmaAhead - kMfmaGroup)) : "memory"); };
     // queries negated (+-32 bytes: x ^ 0xC0): the accumulator is -(a . b); using the fragments here also retires
     // their loads before the asm loads start counting
 #pragma unroll
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint8_t* __restrict
     int B0 = kMfmaEmpty, S0 = kMfmaEmpty, B1 = kMfmaEmpty, S1 = kMfmaEmpty;      // H << 16 | j, of the epochs flushed so far
     int nfold = 0;
     auto products = [&](int slot, v16i& a0, v16i& a1) {
-        const v4i* bt = (const v4i*)tileB[slot];
+        const v4i* bt = (const v4i*)(tileB + slot * 512);
         v4i T[8];
 #pragma unroll
         for (int s = 0; s < 8; s++) T[s] = bt[s * 64 + lane];

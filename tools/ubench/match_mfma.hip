@@ -8,7 +8,7 @@
 int main()
 {
     const int B = 64, n = 2000, maxKp = 2104;
-    const int64_t xPitch = (int64_t)((maxKp + 255) / 256 * 256) * 256;
+    const int64_t xPitch = (int64_t)((maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock * orbm::kMfmaRowsPerBlock) * 256;
     uint8_t* d_x; int32_t* d_count; float* d_ang; int32_t *d_match, *d_hist; uint8_t* d_bin;
     CK(hipMalloc(&d_x, (B + 1) * xPitch));
     CK(hipMalloc(&d_count, (B + 1) * 4));
@@ -23,12 +23,13 @@ int main()
     CK(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
     std::vector<int32_t> hc(B + 1, n);
     CK(hipMemcpy(d_count, hc.data(), (B + 1) * 4, hipMemcpyHostToDevice));
+    CK(hipFuncSetAttribute((const void*)orbm::k_match_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, orbm::kMfmaLdsBytes));
     const int nqb = (maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0));
         for (int i = 0; i < 20; i++)
-            hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(256), 0, 0, (const uint8_t*)d_x, xPitch, aa, nqb, B, (uint2*)nullptr, (int64_t)0);
+            hipLaunchKernelGGL(orbm::k_match_mfma, dim3(8 * ((B + 7) / 8) * nqb), dim3(orbm::kMfmaThreads), orbm::kMfmaLdsBytes, 0, (const uint8_t*)d_x, xPitch, aa, nqb, B, (uint2*)nullptr, (int64_t)0);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("k_match_mfma: %.1f us per launch\n", ms * 1000 / 20);
