@@ -152,30 +152,37 @@ __device__ __forceinline__ void accept_one(const AcceptArgs& a, int f, int qi, u
 }
 
 // ------------------------------------------------------------------ brute-force scan on the matrix cores
-// The scan is a binary GEMM: with descriptors expanded to +-32 bytes, a . b = 1024 (256 - 2 * Hamming(a, b)), exactly, in
-// int32.  The popcount formulation above is bound by the v_bcnt issue rate (tools/ubench/valu_rate.hip); the
-// v_mfma_i32_32x32x32_i8 formulation leaves three VALU ops per pair (key, min, med3).
+// The scan is a binary GEMM: with descriptor bits expanded to +-1, a . b = 256 - 2 * Hamming(a, b).  +-1 are exact in
+// the 4-bit E2M1 format (0x2 / 0xA) of v_mfma_scale_f32_32x32x64_f8f6f4, the two block scales 2^5 make every product
+// +-1024, and sums of at most 256 of them plus a preset below 2^20 are integers the f32 accumulator holds exactly
+// (tools/ubench/mfma_fp4.hip checks the instruction against the host).  Against the int8 form (v_mfma_i32_32x32x32_i8 on
+// +-32 bytes, the first half of round 3) a descriptor is 128 bytes instead of 256 and an instruction of the same 19 ns
+// covers 64 elements instead of 32: half the products' time, half the tile bytes in LDS and from L2.  The popcount
+// formulation above is bound by the v_bcnt issue rate (tools/ubench/valu_rate.hip).
 //
-// Expanded layout of one slot: block b (32 features) at b*8192 bytes; inside a block the 16-element chunk c of
-// feature r sits at (c*32 + r)*16, i.e. MFMA step s (32 elements) is the contiguous KiB [s*1024, (s+1)*1024)
-// with lane l = (c&1)*32 + r owning 16 bytes -- one coalesced 16-byte load per lane and step.  A (queries)
-// and B (trains) fragments are read the same way, so the element order inside a step cancels out.
+// Expanded layout of one slot: block b (32 features) at b*4096 bytes; inside a block the 32-element chunk c of
+// feature r sits at (c*32 + r)*16, i.e. MFMA step s (64 elements) is the contiguous KiB [s*1024, (s+1)*1024)
+// with lane l = (c&1)*32 + r owning 16 bytes -- one coalesced 16-byte load per lane and step.  A and B fragments
+// are read the same way, so the element order inside a step cancels out.
+constexpr int kMfmaDescBytes = 128;  // one expanded descriptor
 __global__ __launch_bounds__(256) void k_expand_desc(MatchIO io, int slot0, int xslot0, uint8_t* __restrict__ xdesc, int64_t xPitch)
 {
     const int slot = slot0 + blockIdx.y;
     const int n = io.count[slot];
     const int t = blockIdx.x * 256 + threadIdx.x;  // (block, chunk, row)
-    const int blk = t >> 9, c = (t >> 5) & 15, r = t & 31;
+    const int blk = t >> 8, c = (t >> 5) & 7, r = t & 31;
     if (blk * 32 >= n) return;
     const int kp = blk * 32 + r;
     uint4 o = make_uint4(0, 0, 0, 0);
     if (kp < n) {
-        const uint32_t bits = *(const uint16_t*)(io.desc + (int64_t)slot * io.descPitch + (int64_t)kp * 32 + 2 * c);
-        auto pm1 = [](uint32_t b4) {  // 4 bits -> 4 bytes, set = +32, clear = -32
-            const uint32_t x = (b4 * 0x00204081u) & 0x01010101u;
-            return (x * 0x20u) | ((x ^ 0x01010101u) * 0xE0u);
+        const uint32_t bits = *(const uint32_t*)(io.desc + (int64_t)slot * io.descPitch + (int64_t)kp * 32 + 4 * c);
+        auto pm1 = [](uint32_t b8) {  // 8 bits -> 8 nibbles, set = +1 (0x2), clear = -1 (0xA)
+            uint32_t x = (b8 | (b8 << 12)) & 0x000F000Fu;
+            x = (x | (x << 6)) & 0x03030303u;
+            x = (x | (x << 3)) & 0x11111111u;       // bit i at 4 i
+            return 0x22222222u | ((x ^ 0x11111111u) << 3);
         };
-        o.x = pm1(bits & 15); o.y = pm1((bits >> 4) & 15); o.z = pm1((bits >> 8) & 15); o.w = pm1(bits >> 12);
+        o.x = pm1(bits & 255); o.y = pm1((bits >> 8) & 255); o.z = pm1((bits >> 16) & 255); o.w = pm1(bits >> 24);
     }
     ((uint4*)(xdesc + (int64_t)(xslot0 + blockIdx.y) * xPitch))[t] = o;
 }
@@ -184,57 +191,62 @@ __global__ __launch_bounds__(256) void k_expand_desc(MatchIO io, int slot0, int 
 __device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-#ifndef ORBM_MFMA_WAVES
-#define ORBM_MFMA_WAVES 4
-#endif
-constexpr int kMfmaWaves = ORBM_MFMA_WAVES;            // waves of a k_match_mfma workgroup (4 or 8), two query blocks of 32 each
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr int kMfmaWaves = 4;                          // waves of a k_match_mfma workgroup, two query blocks of 32 each
 constexpr int kMfmaThreads = 64 * kMfmaWaves;
 constexpr int kMfmaRowsPerBlock = 64 * kMfmaWaves;
 
-// One workgroup = 256 queries of one frame pair; the train side streams through LDS in tiles of 32 features
-// (8 KiB, ring of 8 filled by LDS-direct loads, one barrier per two tiles); each wave holds two query blocks in registers (64 VGPRs).
+// One workgroup = 256 queries of one frame pair; the train side streams through LDS in tiles of 32 features (4 KiB,
+// a ring filled by LDS-direct loads, one barrier per two tiles); each wave holds two query blocks in registers (32 VGPRs).
 //
 // The product is taken with the TRAIN tile as the A side and the queries as the B side: accumulator element r of lane l
 // is then train row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the tile against query l & 31 -- every lane's sixteen
 // elements belong to ONE query and arrive in ascending train index, tile after tile.  So the running (best, second) of
 // a query are two registers of its lane (and of lane + 32, merged once at the end) instead of two per accumulator
-// element, and the key needs no instruction at all: descriptors are expanded to +-32 bytes and the queries negated,
-// so a . b = 1024 (2 H - 256) exactly in int32, and the accumulators start from the constants r = 0..15:
-//     acc[r] = 1024 (2 H - 256) + r.
-// Before a tile is folded 16 is subtracted from both running keys, so a key of d tiles ago carries -16 d + r in its
-// low field: signed min = smallest H, then the EARLIEST tile, then the lowest row -- the reference's scan with its
-// strict < (ORBmatcher.cc:214-226 form).  -16 d + r > -1024 holds for 64 tiles; every 64 tiles the keys are decoded
-// to H << 16 | j and merged into absolute ones.  Per pair: v_min_i32 + v_med3_i32 (med3(best, key, second) = the new
-// second), nothing else.  The fold of tile t is written beside the products of tile t + 1 (two accumulator sets):
-// the VALU work of a wave sits in the shadow of its own MFMAs.
+// element, and the key needs no instruction at all: the queries are stored negated, every product is -+1024, and the
+// accumulators start from the constants 2^19 + r, r = 0..15:
+//     acc[r] = 2^19 + 1024 (2 H - 256) + r,
+// a positive float holding an integer below 2^20 -- floats of one sign order like their bit patterns, so the fold
+// compares those as integers.  Before a tile is folded 16 is subtracted from both running keys, so a key of d tiles ago
+// carries -16 d + r in its low field: min = smallest H, then the EARLIEST tile, then the lowest row -- the reference's
+// scan with its strict < (ORBmatcher.cc:214-226 form).  -16 d + r > -1024 holds for 64 tiles; every 62 tiles the keys
+// are decoded to H << 16 | j and merged into absolute ones.  Per pair: v_min_i32 + v_med3_i32 (med3(best, key, second) =
+// the new second), nothing else.  The fold of tile t is written beside the products of tile t + 1 (two accumulator
+// sets): the VALU work of a wave sits in the shadow of its own MFMAs.
 // Few frames (the one-frame-per-call entry): gridDim.y > 1 cuts the train side into chunks of whole tiles, one
 // workgroup each, which leave their (k1, k2) keys in `partial` for k_match_accept to merge -- 9 workgroups walking
 // 63 tiles each become 72 walking 8.
-constexpr int kMfmaEmpty = 0x7FFFFFFF;
-constexpr int kMfmaRing = 2 * kMfmaWaves;             // train tiles in LDS: 64 KB per four waves, the CU's waves share 128 KB
-constexpr int kMfmaLdsBytes = kMfmaRing * 8192;
-constexpr int kMfmaLoads = 8 / kMfmaWaves;             // global_load_lds_dwordx4 (1 KiB) per wave and tile
-static_assert(kMfmaWaves == 4 || kMfmaWaves == 8, "a tile is 8 KiB: two or one KiB per wave");
+constexpr int kMfmaEmpty = 0x7FFFFFFF;                 // absolute keys (H << 16 | j)
+constexpr int kMfmaEmptyRel = 0x7F7FFFFF;              // running keys: FLT_MAX (stays FLT_MAX under "- 16")
+constexpr int kMfmaTileBytes = 32 * kMfmaDescBytes;    // 4 KiB: one global_load_lds_dwordx4 per thread
+#ifndef ORBM_MFMA_RING
+#define ORBM_MFMA_RING 16
+#endif
+constexpr int kMfmaRing = ORBM_MFMA_RING;              // train tiles in LDS
+constexpr int kMfmaLdsBytes = kMfmaRing * kMfmaTileBytes;
 constexpr int kMfmaGroup = 2; // tiles per barrier (even)
 constexpr int kMfmaAhead = kMfmaRing - kMfmaGroup; // a group's loads are issued this many tiles ahead of its first tile
+static_assert((kMfmaRing & (kMfmaRing - 1)) == 0 && kMfmaAhead - kMfmaGroup <= 63, "ring slot by mask; vmcnt has six bits");
 __device__ __forceinline__ int mfma_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-// relative key (low field -16 d + r, d = tiles before `tileNow`) -> H << 16 | j; anything that is not a product (the
-// initial value, a masked row) stays "empty"
-__device__ __forceinline__ int mfma_key_abs(int k, int tileNow, int half)
+// running key (bits of the float 2^19 + 1024 (2 H - 256) - 16 d + r, d = tiles before `tileNow`) -> H << 16 | j; anything
+// that is not a product (the initial value, a masked row) stays "empty"
+__device__ __forceinline__ int mfma_key_abs(int bits, int tileNow, int half)
 {
-    if (k >= (1 << 29)) return kMfmaEmpty;
-    const int v = k + 1008, low = v & 1023, r = low & 15;
+    const float f = __int_as_float(bits);
+    if (!(f < 2097152.f)) return kMfmaEmpty;
+    const int v = (int)f - (1 << 19) + 1008, low = v & 1023, r = low & 15;
     const int H = ((v >> 10) + 256) >> 1;
     const int j = (tileNow - (63 - (low >> 4))) * 32 + mfma_row_of(r, half);
     return (H << 16) | j;
 }
-__global__ __launch_bounds__(kMfmaThreads, kMfmaWaves == 4 ? 2 : 1) void k_match_mfma(const uint8_t* __restrict__ xdesc, int64_t xPitch,
+__global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* __restrict__ xdesc, int64_t xPitch,
                                                       AcceptArgs acc, int nqb, int nframes,
                                                       uint2* __restrict__ partial, int64_t partialPitch)
 {
     const int32_t* __restrict__ count = acc.q.count;  // q.count and t.count index the same slot table here
     const int qslot0 = acc.qslot0, tslot0 = acc.tslot0;
-    extern __shared__ uint4 tileB[];  // [kMfmaRing][512]
+    extern __shared__ uint4 tileB[];  // [kMfmaRing][256]
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, so the query blocks of one frame
     // pair are given to one XCD and share that frame's train tiles in its L2
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -253,65 +265,66 @@ __global__ __launch_bounds__(kMfmaThreads, kMfmaWaves == 4 ? 2 : 1) void k_match
         if (qi < nq) partial[((int64_t)f * nchunks + chunk) * partialPitch + qi] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         return;
     }
+    constexpr int kTileItems = kMfmaTileBytes / 16;  // 16-byte items of a tile: one per thread
     const uint8_t* qx = xdesc + (int64_t)(qslot0 + f) * xPitch;
-    const uint4* tsrc = (const uint4*)(xdesc + (int64_t)(tslot0 + f) * xPitch) + (int64_t)tile0 * 512;
+    const uint4* tsrc = (const uint4*)(xdesc + (int64_t)(tslot0 + f) * xPitch) + (int64_t)tile0 * kTileItems;
     const int qblk0 = (q0 >> 5) + wave * 2;
 
-    v4i Q[2][8];
+    v4i Q[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; qb++)
 #pragma unroll
-        for (int s = 0; s < 8; s++) Q[qb][s] = *(const v4i*)(qx + (int64_t)(qblk0 + qb) * 8192 + s * 1024 + lane * 16);
+        for (int s = 0; s < 4; s++) Q[qb][s] = *(const v4i*)(qx + (int64_t)(qblk0 + qb) * kMfmaTileBytes + s * 1024 + lane * 16);
 
     // train tiles go from memory straight into the LDS ring (global_load_lds_dwordx4: the wave's 64 lanes fill one
-    // contiguous KiB at M0; wave w owns KiB 2w and 2w + 1 of a tile), kMfmaAhead tiles ahead: a tile's first reader
-    // in an XCD waits for HBM, and at 0.7 us per tile two tiles of distance did not cover that (the kernel ran at
-    // the speed of its loads: 88 us with them, 66 without).  The loads and their counted waits are inline asm --
-    // hipcc would drain the queue at every barrier.  Every step issues exactly two loads (past the end: the last tile
-    // again; four per pair of tiles), so "vmcnt(2 (kMfmaAhead - 2))" always means "the next two tiles have landed".
-    constexpr int kPerWave = 512 / kMfmaWaves;  // 16-byte items of a tile per wave
-    const uint32_t ldsWave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&tileB[wave * kPerWave]);
+    // contiguous KiB at M0; wave w owns KiB w of a tile), kMfmaAhead tiles ahead: a tile's first reader in an XCD
+    // waits for HBM, and a few tiles of distance do not cover that (int8 form, 0.65 us per tile: four ahead 0.094 ms,
+    // six ahead 0.081).  The loads and their counted waits are inline asm -- hipcc would drain the queue at every
+    // barrier.  Every step issues exactly one load per tile (past the end: the last tile again), so
+    // "vmcnt(kMfmaAhead - kMfmaGroup)" always means "the next two tiles have landed".
+    const uint32_t ldsWave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&tileB[wave * 64]);
     auto issue = [&](int tile) {
-        const uint4* p = tsrc + (int64_t)min(tile, ntiles - 1) * 512 + wave * kPerWave + lane;
-        const uint32_t dst = ldsWave + (uint32_t)(tile % kMfmaRing) * 8192u;
+        const uint4* p = tsrc + (int64_t)min(tile, ntiles - 1) * kTileItems + tid;
+        const uint32_t dst = ldsWave + (uint32_t)(tile & (kMfmaRing - 1)) * (uint32_t)kMfmaTileBytes;
         uint32_t keep;
-        if constexpr (kMfmaLoads == 2)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
-        else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
     };
     // (tied to the last key of the step so that the wait stays behind the step's arithmetic)
-    auto landed = [&](int& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(kMfmaLoads * (kMfmaAhead - kMfmaGroup)) : "memory"); };
-    // queries negated (+-32 bytes: x ^ 0xC0): the accumulator is -(a . b); using the fragments here also retires
-    // their loads before the asm loads start counting
+    auto landed = [&](int& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(kMfmaAhead - kMfmaGroup) : "memory"); };
+    // queries negated (E2M1 sign bits: x ^ 0x88888888): the accumulator counts -(a . b); using the fragments here also
+    // retires their loads before the asm loads start counting
 #pragma unroll
     for (int qb = 0; qb < 2; qb++)
 #pragma unroll
-        for (int s = 0; s < 8; s++) {
-            Q[qb][s] ^= (int)0xC0C0C0C0;
+        for (int s = 0; s < 4; s++) {
+            Q[qb][s] ^= (int)0x88888888;
             asm volatile("" : "+v"(Q[qb][s]));  // pinned here: sunk below the tile loads, hipcc's own wait for Q would drain them
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    const v16i rowIdx = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
-    int b0 = kMfmaEmpty, s0 = kMfmaEmpty, b1 = kMfmaEmpty, s1 = kMfmaEmpty;      // keys relative to the tile folded last
-    int B0 = kMfmaEmpty, S0 = kMfmaEmpty, B1 = kMfmaEmpty, S1 = kMfmaEmpty;      // H << 16 | j, of the epochs flushed so far
+    constexpr float kBias = 524288.f;  // 2^19: every key a positive float
+    const v16f rowIdx = {kBias, kBias + 1, kBias + 2, kBias + 3, kBias + 4, kBias + 5, kBias + 6, kBias + 7,
+                         kBias + 8, kBias + 9, kBias + 10, kBias + 11, kBias + 12, kBias + 13, kBias + 14, kBias + 15};
+    int b0 = kMfmaEmptyRel, s0 = kMfmaEmptyRel, b1 = kMfmaEmptyRel, s1 = kMfmaEmptyRel;  // keys relative to the tile folded last
+    int B0 = kMfmaEmpty, S0 = kMfmaEmpty, B1 = kMfmaEmpty, S1 = kMfmaEmpty;              // H << 16 | j, of the epochs flushed so far
     int nfold = 0;
-    auto products = [&](int slot, v16i& a0, v16i& a1) {
-        const v4i* bt = (const v4i*)(tileB + slot * 512);
-        v4i T[8];
+    auto mfma = [](const v4i& a, const v4i& b, const v16f& c) {  // fp4 x fp4 (cbsz = blgp = 4), block scales 2^5 each
+        const v8i a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 132, 0, 132);
+    };
+    auto products = [&](int slot, v16f& a0, v16f& a1) {
+        const v4i* bt = (const v4i*)(tileB + slot * kTileItems);
+        v4i T[4];
 #pragma unroll
-        for (int s = 0; s < 8; s++) T[s] = bt[s * 64 + lane];
-        a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[0], Q[0][0], rowIdx, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[0], Q[1][0], rowIdx, 0, 0, 0);
+        for (int s = 0; s < 4; s++) T[s] = bt[s * 64 + lane];
+        a0 = mfma(T[0], Q[0][0], rowIdx);
+        a1 = mfma(T[0], Q[1][0], rowIdx);
 #pragma unroll
-        for (int s = 1; s < 8; s++) {
-            a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[s], Q[0][s], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[s], Q[1][s], a1, 0, 0, 0);
+        for (int s = 1; s < 4; s++) {
+            a0 = mfma(T[s], Q[0][s], a0);
+            a1 = mfma(T[s], Q[1][s], a1);
         }
     };
     auto flush = [&]() {  // relative keys of this epoch -> absolute, merged behind the earlier epochs (which win ties)
@@ -320,28 +333,30 @@ __global__ __launch_bounds__(kMfmaThreads, kMfmaWaves == 4 ? 2 : 1) void k_match
         const int cb1 = mfma_key_abs(b1, now, half), cs1 = mfma_key_abs(s1, now, half);
         S0 = min(max(B0, cb0), min(S0, cs0)); B0 = min(B0, cb0);
         S1 = min(max(B1, cb1), min(S1, cs1)); B1 = min(B1, cb1);
-        b0 = s0 = b1 = s1 = kMfmaEmpty;
+        b0 = s0 = b1 = s1 = kMfmaEmptyRel;
     };
-    auto fold = [&](const v16i& a0, const v16i& a1) {
+    auto older = [](int bits) { return __float_as_int(__int_as_float(bits) - 16.f); };
+    auto fold = [&](const v16f& a0, const v16f& a1) {
         // compiler-visible VALU ops on the accumulator: hipcc pads the MFMA -> VALU read hazard itself
         // (an inline-asm consumer would read the accumulator too early)
-        b0 -= 16; s0 -= 16; b1 -= 16; s1 -= 16;
+        b0 = older(b0); s0 = older(s0); b1 = older(b1); s1 = older(s1);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            s0 = med3i(b0, a0[r], s0);
-            b0 = min(b0, a0[r]);
-            s1 = med3i(b1, a1[r], s1);
-            b1 = min(b1, a1[r]);
+            const int k0 = __float_as_int(a0[r]), k1 = __float_as_int(a1[r]);
+            s0 = med3i(b0, k0, s0);
+            b0 = min(b0, k0);
+            s1 = med3i(b1, k1, s1);
+            b1 = min(b1, k1);
         }
-        if ((++nfold & 63) == 0) flush();
+        ++nfold;  // (the epoch's flush is the caller's: a branch here parts the fold from the products it should run beside)
     };
-    auto fold_last = [&](const v16i& a0, const v16i& a1) {  // the last tile may hold rows past the end of the frame
-        b0 -= 16; s0 -= 16; b1 -= 16; s1 -= 16;
+    auto fold_last = [&](const v16f& a0, const v16f& a1) {  // the last tile may hold rows past the end of the frame
+        b0 = older(b0); s0 = older(s0); b1 = older(b1); s1 = older(s1);
         const int jrow = (tile0 + ntiles - 1) * 32 + 4 * half;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const bool in = jrow + (r & 3) + 8 * (r >> 2) < nt;
-            const int k0 = in ? a0[r] : kMfmaEmpty, k1 = in ? a1[r] : kMfmaEmpty;
+            const int k0 = in ? __float_as_int(a0[r]) : kMfmaEmptyRel, k1 = in ? __float_as_int(a1[r]) : kMfmaEmptyRel;
             s0 = med3i(b0, k0, s0);
             b0 = min(b0, k0);
             s1 = med3i(b1, k1, s1);
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(kMfmaThreads, kMfmaWaves == 4 ? 2 : 1) void k_match
     };
 
     if (ntiles > 0) {
-        v16i accE0, accE1, accO0, accO1;
+        v16f accE0, accE1, accO0, accO1;
 #pragma unroll
         for (int t = 0; t < kMfmaAhead; t++) issue(t);
         landed(s1);
@@ -362,19 +377,24 @@ __global__ __launch_bounds__(kMfmaThreads, kMfmaWaves == 4 ? 2 : 1) void k_match
         auto group_step = [&](int a, auto first) {
 #pragma unroll
             for (int i = 0; i < kMfmaGroup; i++) issue(a + kMfmaAhead + i);
-            products(a % kMfmaRing, accE0, accE1);
+            products(a & (kMfmaRing - 1), accE0, accE1);
             if (!decltype(first)::value) fold(accO0, accO1);
 #pragma unroll
             for (int i = 1; i < kMfmaGroup; i++) {
                 if (a + i >= ntiles) break;
-                if (i & 1) { products((a + i) % kMfmaRing, accO0, accO1); fold(accE0, accE1); }
-                else       { products((a + i) % kMfmaRing, accE0, accE1); fold(accO0, accO1); }
+                if (i & 1) { products((a + i) & (kMfmaRing - 1), accO0, accO1); fold(accE0, accE1); }
+                else       { products((a + i) & (kMfmaRing - 1), accE0, accE1); fold(accO0, accO1); }
             }
             landed(s1);
             __syncthreads();
         };
         group_step(0, std::true_type());
-        for (int a = kMfmaGroup; a < ntiles; a += kMfmaGroup) group_step(a, std::false_type());
+        // epochs of at most 62 tiles (the first holds tile 0's fold as well, the last fold_last's): 64 at most between flushes
+        for (int e0 = kMfmaGroup; e0 < ntiles; e0 += 62) {
+            const int e1 = min(ntiles, e0 + 62);
+            for (int a = e0; a < e1; a += kMfmaGroup) group_step(a, std::false_type());
+            flush();
+        }
         if (ntiles & 1) fold_last(accE0, accE1); else fold_last(accO0, accO1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -8,7 +8,7 @@
 int main()
 {
     const int B = 64, n = 2000, maxKp = 2104;
-    const int64_t xPitch = (int64_t)((maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock * orbm::kMfmaRowsPerBlock) * 256;
+    const int64_t xPitch = (int64_t)((maxKp + orbm::kMfmaRowsPerBlock - 1) / orbm::kMfmaRowsPerBlock * orbm::kMfmaRowsPerBlock) * orbm::kMfmaDescBytes;
     uint8_t* d_x; int32_t* d_count; float* d_ang; int32_t *d_match, *d_hist; uint8_t* d_bin;
     CK(hipMalloc(&d_x, (B + 1) * xPitch));
     CK(hipMalloc(&d_count, (B + 1) * 4));
@@ -19,7 +19,7 @@ int main()
     orbm::AcceptArgs aa = {io, io, 1, 0, 0.7f, 50, 1, d_match, (int64_t)maxKp, d_bin, d_hist};
     std::vector<uint8_t> hx((B + 1) * xPitch);
     uint32_t s = 12345;
-    for (auto& b : hx) { s = s * 1664525u + 1013904223u; b = (s >> 24) & 1 ? 0x20 : 0xE0; }
+    for (auto& b : hx) { s = s * 1664525u + 1013904223u; b = ((s >> 24) & 1 ? 0x2 : 0xA) | ((s >> 25) & 1 ? 0x20 : 0xA0); }
     CK(hipMemcpy(d_x, hx.data(), hx.size(), hipMemcpyHostToDevice));
     std::vector<int32_t> hc(B + 1, n);
     CK(hipMemcpy(d_count, hc.data(), (B + 1) * 4, hipMemcpyHostToDevice));
