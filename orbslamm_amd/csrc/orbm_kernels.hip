@@ -225,7 +225,7 @@ constexpr int kMfmaTileBytes = 32 * kMfmaDescBytes;    // 4 KiB: one global_load
 #endif
 constexpr int kMfmaRing = ORBM_MFMA_RING;              // train tiles in LDS
 constexpr int kMfmaLdsBytes = kMfmaRing * kMfmaTileBytes;
-constexpr int kMfmaGroup = 2; // tiles per barrier (even)
+constexpr int kMfmaGroup = 4; // tiles per barrier (even)
 constexpr int kMfmaAhead = kMfmaRing - kMfmaGroup; // a group's loads are issued this many tiles ahead of its first tile
 static_assert((kMfmaRing & (kMfmaRing - 1)) == 0 && kMfmaAhead - kMfmaGroup <= 63, "ring slot by mask; vmcnt has six bits");
 __device__ __forceinline__ int mfma_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -389,9 +389,10 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
             __syncthreads();
         };
         group_step(0, std::true_type());
-        // epochs of at most 62 tiles (the first holds tile 0's fold as well, the last fold_last's): 64 at most between flushes
-        for (int e0 = kMfmaGroup; e0 < ntiles; e0 += 62) {
-            const int e1 = min(ntiles, e0 + 62);
+        // epochs of whole groups, 64 - kMfmaGroup tiles at most (the first holds the first group's folds as well, the last fold_last's): 64 folds at most between flushes
+        constexpr int kEpoch = (64 - kMfmaGroup) / kMfmaGroup * kMfmaGroup;
+        for (int e0 = kMfmaGroup; e0 < ntiles; e0 += kEpoch) {
+            const int e1 = min(ntiles, e0 + kEpoch);
             for (int a = e0; a < e1; a += kMfmaGroup) group_step(a, std::false_type());
             flush();
         }
