@@ -748,17 +748,21 @@ def run_rank(args):
             out["roofline"]["pipeline_bytes_per_frame"] = bytes_frame
             out["roofline"]["pipeline_achieved_GBs"] = fps / world * bytes_frame / 1e9
             out["roofline"]["pipeline_frac"] = fps / world * bytes_frame / 1e9 / HBM_PEAK_GBS
-            # The one GEMM-shaped kernel gets the matrix-core yardstick: v_mfma_i32_32x32x32_i8 issued per step
-            # (query workgroups of 256 x 4 waves x train tiles of 32 x 16 MFMAs per tile and wave) x 65 536 ops each,
-            # over its time, against the dense int8 peak of the guide (>= 3944 TOPS).  An HBM fraction says nothing about it.
+            # The one GEMM-shaped kernel gets the matrix-core yardstick: v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 operands) issued
+            # per step (query workgroups of 256 x 4 waves x train tiles of 32 x 8 MFMAs per tile and wave) x 131 072 ops each,
+            # over its time, against the dense fp4 peak of the guide (~10 PFLOP/s; its micro-benchmark floor is 9 099).  An HBM
+            # fraction says nothing about it.  (The first half of round 3 ran it on v_mfma_i32_32x32x32_i8: twice the
+            # instructions for the same 135 GOP, priced against 3 944 TOP/s.)
             nkp = float(np.mean([g[1] for g in gathered]))
-            mfmas = B * int(np.ceil(nkp / 256.0)) * 4 * int(np.ceil(nkp / 32.0)) * 16
-            mm = {"kernel": "k_match_mfma", "bound": "mfma", "peak": 3944.0, "unit": "TOP/s", "mfma_per_step": mfmas, "ops_per_step": mfmas * 65536.0,
-                  "what": "exact +-32 int8 product = 1024 (256 - 2 Hamming), the accumulator IS the match key; 2 x 32 x 32 x 32 ops per v_mfma_i32_32x32x32_i8"}
+            mfmas = B * int(np.ceil(nkp / 256.0)) * 4 * int(np.ceil(nkp / 32.0)) * 8
+            FP4_PEAK = 10000.0
+            mm = {"kernel": "k_match_mfma", "bound": "mfma", "peak": FP4_PEAK, "unit": "TFLOP/s", "mfma_per_step": mfmas, "ops_per_step": mfmas * 131072.0,
+                  "what": "exact +-1 fp4 (E2M1) product, block scales 2^5: 1024 (256 - 2 Hamming) in the f32 accumulator, which IS the match key; "
+                          "2 x 32 x 32 x 64 ops per v_mfma_scale_f32_32x32x64_f8f6f4"}
             for tag, kms in (("isolated", iso["kernel_ms_per_step"]), ("overlapped", out["roofline"].get("kernel_ms_per_step_all_bracketed", {}))):
                 if kms.get("k_match_mfma"):
-                    a = mfmas * 65536.0 / (kms["k_match_mfma"] * 1e-3) / 1e12
-                    mm[tag] = {"ms_per_step": kms["k_match_mfma"], "achieved": a, "frac": a / 3944.0}
+                    a = mfmas * 131072.0 / (kms["k_match_mfma"] * 1e-3) / 1e12
+                    mm[tag] = {"ms_per_step": kms["k_match_mfma"], "achieved": a, "frac": a / FP4_PEAK}
             out["roofline"]["mfma"] = mm
             if sq_tab and args.config == "c3":
                 cyc, clk = sq_tab["cycles_per_valu_instr"], sq_tab["clock_ghz"] * 1e9
