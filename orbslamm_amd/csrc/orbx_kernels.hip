@@ -386,7 +386,7 @@ template <int TSB>
 __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const Cell* __restrict__ cells,
                                             FrameSrc src, uint64_t* __restrict__ cand,
                                             int32_t* __restrict__ cellCount, int32_t* __restrict__ errFlag,
-                                            int tileRows, int listCap, int nframes, int cell0)
+                                            int tileRows, int listCap, int smapPitch, int nframes, int cell0)
 {
     extern __shared__ uint32_t lds[];
     constexpr int TSD = TSB / 4;
@@ -409,8 +409,11 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
 #define FAST_TICK(i) do { } while (0)
 #endif
     uint32_t* tile = lds;                                           // [tileRows][TSD] dwords (+ slack)
-    uint8_t* smap = (uint8_t*)(lds + tileRows * TSD + 4);           // same geometry, bytes
-    uint16_t* list = (uint16_t*)(lds + 2 * (tileRows * TSD + 4));   // listCap entries
+    // score map: the detection area and a one-pixel apron of zeros, rows smapPitch bytes apart -- a map with the tile's own
+    // geometry was 0.9 KB more of the 6.3 KB that decide how many cells a CU holds
+    uint8_t* smap = (uint8_t*)(lds + tileRows * TSD + 4);
+    uint16_t* list = (uint16_t*)(smap + (((tileRows - 4) * smapPitch + 7) & ~7));   // listCap entries
+    uint8_t* const smapD = smap + smapPitch + 1;                    // S of detection pixel (x, y) at smapD[y * smapPitch + x]
     const uint8_t* tb = (const uint8_t*)tile;
 
     const int cw = c.w, ch = c.h;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
             }
         }
         uint2* sm64 = (uint2*)smap;
-        for (int i = lane; i < ch * (TSD / 2); i += 64) sm64[i] = make_uint2(0u, 0u);
+        for (int i = lane; i < ((ch - 4) * smapPitch + 7) >> 3; i += 64) sm64[i] = make_uint2(0u, 0u);
     }
     __syncthreads();
     FAST_TICK(9);
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
         if (pass) {  // the first pass's scores (all <= ... > th1) go: the map must hold zeros wherever S <= th
             __syncthreads();
             uint2* sm64 = (uint2*)smap;
-            for (int i = lane; i < ch * (TSD / 2); i += 64) sm64[i] = make_uint2(0u, 0u);
+            for (int i = lane; i < ((ch - 4) * smapPitch + 7) >> 3; i += 64) sm64[i] = make_uint2(0u, 0u);
             __syncthreads();
         }
         // stage 1: two lists of (y << 7 | x) entries -- the pixels that pass the compass test on the dark side grow one up
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const int Sx = fast_S_dark<TSB>(tb + pos);
                 const bool corner = act && Sx > th;
                 const uint64_t bal = ballot64(Sx > th) & tail_mask(nD - i0);
-                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+                if (corner) { smapD[(e >> 7) * smapPitch + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
                 nC += __popcll(bal);
             }
             for (int i0 = 0; i0 < nBt; i0 += 64) {
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const int Sx = fast_S_bright<TSB>(tb + pos);
                 const bool corner = act && Sx > th;
                 const uint64_t bal = ballot64(Sx > th) & tail_mask(nBt - i0);
-                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+                if (corner) { smapD[(e >> 7) * smapPitch + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
                 nC += __popcll(bal);
             }
         } else {
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const int Sx = fast_S<TSB>(tb + pos);
                 const bool corner = act && Sx > th;
                 const uint64_t bal = ballot64(Sx > th) & tail_mask(npx - i0);
-                if (corner) { smap[pos] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+                if (corner) { smapD[(e >> 7) * smapPitch + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
                 nC += __popcll(bal);
             }
         }
@@ -577,9 +580,11 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
         for (int i0 = 0; i0 < nC; i0 += 64) {
             const int i = i0 + lane;
             const int e = i < nC ? list[i] : 0;
-            const uint8_t* sp = smap + pos0 + (e >> 7) * TSB + (e & 0x7F);
+            const uint8_t* sp = smapD + (e >> 7) * smapPitch + (e & 0x7F);
+            const uint8_t* up = sp - smapPitch;
+            const uint8_t* dn = sp + smapPitch;
             const int sc = sp[0];
-            const int n0 = sp[-TSB - 1], n1 = sp[-TSB], n2 = sp[-TSB + 1], n3 = sp[-1], n4 = sp[1], n5 = sp[TSB - 1], n6 = sp[TSB], n7 = sp[TSB + 1];
+            const int n0 = up[-1], n1 = up[0], n2 = up[1], n3 = sp[-1], n4 = sp[1], n5 = dn[-1], n6 = dn[0], n7 = dn[1];
             const int m = max3i(max3i(n0, n1, n2), max3i(n3, n4, n5), max(n6, n7));
             const bool keep = i < nC && sc > th && sc >= 2 && sc > m;
             const uint64_t bal = ballot64(sc > m) & ballot64(sc > max(th, 1)) & tail_mask(nC - i0);
