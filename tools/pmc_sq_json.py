@@ -24,7 +24,7 @@ clock = []
 for db in sys.argv[2:]:
     c = sqlite3.connect(db)
     rows = c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name").fetchall()
-    nsteps = max([n for k, cn, n, v, d in rows if short(k) == "k_blur"] or [1])
+    nsteps = max([n for k, cn, n, v, d in rows if short(k) == "k_pyramid"] or [1])  # one launch per step when ORBX_SERIAL=1
     for k, cn, n, v, d in rows:
         k = short(k)
         if k.startswith("__amd"):
