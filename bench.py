@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-host-path", action="store_true", help="skip the (untimed) host-buffer entry measurements")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of two frames of the last timed step")
     ap.add_argument("--no-tracking-path", action="store_true", help="skip the (untimed) Tracking-shaped matcher measurements")
+    ap.add_argument("--no-live-streams", action="store_true", help="skip the (untimed) one-frame-per-robot-per-call measurements (examples/multi_robot)")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--no-replay", action="store_true", help="skip the untimed serialized replay (roofline.isolated); used under rocprofv3 so that its per-kernel averages are those of the timed launches")
     return ap.parse_args(argv)
@@ -480,6 +481,59 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
     return out
 
 
+def live_streams(cfg, dev_index=0, frames=600):
+    """The mode the reference actually runs (never `value`): ONE live frame per robot per iteration
+    (MultipleRobotsScenario/Examples/Monocular/mono_kitti.cc:80-101 -> Tracking::GrabImageMonocular, Tracking.cc:240-267;
+    the search of frame t needs only the pose predicted from frame t-1, Tracking.cc:905-936).  Measured by the native
+    program a maintainer would write against the C ABI (examples/multi_robot.cpp: one thread per robot, one extractor +
+    matcher + frame-set handle per robot, frames from a pinned camera ring unless stated), each configuration in a process
+    of its own, per-frame median / mean printed like mono_tum.cc:113-122:
+      one_robot.track       extract + Frame tail + SearchByProjection(Cur, Last, th = 15), the frame set attached to the
+                            extractor (one chain on the device), keypoints + descriptors + match table on the host
+      one_robot.track_d2    the same with the next frame submitted before this one is collected (tickets two deep)
+      one_robot.track_d2_two_queues   two deep, frame set NOT attached: the next frame's extraction on the extractor's
+                            queue runs beside this frame's search on the matcher's
+      one_robot.bf          extract + brute-force match vs previous frame (BASELINE.json's pair), one frame per call
+      robots_on_one_gpu     K robots = K threads on the one GPU, one frame per robot per call, and 8 cameras fed two per
+                            call by 4 threads (the GPU runs about four queues at a time: tools/live_scale_probe.sh)"""
+    import __graft_entry__ as ge
+    exe = ge.build_examples()
+    base = [exe, "--json", "--interval", "0", "--w", str(cfg["w"]), "--h", str(cfg["h"]), "--nfeat", str(cfg["nfeat"]), "--gpus", "1"]
+    env = dict(os.environ)   # (single-GPU runs only: the program takes device 0 of what this process sees)
+    keep = ("frames_per_s", "ms_median", "ms_mean", "ms_p99", "keypoints_mean", "matches_mean", "host_us_submit", "host_us_enqueue")
+
+    def run(*extra, n=frames):
+        try:
+            r = subprocess.run(base + ["--frames", str(n), "--warmup", "40"] + [str(a) for a in extra], capture_output=True, text=True, timeout=180, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                return {"error": (r.stderr or r.stdout)[-300:]}
+            d = json.loads(line[-1])
+            return {k: d[k] for k in keep}
+        except Exception as e:  # never lose the record over a secondary block
+            return {"error": repr(e)}
+
+    out = {"what": "examples/multi_robot (C ABI, one thread per robot, B = 1 per call, pinned camera ring unless stated); never `value`",
+           "one_robot": {
+               "track": run("--mode", "track"),
+               "track_pageable_frames": run("--mode", "track", "--pinned", 0),
+               "track_d2": run("--mode", "track", "--depth", 2),
+               "track_d2_two_queues": run("--mode", "track", "--depth", 2, "--attach", 0),
+               "bf": run("--mode", "bf"),
+               "bf_pageable_frames": run("--mode", "bf", "--pinned", 0),
+               "extract": run("--mode", "extract")},
+           "robots_on_one_gpu": {}}
+    for k in (2, 4, 8):
+        out["robots_on_one_gpu"]["track_%d_threads_x1" % k] = run("--mode", "track", "--robots", k, n=400)
+    out["robots_on_one_gpu"]["track_4_threads_x2_cameras"] = run("--mode", "track", "--robots", 4, "--per-call", 2, n=400)
+    out["robots_on_one_gpu"]["bf_4_threads_x1"] = run("--mode", "bf", "--robots", 4, n=400)
+    t = out["one_robot"]["track"]
+    if "ms_median" in t:
+        out["target"] = {"track_ms_median_le_0.20": bool(t["ms_median"] <= 0.20), "bf_ms_median_le_0.15": bool(out["one_robot"]["bf"].get("ms_median", 9) <= 0.15),
+                         "eight_cameras_ge_25k": bool(out["robots_on_one_gpu"]["track_4_threads_x2_cameras"].get("frames_per_s", 0) >= 25000)}
+    return out
+
+
 def pin_to_gpu_numa(dev_index):
     """Pin this rank to the cores of its GPU's NUMA node (os.sched_setaffinity): the HBM-resident headline does not
     care, the host-fed entries on a two-socket box do (staging copies and pinned buffers on the far socket cross the
@@ -783,6 +837,8 @@ def run_rank(args):
                 out["parity_check"]["per_rank_ok"] = [bool(g[4] > 0) for g in gathered]
         if world == 1 and not args.no_tracking_path and hasattr(ex, "extract_match_host"):
             out["tracking_path"] = tracking_path(ex, cfg, first_batch, dargs)
+        if world == 1 and real and not args.no_live_streams and not args.no_tracking_path:
+            out["live_streams"] = live_streams(cfg, dev_index)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, first_batch)
         line = json.dumps(out) + "\n"

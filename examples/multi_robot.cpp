@@ -1,0 +1,332 @@
+// multi_robot.cpp -- the reference's multi-robot main loop on the C ABI of liborbslamm_hip.so.
+//
+// Reference: /root/reference/MultipleRobotsScenario/Examples/Monocular/mono_kitti.cc:83-125 -- one System / tracking
+// thread per robot, each feeding ITS camera stream one frame per iteration (:88-101), per-frame times collected and
+// printed as median / mean at the end (SingleRobotScenario/Examples/Monocular/mono_tum.cc:113-122).  Here: one host
+// thread per robot, robot r on GPU r % N, one extractor handle (ORBextractor) + one matcher handle and frame set
+// (what Frame::Frame's tail and ORBmatcher::SearchByProjection need) per robot, nothing shared between robots.
+// Per frame a robot does what Tracking::GrabImageMonocular does on the hot path (SingleRobotScenario/src/Tracking.cc:240-267):
+//   Frame::Frame        ExtractORB -> UndistortKeyPoints -> AssignFeaturesToGrid   (src/Frame.cc:175-210)
+//   TrackWithMotionModel SearchByProjection(CurrentFrame, LastFrame, th = 15, mono)  (src/Tracking.cc:925-936)
+// with keypoints + descriptors and the match table back on the host (--mode track), or extract + brute-force match
+// against the previous frame (--mode bf, BASELINE.json's headline pair), or extraction alone (--mode extract).
+// The GPUs exchange nothing on the data path; once per reporting interval the robots' counters (a 64-byte record per
+// GPU) are gathered with ONE ncclAllGather over RCCL -- the only collective there is.
+//
+// Synthetic camera: a static scene of rectangles and discs on a canvas, a slowly panning viewport, additive noise
+// (the shape SURVEY.md 8d describes; SplitMix64, no Python).
+//
+// build:  hipcc -O2 -std=c++17 examples/multi_robot.cpp -Iinclude -Lorbslamm_amd -lorbslamm_hip -lrccl -Wl,-rpath,'$ORIGIN/../orbslamm_amd' -o examples/multi_robot
+// usage:  multi_robot [--gpus N] [--robots R] [--frames F] [--warmup W] [--mode track|bf|extract] [--depth 1|2]
+//                     [--per-call 1|2 (cameras whose frames one thread puts through the chain together)] [--attach 0|1] [--pinned 0|1] [--w 1241 --h 376 --nfeat 2000] [--interval 200] [--json]
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "orbslamm_hip.h"
+
+namespace {
+
+struct Args {
+    int gpus = 1, robots = 1, per_call = 1, frames = 600, warmup = 30, depth = 1, attach = 1, pinned = 1, w = 1241, h = 376, nfeat = 2000, interval = 200;
+    std::string mode = "track";
+    bool json = false;
+};
+
+// ---------------------------------------------------------------- synthetic camera
+struct SplitMix { uint64_t s; uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+                  int below(int n) { return (int)(next() % (uint64_t)n); } };
+
+static int tri(int a, int m) { a %= 2 * m; return a <= m ? a : 2 * m - a; }
+
+static std::vector<uint8_t> make_scene(int w, int h, int robot, int& cw, int& ch)
+{
+    cw = w + 64; ch = h + 16;
+    std::vector<uint8_t> c((size_t)cw * ch, 128);
+    SplitMix r{0x0B5A4000ull + (uint64_t)robot};
+    const int nshapes = std::max(200, (int)(4000.0 * w * h / (1241.0 * 376.0)));
+    for (int i = 0; i < nshapes; i++) {
+        const int x0 = r.below(cw), y0 = r.below(ch), sx = 4 + r.below(37), sy = 4 + r.below(37), val = r.below(256), kind = r.below(2);
+        if (kind == 0) {
+            for (int y = std::max(0, y0 - sy / 2); y <= std::min(ch - 1, y0 + sy / 2); y++)
+                for (int x = std::max(0, x0 - sx / 2); x <= std::min(cw - 1, x0 + sx / 2); x++) c[(size_t)y * cw + x] = (uint8_t)val;
+        } else {
+            const int rad = sx / 2;
+            for (int y = std::max(0, y0 - rad); y <= std::min(ch - 1, y0 + rad); y++)
+                for (int x = std::max(0, x0 - rad); x <= std::min(cw - 1, x0 + rad); x++)
+                    if ((y - y0) * (y - y0) + (x - x0) * (x - x0) <= rad * rad) c[(size_t)y * cw + x] = (uint8_t)val;
+        }
+    }
+    return c;
+}
+
+static void make_frame(const std::vector<uint8_t>& scene, int cw, int w, int h, int robot, int t, uint8_t* dst, int stride)
+{
+    const int ox = tri(2 * t, 64), oy = tri(t, 16);
+    SplitMix r{(0x5EED0000ull + (uint64_t)robot) * 100003ull + (uint64_t)t};
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = &scene[(size_t)(oy + y) * cw + ox];
+        uint8_t* d = dst + (size_t)y * stride;
+        for (int x = 0; x < w; x += 8) {
+            uint64_t bits = r.next();
+            for (int k = 0; k < 8 && x + k < w; k++, bits >>= 8) {
+                const int v = (int)s[x + k] + (int)((bits & 0xFF) % 9) - 4;
+                d[x + k] = (uint8_t)std::min(255, std::max(0, v));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- per-robot state and loop
+struct Stats {   // the record the GPUs gather (64 bytes)
+    int64_t frames, keypoints, matches, ns_busy;
+    uint64_t checksum;
+    int64_t pad[3];
+};
+static_assert(sizeof(Stats) == 64, "stats record");
+
+#define OX(call) do { int rc_ = (call); if (rc_ != 0) { fprintf(stderr, "robot %d: %s failed (%d): %s\n", robot, #call, rc_, orbx_last_error()); failed = true; return; } } while (0)
+
+struct Robot {
+    int robot = 0, device = 0;
+    const Args* a = nullptr;
+    std::vector<double> lat_ms;
+    Stats st{};
+    bool failed = false;
+    std::atomic<int64_t> live_frames{0}, live_kps{0}, live_matches{0};
+    double us_submit = 0, us_enqueue = 0, us_wait = 0;   // host time in orbx_submit_batch | build + track calls | collect + results (waiting included)
+
+    void run(std::atomic<int>& ready, std::atomic<bool>& go)
+    {
+        const Args& A = *a;
+        const bool track = A.mode == "track", bf = A.mode == "bf";
+        OrbxParams prm{A.nfeat, 1.2f, 8, 20, 7};
+        orbx_t* ex = nullptr;
+        const int P = A.per_call;   // cameras this thread feeds per call (their frames go through the chain together)
+        OX(orbx_create(&prm, A.w, A.h, P, device, &ex));
+        const int cap = orbx_max_keypoints(ex);
+        orbm_t* m = nullptr;
+        orbm_frameset_t* fs = nullptr;
+        if (track) {
+            OX(orbm_create(device, &m));
+            float sf[ORBX_MAX_LEVELS];
+            OX(orbx_scale_tables(ex, sf, nullptr, nullptr, nullptr));
+            const float K[4] = {718.856f, 718.856f, 607.1928f, 185.2157f}, D[5] = {0, 0, 0, 0, 0};
+            const float bounds[4] = {0.f, (float)A.w, 0.f, (float)A.h};
+            OrbmGrid g{0.f, 0.f, 64.f / (float)A.w, 48.f / (float)A.h, 64, 48};
+            OX(orbm_frameset_create(m, 4 * P, cap, K, D, &g, bounds, sf, orbx_levels(ex), &fs));
+            if (A.attach) OX(orbm_frameset_attach(fs, ex));
+        }
+        // the camera's ring buffer: 8 frames, pinned in the device layout (what a capture driver would fill) or pageable
+        // (camera j of this thread: frames j * nring .. of the buffer, scene of robot `robot * P + j`)
+        const int nring = 8;
+        uint8_t* ring = nullptr; int stride = A.w; size_t pitch = (size_t)A.w * A.h;
+        std::vector<uint8_t> pageable;
+        if (A.pinned) OX(orbx_host_alloc_frames(ex, nring * P, A.w, A.h, &ring, &stride, &pitch));
+        else { pageable.resize(pitch * nring * P); ring = pageable.data(); }
+        for (int j = 0; j < P; j++) {
+            int cw, ch;
+            const std::vector<uint8_t> scene = make_scene(A.w, A.h, robot * P + j, cw, ch);
+            for (int t = 0; t < nring; t++) make_frame(scene, cw, A.w, A.h, robot * P + j, t, ring + (size_t)(j * nring + t) * pitch, stride);
+        }
+        OrbxStreamOpts so{bf ? 1 : 0, 0.7f, 50, 1};
+        OrbmProjParams pp{4, 0.9f, 1, 100};
+        const int total = A.warmup + A.frames;
+        lat_ms.reserve(A.frames);
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+
+        using clk = std::chrono::steady_clock;
+        int pendingTicket = -1, pendingIdx = -1;
+        clk::time_point pendingT0{};
+        auto finish = [&](int idx, int ticket, clk::time_point t0, int back) {   // collect frame idx: keypoints / descriptors, then its match table (`back` searches behind the newest)
+            OrbxBatchView v{};
+            OX(orbx_collect_view(ex, ticket, &v));
+            int nm = 0, n = 0, nLast = 0;
+            uint64_t cs = 0;
+            for (int j = 0; j < P; j++) {
+                if (bf) nm += v.nmatch[j];
+                nLast = v.n[j]; n += nLast;
+                cs = cs * 31 + (uint64_t)nLast * 1315423911ull;
+                if (nLast > 0) { uint32_t d0; memcpy(&d0, v.desc + ((size_t)j * v.cap + (nLast - 1)) * 32, 4); cs ^= d0; }
+            }
+            OX(orbx_release(ex, ticket));
+            if (track && idx > 0) {
+                const int32_t *assign, *nmp; int np, c2;
+                OX(orbm_track_results(fs, back, &assign, &nmp, &np, &c2));
+                for (int j = 0; j < P; j++) nm += nmp[j];
+                if (nLast > 0) cs ^= (uint64_t)(uint32_t)assign[(size_t)(P - 1) * c2 + nLast - 1] << 32;
+            }
+            const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+            if (idx >= A.warmup) {
+                lat_ms.push_back(ms);
+                st.frames += P; st.keypoints += n; st.matches += nm; st.checksum = st.checksum * 1099511628211ull ^ cs;
+                live_frames.fetch_add(P, std::memory_order_relaxed); live_kps.fetch_add(n, std::memory_order_relaxed); live_matches.fetch_add(nm, std::memory_order_relaxed);
+            }
+        };
+        const auto tStart = clk::now();
+        clk::time_point tTimed = tStart;
+        for (int i = 0; i < total; i++) {
+            if (i == A.warmup) tTimed = clk::now();
+            const uint8_t* img[8];
+            for (int j = 0; j < P; j++) img[j] = ring + (size_t)(j * nring + i % nring) * pitch;
+            const auto t0 = clk::now();
+            int ticket = -1;
+            OX(orbx_submit_batch(ex, img, P, A.w, A.h, stride, &so, &ticket));
+            const auto t1 = clk::now();
+            if (track) {
+                // camera j keeps its last four frames in slots (i & 3) * P + j: one build for the call's P frames
+                int32_t cur[8], last[8];
+                for (int j = 0; j < P; j++) { cur[j] = (i & 3) * P + j; last[j] = ((i - 1) & 3) * P + j; }
+                OX(orbm_frameset_build_from_extractor(fs, cur[0], ex));
+                if (A.depth == 2 && !A.attach) {
+                    // the search of the PREVIOUS frame is collected below before this frame's search goes out (two
+                    // searches never share a result set here), while this frame's extraction already runs beside it
+                    if (pendingTicket >= 0) { finish(pendingIdx, pendingTicket, pendingT0, 0); pendingTicket = -1; if (failed) return; }
+                }
+                if (i > 0) OX(orbm_track_frames(fs, &pp, 15.0f, cur, last, P));
+            }
+            const auto t2 = clk::now();
+            if (i >= A.warmup) { us_submit += std::chrono::duration<double, std::micro>(t1 - t0).count(); us_enqueue += std::chrono::duration<double, std::micro>(t2 - t1).count(); }
+            if (A.depth == 2) {
+                if (pendingTicket >= 0) { finish(pendingIdx, pendingTicket, pendingT0, track && i > 0 ? 1 : 0); if (failed) return; }  // (attached: this frame's search is already in the queue behind it)
+                pendingTicket = ticket; pendingIdx = i; pendingT0 = t0;
+            } else {
+                finish(i, ticket, t0, 0);
+                if (failed) return;
+            }
+        }
+        if (pendingTicket >= 0) finish(pendingIdx, pendingTicket, pendingT0, 0);
+        us_submit /= std::max(1, A.frames); us_enqueue /= std::max(1, A.frames);
+        st.frames = (int64_t)lat_ms.size() * P;
+        st.ns_busy = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tTimed).count();
+        if (fs) orbm_frameset_destroy(fs);
+        if (m) orbm_destroy(m);
+        if (A.pinned) orbx_host_free(ex, ring);
+        orbx_destroy(ex);
+    }
+};
+
+static double median(std::vector<double> v) { if (v.empty()) return 0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Args A;
+    for (int i = 1; i < argc; i++) {
+        const std::string k = argv[i];
+        auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
+        if (k == "--gpus") A.gpus = atoi(val()); else if (k == "--robots") A.robots = atoi(val()); else if (k == "--per-call") A.per_call = atoi(val()); else if (k == "--frames") A.frames = atoi(val());
+        else if (k == "--warmup") A.warmup = atoi(val()); else if (k == "--mode") A.mode = val(); else if (k == "--depth") A.depth = atoi(val());
+        else if (k == "--attach") A.attach = atoi(val()); else if (k == "--pinned") A.pinned = atoi(val()); else if (k == "--w") A.w = atoi(val());
+        else if (k == "--h") A.h = atoi(val()); else if (k == "--nfeat") A.nfeat = atoi(val()); else if (k == "--interval") A.interval = atoi(val());
+        else if (k == "--json") A.json = true;
+        else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+    }
+    const int ndev = orbx_device_count();
+    if (ndev < 1) { fprintf(stderr, "no HIP device: the ORB front-end has no CPU fallback\n"); return 3; }
+    if (A.gpus < 1 || A.gpus > ndev) { fprintf(stderr, "--gpus %d but %d device(s) visible\n", A.gpus, ndev); return 2; }
+    if (A.robots < A.gpus) A.robots = A.gpus;
+    if (A.mode != "track" && A.mode != "bf" && A.mode != "extract") { fprintf(stderr, "--mode track|bf|extract\n"); return 2; }
+    if (A.depth != 1 && A.depth != 2) { fprintf(stderr, "--depth 1|2\n"); return 2; }
+    if (A.per_call < 1 || A.per_call > 2 || (A.per_call > 1 && A.mode == "bf")) { fprintf(stderr, "--per-call 1|2 (2: modes track and extract -- the brute-force match is against the SAME camera's previous frame)\n"); return 2; }
+
+    // RCCL: one communicator per GPU in this one process (the reference is one process, one thread per robot)
+    std::vector<ncclComm_t> comms(A.gpus);
+    std::vector<int> devs(A.gpus);
+    for (int d = 0; d < A.gpus; d++) devs[d] = d;
+    if (ncclCommInitAll(comms.data(), A.gpus, devs.data()) != ncclSuccess) { fprintf(stderr, "ncclCommInitAll failed\n"); return 4; }
+    std::vector<hipStream_t> cstream(A.gpus);
+    std::vector<Stats*> d_send(A.gpus), d_recv(A.gpus);
+    for (int d = 0; d < A.gpus; d++) {
+        if (hipSetDevice(d) != hipSuccess || hipStreamCreateWithFlags(&cstream[d], hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc(&d_send[d], sizeof(Stats)) != hipSuccess || hipMalloc(&d_recv[d], sizeof(Stats) * A.gpus) != hipSuccess) { fprintf(stderr, "hip setup failed\n"); return 4; }
+    }
+
+    std::vector<Robot> robots(A.robots);
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<std::thread> th;
+    for (int r = 0; r < A.robots; r++) { robots[r].robot = r; robots[r].device = r % A.gpus; robots[r].a = &A; }
+    for (int r = 0; r < A.robots; r++) th.emplace_back([&, r] { robots[r].run(ready, go); if (robots[r].failed) ready.fetch_add(1 << 16); });
+    while ((ready.load() & 0xFFFF) + (ready.load() >> 16) < A.robots) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+
+    // the reporting loop: every --interval frames (of robot 0) gather the per-GPU counters with one ncclAllGather
+    std::vector<Stats> gathered(A.gpus);
+    int gathers = 0;
+    auto gather = [&]() -> bool {
+        for (int d = 0; d < A.gpus; d++) {
+            Stats s{};
+            for (int r = d; r < A.robots; r += A.gpus) { s.frames += robots[r].live_frames.load(); s.keypoints += robots[r].live_kps.load(); s.matches += robots[r].live_matches.load(); }
+            if (hipSetDevice(d) != hipSuccess || hipMemcpyAsync(d_send[d], &s, sizeof s, hipMemcpyHostToDevice, cstream[d]) != hipSuccess) return false;
+            if (hipStreamSynchronize(cstream[d]) != hipSuccess) return false;   // `s` is a stack variable
+        }
+        if (ncclGroupStart() != ncclSuccess) return false;
+        for (int d = 0; d < A.gpus; d++)
+            if (ncclAllGather(d_send[d], d_recv[d], sizeof(Stats), ncclChar, comms[d], cstream[d]) != ncclSuccess) return false;
+        if (ncclGroupEnd() != ncclSuccess) return false;
+        for (int d = 0; d < A.gpus; d++) { if (hipSetDevice(d) != hipSuccess || hipStreamSynchronize(cstream[d]) != hipSuccess) return false; }
+        if (hipSetDevice(0) != hipSuccess || hipMemcpy(gathered.data(), d_recv[0], sizeof(Stats) * A.gpus, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        gathers++;
+        return true;
+    };
+    int64_t nextReport = A.interval;
+    bool anyFailed = false;
+    for (;;) {
+        bool done = true;
+        for (auto& r : robots) done &= r.failed || r.live_frames.load() >= (int64_t)A.frames * A.per_call;
+        if (done) break;
+        if (A.interval > 0 && robots[0].live_frames.load() >= nextReport) {
+            if (!gather()) { fprintf(stderr, "stats gather failed\n"); anyFailed = true; break; }
+            nextReport += A.interval;
+            if (!A.json) { int64_t f = 0, mm = 0; for (auto& s : gathered) { f += s.frames; mm += s.matches; } fprintf(stderr, "[gather %d] %lld frames, %lld matches over %d GPU(s)\n", gathers, (long long)f, (long long)mm, A.gpus); }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(500));
+    }
+    for (auto& t : th) t.join();
+    const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (auto& r : robots) anyFailed |= r.failed;
+    if (!anyFailed && !gather()) { fprintf(stderr, "final stats gather failed\n"); anyFailed = true; }
+    for (int d = 0; d < A.gpus; d++) { (void)hipSetDevice(d); (void)hipFree(d_send[d]); (void)hipFree(d_recv[d]); (void)hipStreamDestroy(cstream[d]); ncclCommDestroy(comms[d]); }
+    if (anyFailed) return 1;
+
+    std::vector<double> all;
+    int64_t frames = 0, kps = 0, matches = 0, ns_max = 0;
+    uint64_t cs = 0;
+    for (auto& r : robots) { all.insert(all.end(), r.lat_ms.begin(), r.lat_ms.end()); frames += r.st.frames; kps += r.st.keypoints; matches += r.st.matches; ns_max = std::max(ns_max, r.st.ns_busy); cs ^= r.st.checksum; }
+    int64_t gframes = 0; for (auto& s : gathered) gframes += s.frames;
+    double mean = 0; for (double v : all) mean += v; mean /= std::max<size_t>(1, all.size());
+    const double fps = frames / (ns_max * 1e-9);
+    double usSub = 0, usEnq = 0;
+    for (auto& r : robots) { usSub += r.us_submit / A.robots; usEnq += r.us_enqueue / A.robots; }
+    std::sort(all.begin(), all.end());
+    const double p95 = all.empty() ? 0 : all[all.size() * 95 / 100], p99 = all.empty() ? 0 : all[all.size() * 99 / 100], pmax = all.empty() ? 0 : all.back();
+    if (A.json) {
+        printf("{\"mode\": \"%s\", \"gpus\": %d, \"robots\": %d, \"cameras_per_call\": %d, \"depth\": %d, \"attach\": %d, \"pinned\": %d, \"w\": %d, \"h\": %d, \"nfeat\": %d, \"frames_per_robot\": %d, "
+               "\"frames_per_s\": %.1f, \"ms_median\": %.4f, \"ms_mean\": %.4f, \"ms_p95\": %.4f, \"ms_p99\": %.4f, \"ms_max\": %.4f, \"host_us_submit\": %.1f, \"host_us_enqueue\": %.1f, \"keypoints_mean\": %.1f, \"matches_mean\": %.1f, \"wall_s\": %.3f, "
+               "\"rccl_allgathers\": %d, \"gathered_frames\": %lld, \"checksum\": \"%016llx\"}\n",
+               A.mode.c_str(), A.gpus, A.robots, A.per_call, A.depth, A.attach, A.pinned, A.w, A.h, A.nfeat, A.frames, fps, median(all), mean, p95, p99, pmax, usSub, usEnq,
+               (double)kps / std::max<int64_t>(1, frames), (double)matches / std::max<int64_t>(1, frames), wall_s, gathers, (long long)gframes, (unsigned long long)cs);
+    } else {
+        // as the reference's examples end (mono_tum.cc:113-122)
+        printf("-------\n\nmedian tracking time: %f ms\nmean tracking time: %f ms\n", median(all), mean);
+        printf("%d robot(s) on %d GPU(s), mode %s: %lld frames, %.0f frames/s aggregate, %.1f keypoints and %.1f matches per frame; %d RCCL gathers (%lld frames seen)\n",
+               A.robots, A.gpus, A.mode.c_str(), (long long)frames, fps, (double)kps / std::max<int64_t>(1, frames), (double)matches / std::max<int64_t>(1, frames), gathers, (long long)gframes);
+    }
+    return 0;
+}

@@ -402,6 +402,18 @@ int orbm_frameset_build(orbm_frameset_t* fs, int slot0, int n, const OrbxKeyPoin
  * the device; the extractor will not reuse that result set before the build has read it. */
 int orbm_frameset_build_from_extractor(orbm_frameset_t* fs, int slot0, orbx_t* ex);
 int orbm_frameset_sync(orbm_frameset_t* fs);
+/* The live stream -- one frame per robot per call, what the reference's main loops do
+ * (MultipleRobotsScenario/Examples/Monocular/mono_kitti.cc:80-101 -> Tracking::GrabImageMonocular, src/Tracking.cc:240-267):
+ * after orbm_frameset_attach(fs, ex) the frame set's kernels are enqueued on the extractor's own stream, so that
+ *   orbx_submit_batch(ex, one frame)  ->  orbm_frameset_build_from_extractor(fs, slot, ex)  ->  orbm_track_frames(fs, ...)
+ * is ONE chain of kernels on the device: Frame::Frame (ExtractORB, UndistortKeyPoints, AssignFeaturesToGrid, src/Frame.cc:175-210)
+ * followed by TrackWithMotionModel's SearchByProjection (src/Tracking.cc:925-936) with no host round trip and no cross-stream
+ * hand-over in between; the keypoints / descriptors come back through the ticket (flag-polled), the match table through
+ * orbm_track_results (flag-polled for up to 8 pairs).  The search of frame t needs only the pose PREDICTED from frame t-1
+ * (mVelocity * mLastFrame.mTcw, src/Tracking.cc:905), so it can be submitted together with the frame.  ex = NULL detaches.
+ * Attach before the first orbm_frameset_compute_bow.  Calls on the extractor and on the attached frame set must come from
+ * one thread at a time (they share a stream). */
+int orbm_frameset_attach(orbm_frameset_t* fs, orbx_t* ex);
 /* mvKeysUn / descriptors of one slot for the host side (pose optimisation reads mvKeysUn) */
 int orbm_frameset_download(orbm_frameset_t* fs, int slot, OrbxKeyPoint* keys_un, uint8_t* desc, int cap, int* n_out);
 int orbm_track_frames(orbm_frameset_t* fs, const OrbmProjParams* pp, float th, const int32_t* cur_slots,

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>

@@ -207,7 +207,18 @@ struct ProjPair {
     int32_t* qres;                               // [nq]
     int32_t* qscr;                               // [2 nq ints + nq bytes] best / second / state of a query when they do not fit LDS
     int32_t* stats;                              // optional: [0] rounds, [1] candidates
+    int32_t* flag; int32_t flagValue;            // optional (pinned host): raised behind this pair's results -- a caller polling it
+                                                 // skips the wake-up of an event wait (the one-frame-per-call path)
 };
+
+// every thread's result writes are performed system-wide, then ONE store publishes them (the host polls the word)
+__device__ __forceinline__ void proj_publish(const ProjPair& P)
+{
+    if (!P.flag) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(P.flag, P.flagValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct ProjCommon {
     int32_t mode; float nnratio; int32_t checkOri; int32_t thDist;
@@ -647,6 +658,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
         *P.nmatch = *sCount;
         if (P.stats) { P.stats[0] = (nq > 0 && nt > 0) ? round + 1 : 0; P.stats[1] = total; }
     }
+    proj_publish(P);
     ORBT_MARK(3);
 }
 
@@ -678,6 +690,7 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
     if (total > P.candCap) {  // nothing was listed past the arena; the caller grows it and calls again
         __syncthreads();
         if (tid == 0) { *P.total = 0; *P.nmatch = -total - 1; if (P.stats) { P.stats[0] = 0; P.stats[1] = total; } }
+        proj_publish(P);
         return;
     }
     if (total <= c.ldsCand && nq <= c.qCap) proj_resolve_rounds<true>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount, sLive);
@@ -706,6 +719,7 @@ struct TrackArgs {
     uint8_t* occ; int32_t* assign; int32_t* nmatch; int32_t* stats;   // [pair][cap], [pair][cap] (pinned host), [pair], [pair][2]
     int32_t* total; int32_t* candOff; int32_t* candCnt; uint2* cand; int32_t candCap; int32_t* qres; int32_t* qscr;  // [pair], [pair][cap] x2, [pair][candCap], [pair][cap], [pair][3 cap]
     int32_t pair0;
+    int32_t* flag; int32_t flagValue;   // [pair] (pinned host) or null
     int16_t cur[kTrackMaxPairs], last[kTrackMaxPairs];
 };
 
@@ -728,6 +742,7 @@ __device__ __forceinline__ ProjPair track_pair(const TrackArgs& a, int b)
     P.total = a.total + p;
     P.candOff = a.candOff + p * C; P.candCnt = a.candCnt + p * C; P.cand = a.cand + (int64_t)p * a.candCap; P.candCap = a.candCap;
     P.qres = a.qres + p * C; P.qscr = a.qscr + p * C * 3; P.stats = a.stats + 2 * p;
+    P.flag = a.flag ? a.flag + p : nullptr; P.flagValue = a.flagValue;
     return P;
 }
 

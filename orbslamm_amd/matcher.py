@@ -344,6 +344,11 @@ class FrameSet:
     def sync(self):
         check(self._L.orbm_frameset_sync(self._h))
 
+    def attach(self, extractor):
+        """orbm_frameset_attach: the set's kernels ride on the extractor's stream (the live, one-frame-per-call chain);
+        None detaches"""
+        check(self._L.orbm_frameset_attach(self._h, extractor._h if extractor is not None else None))
+
     def download(self, slot):
         keys = np.zeros(self.cap, dtype=KP_DTYPE)
         desc = np.zeros((self.cap, 32), dtype=np.uint8)

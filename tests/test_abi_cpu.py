@@ -88,3 +88,15 @@ def test_mapserializer_descriptor_text():
     from orbslamm_amd import OrbError
     with pytest.raises(OrbError):
         matcher.descriptors_from_text("[1, 2; 3]", cols=2)
+
+
+def test_multi_robot_example_builds_against_the_abi():
+    """examples/multi_robot.cpp (the reference's multi-robot main loop on the C ABI + RCCL) compiles and links here, where
+    there is no GPU; without one it refuses to run instead of falling back to anything"""
+    import subprocess
+    import __graft_entry__ as ge
+    exe = ge.build_examples(force=True)
+    r = subprocess.run([exe, "--frames", "1"], capture_output=True, text=True, timeout=120)
+    from orbslamm_amd import _lib
+    if _lib.lib().orbx_device_count() == 0:
+        assert r.returncode == 3 and "no CPU fallback" in r.stderr

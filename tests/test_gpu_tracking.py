@@ -221,3 +221,81 @@ def test_frame_set_bow_and_batched_search_by_bow(gpu, oracle):
         fs.search_by_bow([0], [1], 0.7, True)
         assert fs.bow_results()[1][0] == 0
         fs.close(); m.close(); G.close()
+
+
+@pytest.mark.parametrize("lat_streams", ["", "1", "2"])
+@pytest.mark.parametrize("w,h,nf,K,D,P", [(1241, 376, 2000, KITTI_K, [0, 0, 0, 0, 0], 1), (640, 480, 1000, TUM_K, TUM_D, 2)])
+def test_live_stream_chain_attached_to_the_extractor(gpu, oracle, monkeypatch, lat_streams, w, h, nf, K, D, P):
+    """The live stream (round 4): one host frame per call (P = 2: two cameras' frames per call), the frame set attached
+    to the extractor -- upload, extraction, Frame tail and SearchByProjection(Cur, Last) are ONE chain on the
+    extractor's stream, keypoints / descriptors come back behind the ticket's flag and the match table behind the
+    resolve kernel's flag.  Every frame's keypoints, descriptors and match table against the oracle, over enough
+    frames that result sets, slots and tickets wrap around; both forms of the latency chain (one queue / two)."""
+    from orbslamm_amd import ORBextractor, ORBmatcher, make_grid, synth
+    if lat_streams:
+        monkeypatch.setenv("ORBX_LAT_STREAMS", lat_streams)
+    else:
+        monkeypatch.delenv("ORBX_LAT_STREAMS", raising=False)
+    nfr = 7
+    cams = [synth.make_frames(w, h, nfr, stream=20 + j) for j in range(P)]
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=P, device=0)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    sf = np.array(gex.GetScaleFactors(), np.float32)
+    bounds = [0.0, float(w), 0.0, float(h)]
+    g = make_grid(*[bounds[i] for i in (0, 2, 1, 3)])
+    gp = oracle.make_grid_params(bounds[0], bounds[2], bounds[1], bounds[3])
+    m = ORBmatcher(0.9, True, device=0)
+    fs = m.frame_set(4 * P, gex.max_keypoints, K, D, g, bounds, sf)
+    fs.attach(gex)
+    prev = [None] * P
+    matched = 0
+    for i in range(nfr):
+        batch = np.stack([cams[j][i] for j in range(P)])
+        tk = gex.submit_host(batch, match=False)
+        cur = [(i & 3) * P + j for j in range(P)]
+        last = [((i - 1) & 3) * P + j for j in range(P)]
+        fs.build_from_extractor(cur[0], gex)
+        if i:
+            fs.track(cur, last, th=15.0)
+        kps, desc, n, _, _ = gex.collect_host(tk, view=False)
+        if i:
+            assign, nm = fs.results()
+        for j in range(P):
+            ref = oex(cams[j][i])
+            assert n[j] == len(ref["kps"]) and kps[j, :n[j]].tobytes() == ref["kps"].tobytes() and desc[j, :n[j]].tobytes() == ref["desc"].tobytes()
+            ku = oracle.undistort_keypoints(ref["kps"], K, D)
+            if i:
+                kl, dl = prev[j]
+                uvr, lvl, qv = _identity_queries(kl, sf, 15.0, bounds)
+                start, idx = oracle.grid_build(gp, ku)
+                wa, _, wn = oracle.search_by_projection(4, 0.9, True, 100, uvr, lvl, dl, kl["angle"], qv, None, gp, ku, start, idx, ref["desc"],
+                                                        np.zeros(len(ku), np.uint8), np.full(len(ku), -1, np.int32))
+                assert nm[j] == wn and np.array_equal(assign[j, :len(ku)], wa), (i, j, nm[j], wn)
+                matched += wn
+            prev[j] = (ku, ref["desc"])
+    assert matched > 200 * P * (nfr - 1)
+    # detached again the set still holds its frames and searches on the matcher's own stream
+    fs.attach(None)
+    fs.track([((nfr - 1) & 3) * P], [((nfr - 2) & 3) * P], th=15.0)
+    a2, n2 = fs.results()
+    assert n2[0] == nm[0] and np.array_equal(a2[0], assign[0])
+    fs.close(); m.close(); gex.close()
+
+
+def test_projection_search_at_the_largest_frame_capacity(gpu, oracle):
+    """at cap = 8192 (kProjMaxTrain) the per-train tables alone take 128 KB of the resolve's LDS -- the plan
+    must shrink the per-query tables / candidate lists (rounds from memory) instead of asking for more LDS than a CU has"""
+    rng = np.random.default_rng(8192)
+    for nq, nt in ((4096, 8192), (6000, 7000)):
+        c = make_proj_case(rng, nq, nt)
+        for mode, th, ratio in ((4, 100, 0.9), (3, 100, 0.8)):
+            wn, _ = _both(oracle, mode, th, ratio, True, c, nt)
+            assert wn > 300
+    from orbslamm_amd import ORBmatcher, make_grid
+    m = ORBmatcher(0.9, True, device=0)
+    g = make_grid(0.0, 0.0, 1241.0, 376.0)
+    fs = m.frame_set(2, 8192, KITTI_K, [0, 0, 0, 0, 0], g, [0.0, 1241.0, 0.0, 376.0], np.ones(8, np.float32))
+    fs.track([0], [1], th=15.0)       # two empty slots of the largest capacity: the launch itself must be accepted
+    a, n = fs.results()
+    assert n[0] == 0
+    fs.close(); m.close()

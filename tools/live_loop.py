@@ -28,6 +28,25 @@ class Stream:
         sf = np.array(self.ex.GetScaleFactors(), np.float32)
         g = make_grid(0.0, 0.0, float(W), float(H))
         self.fs = self.m.frame_set(4, self.ex.max_keypoints, [718.856, 718.856, 607.1928, 185.2157], [0, 0, 0, 0, 0], g, [0.0, float(W), 0.0, float(H)], sf)
+        if os.environ.get("LIVE_ATTACH", "1") == "1":
+            self.fs.attach(self.ex)
+
+    def live(self, n):
+        """the attached chain: frame + build + search submitted together, keypoints and the match table collected after"""
+        ex, fs, fr = self.ex, self.fs, self.fr
+        lat = []
+        for i in range(n):
+            slot, prev = i & 1, (i & 1) ^ 1
+            t0 = time.perf_counter()
+            tk = ex.submit_host(fr[i % 8][None], match=False)
+            fs.build_from_extractor(slot, ex)
+            if i:
+                fs.track([slot], [prev], th=15.0)
+            ex.collect_host(tk, view=True)
+            if i:
+                fs.results()
+            lat.append(time.perf_counter() - t0)
+        return np.array(lat[5:]) * 1e3
 
     def track(self, n):
         ex, fs, fr = self.ex, self.fs, self.fr
