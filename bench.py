@@ -502,9 +502,10 @@ def live_streams(cfg, dev_index=0, frames=600):
     env = dict(os.environ)   # (single-GPU runs only: the program takes device 0 of what this process sees)
     keep = ("frames_per_s", "ms_median", "ms_mean", "ms_p99", "keypoints_mean", "matches_mean", "host_us_submit", "host_us_enqueue")
 
-    def run(*extra, n=frames):
+    def run(*extra, n=frames, more_env=None):
         try:
-            r = subprocess.run(base + ["--frames", str(n), "--warmup", "40"] + [str(a) for a in extra], capture_output=True, text=True, timeout=180, env=env)
+            e = dict(env, **more_env) if more_env else env
+            r = subprocess.run(base + ["--frames", str(n), "--warmup", "40"] + [str(a) for a in extra], capture_output=True, text=True, timeout=180, env=e)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 return {"error": (r.stderr or r.stdout)[-300:]}
@@ -518,7 +519,9 @@ def live_streams(cfg, dev_index=0, frames=600):
                "track": run("--mode", "track"),
                "track_pageable_frames": run("--mode", "track", "--pinned", 0),
                "track_d2": run("--mode", "track", "--depth", 2),
-               "track_d2_two_queues": run("--mode", "track", "--depth", 2, "--attach", 0),
+               # (ORBX_LAT_PRIO=0: the extractor's queue at the matcher's priority -- a high- and a normal-priority queue busy
+               # at the same time are time-sliced in ~50 us quanta, tools/live_d2_trace.sh: 2.7 k frames/s instead of 8.2 k)
+               "track_d2_two_queues": run("--mode", "track", "--depth", 2, "--attach", 0, more_env={"ORBX_LAT_PRIO": "0"}),
                "bf": run("--mode", "bf"),
                "bf_pageable_frames": run("--mode", "bf", "--pinned", 0),
                "extract": run("--mode", "extract")},
@@ -618,6 +621,13 @@ def run_rank(args):
     stream_id = streams.stream_of_rank(rank)[0]  # this rank's camera stream
     pool = max(1, args.pool)
     pin = pin_to_gpu_numa(dev_index) if distributed else {"pinned": False, "why": "single process: left to the caller's cpuset"}
+    # The live-stream block runs FIRST, before this process owns a queue on the GPU: its robots are to be measured the way
+    # they would be deployed -- their process alone on the device.  (Measured behind the headline, beside this process's
+    # dozen idle hardware queues, 8 cameras read 18.6 k frames/s instead of 30 k: the GPU runs about four queues at a time
+    # and idle ones still take part in the rotation.)  It is no part of the timed region either way.
+    ls = None
+    if world == 1 and not distributed and not os.environ.get("ORBX_BENCH_EXTRACTOR") and not args.no_live_streams and not args.no_tracking_path:
+        ls = live_streams(cfg, dev_index)
     ex = make_extractor(cfg, B, dev_index)
     canvas = synth.make_scene(W, H, stream_id)
     dargs = []
@@ -837,8 +847,8 @@ def run_rank(args):
                 out["parity_check"]["per_rank_ok"] = [bool(g[4] > 0) for g in gathered]
         if world == 1 and not args.no_tracking_path and hasattr(ex, "extract_match_host"):
             out["tracking_path"] = tracking_path(ex, cfg, first_batch, dargs)
-        if world == 1 and real and not args.no_live_streams and not args.no_tracking_path:
-            out["live_streams"] = live_streams(cfg, dev_index)
+        if ls is not None:
+            out["live_streams"] = ls
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, first_batch)
         line = json.dumps(out) + "\n"
