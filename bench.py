@@ -425,6 +425,48 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
     dt = (time.perf_counter() - t0) / reps
     out["cpu_oracle"] = {"ms_per_pair": dt * 1e3, "pairs_per_s": 1.0 / dt, "cores": 1, "kind": "port", "matches": int(wn)}
     out["parity_ok"] = bool(wn == gn and np.array_equal(wa, ga) and int(k[B - 1]) == wn and np.array_equal(a[B - 1, :len(kc)], wa))
+    # ---- Tracking::SearchLocalPoints' search (Tracking.cc:1242-1249 -> ORBmatcher.cc:45-129, mode 3): the local map's
+    # MapPoints in view -- here 3 000 made from the two previous frames' keypoints, jittered, radius by viewing angle -- against
+    # the frame resident in the set; one pinned upload, two launches, flag-polled table.  The CPU oracle beside it.
+    try:
+        rng = np.random.default_rng(11)
+        src_k = np.concatenate([fs.download(B - 2)[0], fs.download(B - 3)[0]])
+        src_d = np.concatenate([fs.download(B - 2)[1], fs.download(B - 3)[1]])
+        lm = {"what": "orbm_track_local_points (SearchByProjection(Frame, local MapPoints, th), nnratio 0.8, TH_HIGH 100) against a frame resident in the set: "
+                      "queries from host memory in one pinned upload, table read behind the resolve kernel's flag; per call"}
+        for th in (1.0, 3.0):
+            sel = rng.permutation(len(src_k))[:3000]
+            ks, qd = src_k[sel], np.ascontiguousarray(src_d[sel])
+            lv = ks["octave"].astype(np.int32)
+            r = (np.where(rng.random(len(ks)) < 0.5, np.float32(2.5), np.float32(4.0)) * np.float32(th)).astype(np.float32) * sf[lv]
+            uvr3 = np.stack([ks["x"] + rng.normal(0, 1.2, len(ks)), ks["y"] + rng.normal(0, 1.2, len(ks)), r], axis=1).astype(np.float32)
+            ql3 = np.stack([lv - 1, lv], axis=1).astype(np.int8)
+            ts3 = []
+            for _ in range(80):
+                t0 = time.perf_counter()
+                fs.track_local_points(B - 1, uvr3, ql3, qd)
+                ga3, gn3 = fs.results()
+                ts3.append(time.perf_counter() - t0)
+            ts3 = np.array(ts3[8:]) * 1e3
+            start3, idx3 = ob.grid_build(gp, kc)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                wa3, _, wn3 = ob.search_by_projection(3, 0.8, True, 100, uvr3, ql3, qd, None, None, None, gp, kc, start3, idx3, dc, occ0, a0)
+            cpu_ms = (time.perf_counter() - t0) / 5 * 1e3
+            # batched: 16 searches in flight (a server tracking many robots' local maps), tables read three calls behind
+            nrep, t0 = 200, time.perf_counter()
+            for i in range(nrep):
+                fs.track_local_points(B - 1, uvr3, ql3, qd)
+                if i >= 3:
+                    fs.results(back=3)
+            fs.results()
+            pipelined_ms = (time.perf_counter() - t0) / nrep * 1e3
+            lm["th%d" % int(th)] = {"queries": int(len(ks)), "ms_median": float(np.median(ts3)), "ms_mean": float(ts3.mean()), "pipelined_ms_per_call": pipelined_ms,
+                                    "matches": int(gn3[0]), "rounds": fs.stats(0)[0], "candidates": fs.stats(0)[1],
+                                    "cpu_oracle_ms": cpu_ms, "parity_ok": bool(int(gn3[0]) == wn3 and np.array_equal(ga3[0, :len(kc)], wa3))}
+        out["local_map"] = lm
+    except Exception as e:  # never lose the record over the secondary block
+        out["local_map"] = {"error": repr(e)}
     # ---- TrackReferenceKeyFrame's pair (Tracking.cc:805-812): Frame::ComputeBoW on the new frame, then
     # SearchByBoW(KeyFrame = the previous frame, Frame), on a synthetic vocabulary of ORBvoc's shape (k = 10, L = 6)
     try:

@@ -418,6 +418,18 @@ int orbm_frameset_attach(orbm_frameset_t* fs, orbx_t* ex);
 int orbm_frameset_download(orbm_frameset_t* fs, int slot, OrbxKeyPoint* keys_un, uint8_t* desc, int cap, int* n_out);
 int orbm_track_frames(orbm_frameset_t* fs, const OrbmProjParams* pp, float th, const int32_t* cur_slots,
                       const int32_t* last_slots, int npairs);
+/* int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)   src/ORBmatcher.cc:45-129
+ * as Tracking::SearchLocalPoints runs it on every frame (src/Tracking.cc:1242-1249: th = 1, or 3 shortly after a
+ * relocalisation, nnratio 0.8), with the frame resident in slot `slot` of the set.  Per local MapPoint in view
+ * (Frame::isInFrustum, src/Frame.cc:269-325): q_uvr = mTrackProjX, mTrackProjY, r = RadiusByViewingCos(mTrackViewCos) * th *
+ * mvScaleFactors[mnTrackScaleLevel]; q_lvl = mnTrackScaleLevel - 1, mnTrackScaleLevel; its descriptor; qvalid =
+ * mbTrackInView && !isBad (NULL: all); q_obs_pos = Observations() > 0 (NULL: all); t_occ[cap] = F.mvpMapPoints[t] holds a
+ * MapPoint with observations (NULL: none).  One pinned upload, two launches, no sync: asynchronous like orbm_track_frames,
+ * the table comes back through orbm_track_results as a search of ONE pair (assign[t] = index of the MapPoint taken by
+ * feature t or -1; the caller writes F.mvpMapPoints).  pp->mode 3 (modes 4 - 6 run without the rotation check: there are no
+ * query angles here).  nq <= slots * cap. */
+int orbm_track_local_points(orbm_frameset_t* fs, int slot, const OrbmProjParams* pp, const float* q_uvr, const int8_t* q_lvl,
+                            const uint8_t* qdesc, const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq, const uint8_t* t_occ);
 int orbm_track_results(orbm_frameset_t* fs, int back, const int32_t** assign, const int32_t** nmatches, int* npairs, int* cap);
 int orbm_track_stats(orbm_frameset_t* fs, int pair, int* rounds, int* candidates);
 

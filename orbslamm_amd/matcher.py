@@ -364,6 +364,21 @@ class FrameSet:
         self._npairs = cs.shape[0]
         check(self._L.orbm_track_frames(self._h, C.byref(pp), C.c_float(th), ptr(cs), ptr(ls), cs.shape[0]))
 
+    def track_local_points(self, slot, q_uvr, q_lvl, qdesc, qvalid=None, q_obs_pos=None, t_occ=None, th_dist=100, nnratio=0.8, mode=3):
+        """orbm_track_local_points: SearchByProjection(Frame, local MapPoints, th) against the frame in `slot`; asynchronous,
+        the table comes back through results() as one pair"""
+        pp = OrbmProjParams(int(mode), float(nnratio), 0, int(th_dist))
+        uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
+        lvl = np.ascontiguousarray(q_lvl, dtype=np.int8)
+        qd = np.ascontiguousarray(qdesc, dtype=np.uint8)
+        qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+        qo = None if q_obs_pos is None else np.ascontiguousarray(q_obs_pos, dtype=np.uint8)
+        occ = None
+        if t_occ is not None:
+            occ = np.zeros(self.cap, np.uint8)
+            occ[:len(t_occ)] = t_occ
+        check(self._L.orbm_track_local_points(self._h, int(slot), C.byref(pp), ptr(uvr), ptr(lvl), ptr(qd), ptr(qv), ptr(qo), uvr.shape[0], ptr(occ)))
+
     def results(self, back=0):
         """waits for the last (back=0) or last-but-one (back=1) track(); (assign[npairs][cap] view of the pinned result
         block, nmatches[npairs])"""

@@ -300,3 +300,62 @@ def test_projection_search_at_the_largest_frame_capacity(gpu, oracle):
     a, n = fs.results()
     assert n[0] == 0
     fs.close(); m.close()
+
+
+def local_map_queries(rng, frames, sf, th, nq_target):
+    """a local map's worth of projected MapPoints made from the keypoints of neighbouring frames: position jittered by a
+    pixel or two, mnTrackScaleLevel = the keypoint's octave, viewCos on either side of 0.998 (RadiusByViewingCos,
+    ORBmatcher.cc:131-137), its descriptor, a few MapPoints without observations"""
+    ks = np.concatenate([k for k, _ in frames]); ds = np.concatenate([d for _, d in frames])
+    sel = rng.permutation(len(ks))[:nq_target]
+    ks, ds = ks[sel], ds[sel]
+    nq = len(ks)
+    lvl = ks["octave"].astype(np.int32)
+    r = (np.where(rng.random(nq) < 0.5, np.float32(2.5), np.float32(4.0)) * np.float32(th)).astype(np.float32) * sf[lvl]
+    uvr = np.stack([ks["x"] + rng.normal(0, 1.2, nq), ks["y"] + rng.normal(0, 1.2, nq), r], axis=1).astype(np.float32)
+    ql = np.stack([lvl - 1, lvl], axis=1).astype(np.int8)
+    qv = (rng.random(nq) < 0.95).astype(np.uint8)
+    qo = (rng.random(nq) < 0.9).astype(np.uint8)
+    return uvr, ql, np.ascontiguousarray(ds), qv, qo
+
+
+@pytest.mark.parametrize("attached", [False, True])
+def test_search_local_points_against_a_resident_frame(gpu, oracle, attached):
+    """Tracking::SearchLocalPoints' search (mode 3, ORBmatcher.cc:45-129) through the frame-set entry: the frame stays in
+    HBM, 3 000 local MapPoints go up in one pinned block; th = 1 and th = 3, with and without features already taken"""
+    from orbslamm_amd import ORBextractor, ORBmatcher, make_grid, synth
+    w, h, nf = 1241, 376, 2000
+    fr = synth.make_frames(w, h, 3, stream=31)
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1 if attached else 3, device=0)
+    sf = np.array(gex.GetScaleFactors(), np.float32)
+    bounds = [0.0, float(w), 0.0, float(h)]
+    g = make_grid(0.0, 0.0, float(w), float(h))
+    gp = oracle.make_grid_params(0.0, 0.0, float(w), float(h))
+    m = ORBmatcher(0.8, True, device=0)
+    fs = m.frame_set(4, gex.max_keypoints, KITTI_K, [0, 0, 0, 0, 0], g, bounds, sf)
+    host = []
+    if attached:
+        fs.attach(gex)
+        for f in range(3):
+            tk = gex.submit_host(fr[f][None], match=False)
+            fs.build_from_extractor(f, gex)
+            kps, desc, n, _, _ = gex.collect_host(tk, view=False)
+            host.append((kps[0, :n[0]].copy(), desc[0, :n[0]].copy()))
+    else:
+        gex.extract_batch_device(*gex.upload_frames(fr))
+        fs.build_from_extractor(0, gex)
+        host = [gex.download(f) for f in range(3)]
+    rng = np.random.default_rng(303)
+    kc, dc = host[2]
+    start, idx = oracle.grid_build(gp, kc)
+    total = 0
+    for th, nq, with_occ in ((1.0, 3000, False), (3.0, 3000, True), (1.0, 4000, True), (3.0, 500, False)):
+        uvr, ql, qd, qv, qo = local_map_queries(rng, host[:2], sf, th, nq)
+        occ = (rng.random(len(kc)) < 0.3).astype(np.uint8) if with_occ else np.zeros(len(kc), np.uint8)
+        fs.track_local_points(2, uvr, ql, qd, qv, qo, occ if with_occ else None)
+        assign, nm = fs.results()
+        wa, _, wn = oracle.search_by_projection(3, 0.8, True, 100, uvr, ql, qd, None, qv, qo, gp, kc, start, idx, dc, occ, np.full(len(kc), -1, np.int32))
+        assert nm[0] == wn and np.array_equal(assign[0, :len(kc)], wa), (th, nq, nm[0], wn)
+        total += wn
+    assert total > 1500
+    fs.close(); m.close(); gex.close()
