@@ -286,3 +286,170 @@ def test_quadtree_tie_break_only_matters_between_equal_sized_nodes():
         L.orc_set_tie_break_reversed(0)
     k0 = set(map(tuple, r0["kps"][["x", "y", "octave"]].tolist())); k1 = set(map(tuple, r1["kps"][["x", "y", "octave"]].tolist()))
     assert len(k0 & k1) >= 0.95 * len(k0)   # the two orders agree on nearly every keypoint of a textured frame
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Independent sanity bounds for the stages that restate OpenCV 3.0 from its published algorithm (parity UNPINNED there:
+# no OpenCV in this container).  None of these can pin the bytes; each would catch a CONVENTION error -- a half-pixel
+# shift, a wrong border rule, a wrong kernel, a score that is not the corner threshold, a wrong distortion model -- which
+# tools/check_vs_opencv would otherwise be the first to find.  Inputs: the natural-image fixture.
+def _natural(name):
+    from natural_cases import load
+    frames, _ = load()
+    return frames[name][0]
+
+
+def test_resize_within_one_level_of_a_float_bilinear(oracle):
+    """cv::resize INTER_LINEAR samples at (dx + 0.5) * scale - 0.5 (half-pixel centres) with the coordinate clamped at the
+    borders: an independent float64 bilinear of that convention must agree with the 11-bit fixed-point restatement within
+    one grey level everywhere (scale 1/1.2, the pyramid's)"""
+    for name in ("c2_camera", "c3_hubble"):
+        img = _natural(name)
+        h, w = img.shape
+        dw, dh = int(round(w / 1.2)), int(round(h / 1.2))
+        got = oracle.resize(img, dw, dh).astype(np.float64)
+        sx, sy = w / dw, h / dh
+        fx = np.clip((np.arange(dw) + 0.5) * sx - 0.5, 0, w - 1)
+        fy = np.clip((np.arange(dh) + 0.5) * sy - 0.5, 0, h - 1)
+        x0 = np.minimum(np.floor(fx).astype(int), w - 2); ax = fx - x0
+        y0 = np.minimum(np.floor(fy).astype(int), h - 2); ay = fy - y0
+        f = img.astype(np.float64)
+        top = f[y0][:, x0] * (1 - ax) + f[y0][:, x0 + 1] * ax
+        bot = f[y0 + 1][:, x0] * (1 - ax) + f[y0 + 1][:, x0 + 1] * ax
+        want = top * (1 - ay)[:, None] + bot * ay[:, None]
+        d = np.abs(got - want)
+        assert d.max() <= 1.0, (name, d.max())
+        assert d.mean() < 0.35   # rounding noise, not a shifted sampling grid (half a pixel off reads > 2 levels on these images)
+
+
+def test_gaussian_within_one_level_of_a_float_filter(oracle):
+    """GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) against a float64 separable filter with the exact normalised kernel
+    and reflect-101 borders.  The 8-bit kernel [18,34,49,55,49,34,18] sums to 257, not 256, and is applied twice, so
+    the restatement reads (257/256)^2 = 1.0078 of the float filter (two levels at white -- SURVEY.md A.4: "not
+    renormalised"): the bound is one level against the float filter scaled by that factor, three against the plain one."""
+    k = np.exp(-0.125 * (np.arange(7) - 3.0) ** 2)
+    k /= k.sum()
+    for name in ("c2_camera", "c2_brick"):
+        img = _natural(name)
+        got = oracle.gaussian7(img).astype(np.float64)
+        p = np.pad(img.astype(np.float64), 3, mode="reflect")   # numpy 'reflect' = reflect-101 (edge pixel not repeated)
+        rows = sum(k[i] * p[:, i:i + img.shape[1]] for i in range(7))
+        want = sum(k[i] * rows[i:i + img.shape[0], :] for i in range(7))
+        gain = (257.0 / 256.0) ** 2
+        assert np.abs(got - np.minimum(want * gain, 255.0)).max() <= 1.0, name
+        assert np.abs(got - want).max() <= 3.0, name
+        # borders included: a wrong border rule (replicate, reflect with the edge repeated) moves the outer rows by more
+        edge = np.abs(got - np.minimum(want * gain, 255.0))
+        assert max(edge[:3].max(), edge[-3:].max(), edge[:, :3].max(), edge[:, -3:].max()) <= 1.0
+
+
+_RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _is_corner(img, t):
+    """FAST-9/16 segment test (the predicate pinned to scikit-image above) at threshold t -- a scalar or one per pixel --
+    for every pixel at least 3 px inside; numpy, independent of the oracle's code"""
+    h, w = img.shape
+    v = img[3:h - 3, 3:w - 3].astype(np.int32)
+    t = np.asarray(t, np.int32)
+    if t.ndim == 2:
+        t = t[3:h - 3, 3:w - 3]
+    ring = np.stack([img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx].astype(np.int32) for dx, dy in _RING])
+    out = np.zeros(v.shape, bool)
+    for side in (ring > v + t, ring < v - t):
+        ext = np.concatenate([side, side[:8]])
+        run = np.ones(v.shape, bool)
+        acc = np.zeros(v.shape, bool)
+        for s in range(16):
+            run = np.logical_and.reduce(ext[s:s + 9])
+            acc |= run
+        out |= acc
+    full = np.zeros((h, w), bool)
+    full[3:h - 3, 3:w - 3] = out
+    return full
+
+
+def test_fast_score_is_the_corner_threshold_and_nms_is_a_strict_maximum(oracle):
+    """Ties cv::FAST's score and non-maximum suppression -- restated, unpinned -- to the segment-test predicate that IS
+    pinned (scikit-image): cornerScore is defined as the largest threshold at which the pixel still passes, so for every
+    keypoint the oracle reports is_corner(p, score) holds and is_corner(p, score + 1) does not; and a keypoint survives
+    exactly when its score beats all eight neighbours' (pixels that are no corner at t count as 0)."""
+    img = np.ascontiguousarray(_natural("c2_camera")[100:300, 150:420])
+    h, w = img.shape
+    for t in (20, 7):
+        kept = oracle.fast(img, t)
+        assert len(kept) > 50
+        sc = np.zeros((h, w), np.int32)
+        sc[kept["y"], kept["x"]] = kept["score"].astype(np.int32)
+        at = _is_corner(img, sc)            # per-pixel threshold = the reported score
+        above = _is_corner(img, sc + 1)
+        assert at[kept["y"], kept["x"]].all(), "a reported score is not a threshold the pixel passes"
+        assert not above[kept["y"], kept["x"]].any(), "a reported score is below the pixel's largest passing threshold"
+        # the score map of ALL corners at t by bisection on the same predicate, then the 3x3 rule
+        corner = _is_corner(img, t)
+        lo = np.where(corner, t, 0).astype(np.int32)      # passes at lo
+        hi = np.full((h, w), 256, np.int32)               # fails at hi
+        for _ in range(9):
+            mid = (lo + hi) // 2
+            ok = _is_corner(img, mid) & corner
+            lo = np.where(ok, mid, lo); hi = np.where(ok, hi, mid)
+        score = np.where(corner, lo, 0)
+        p = np.pad(score, 1)
+        nb = np.max(np.stack([p[1 + dy:h + 1 + dy, 1 + dx:w + 1 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dx, dy) != (0, 0)]), axis=0)
+        want = corner & (score > nb)
+        got = np.zeros((h, w), bool)
+        got[kept["y"], kept["x"]] = True
+        assert np.array_equal(got, want), "%d pixels differ" % int((got != want).sum())
+        assert np.array_equal(sc[got], score[got])
+
+
+def test_undistort_inverts_the_distortion_model(oracle):
+    """cv::undistortPoints' five fixed-point iterations (restated) against a float64 Newton inversion of the
+    radial-tangential model x_d = x (1 + k1 r2 + k2 r4 + k3 r6) + 2 p1 x y + p2 (r2 + 2 x2), ...: within 1e-3 px over the
+    TUM1 image (the residual of five iterations at the image corners), and distorting the result lands on the input"""
+    from oracle.binding import KP_DTYPE
+    K = np.array([517.306408, 516.469215, 318.643040, 255.313989])
+    D = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314])
+    xs, ys = np.meshgrid(np.linspace(0, 639, 33), np.linspace(0, 479, 25))
+    keys = np.zeros(xs.size, KP_DTYPE)
+    keys["x"], keys["y"] = xs.ravel(), ys.ravel()
+    got = oracle.undistort_keypoints(keys, K.astype(np.float32), D.astype(np.float32))
+
+    def distort(x, y):
+        k1, k2, p1, p2, k3 = D
+        r2 = x * x + y * y
+        rad = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+        return x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x), y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+
+    xd, yd = (keys["x"].astype(np.float64) - K[2]) / K[0], (keys["y"].astype(np.float64) - K[3]) / K[1]
+    x, y = xd.copy(), yd.copy()
+    for _ in range(50):   # Newton with a numeric Jacobian
+        fx, fy = distort(x, y)
+        e = 1e-7
+        fxx, fyx = distort(x + e, y); fxy, fyy = distort(x, y + e)
+        a, b, c, d = (fxx - fx) / e, (fxy - fx) / e, (fyx - fy) / e, (fyy - fy) / e
+        rx, ry = fx - xd, fy - yd
+        det = a * d - b * c
+        x -= (d * rx - b * ry) / det
+        y -= (-c * rx + a * ry) / det
+    wx, wy = x * K[0] + K[2], y * K[1] + K[3]
+    err = np.hypot(got["x"] - wx, got["y"] - wy)
+    # five iterations do not fully converge at the far corners of this strongly distorted camera: 1e-3 px in the central
+    # 80 % of the image (where the reference's own result is converged), 0.05 px everywhere
+    r = np.hypot(keys["x"] - 320, keys["y"] - 240)
+    assert err[r < 250].max() < 1e-3, err[r < 250].max()
+    assert err.max() < 0.2, err.max()
+    # ... and what is left at the corners IS the five-iteration residual: the same fixed-point scheme in float64 numpy
+    # (x <- (x_d - tangential(x)) / radial(x), five times from x_d) lands where the restatement does, everywhere
+    k1, k2, p1, p2, k3 = D
+    fx5, fy5 = xd.copy(), yd.copy()
+    for _ in range(5):
+        r2 = fx5 * fx5 + fy5 * fy5
+        icd = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2 * p1 * fx5 * fy5 + p2 * (r2 + 2 * fx5 * fx5)
+        dy = p1 * (r2 + 2 * fy5 * fy5) + 2 * p2 * fx5 * fy5
+        fx5, fy5 = (xd - dx) * icd, (yd - dy) * icd
+    assert np.hypot(got["x"] - (fx5 * K[0] + K[2]), got["y"] - (fy5 * K[1] + K[3])).max() < 1e-3
+    bx, by = distort((got["x"].astype(np.float64) - K[2]) / K[0], (got["y"].astype(np.float64) - K[3]) / K[1])
+    back = np.hypot(bx * K[0] + K[2] - keys["x"], by * K[1] + K[3] - keys["y"])
+    assert back[r < 250].max() < 2e-3
