@@ -314,6 +314,22 @@ def host_path(ex, cfg, frames, seconds=1.5):
             out.update(pipelined_pinned_fps=n / dt, pipelined_pinned_what="the same from pinned frames in the device layout (orbx_host_alloc_frames), results read in place (orbx_collect_view)")
             for pf in pins:
                 pf.free()
+        # the link's own ceiling on this box for exactly these sizes: plain pinned hipMemcpyAsync of one batch's frames up and
+        # one batch's results down, alone and both at once (what the pipeline asks of it), and the fraction reached
+        if hasattr(ex, "link_rate"):
+            try:
+                stride = (W + 63) // 64 * 64
+                up_b = B * stride * H
+                down_b = B * (ex.max_keypoints - 64) * 64   # ~n x (28 + 32 + 4) bytes per frame
+                h2d, d2h, bu, bd = ex.link_rate(up_b, down_b, 40)
+                peak_fps = bu * 1e9 / (stride * H)
+                out.update(pcie_peak_gbs={"h2d_alone": h2d, "d2h_alone": d2h, "h2d_beside_d2h": bu, "d2h_beside_h2d": bd,
+                                          "what": "pinned hipMemcpyAsync of %d B up / %d B down per repetition (one batch), GB/s" % (up_b, down_b)},
+                           pcie_frames_per_s_ceiling=peak_fps,
+                           pcie_frac_pinned=out.get("pipelined_pinned_fps", 0.0) / peak_fps,
+                           pcie_frac_pageable=out.get("pipelined_fps", 0.0) / peak_fps)
+            except Exception as e:
+                out["pcie_peak_gbs"] = {"error": repr(e)}
     return out
 
 

@@ -236,6 +236,12 @@ int orbx_profile_read(orbx_t* h, OrbxProfile* out, int reset);
 int orbx_debug_pair_overlap(orbx_t* h, int nb, float target_ms, int* n_kernels, const char** names,
                             float* alone_ms, float* co_ms, int32_t* lds_bytes, int32_t* wg_threads, int32_t* wgs);
 
+/* Diagnostics: the rate of plain pinned hipMemcpyAsync copies of up_bytes (host to device) and down_bytes (device to host) on
+ * this box, each direction alone and both at once on two streams -- the ceiling the host-buffer entries are read against
+ * (bench.py host_path.pcie_*).  GB/s of payload. */
+int orbx_debug_link_rate(orbx_t* h, size_t up_bytes, size_t down_bytes, int reps, float* h2d_gbs, float* d2h_gbs,
+                         float* both_up_gbs, float* both_down_gbs);
+
 /* ---------------------------------------------------------------- matcher
  * replaces class ORBmatcher (include/ORBmatcher.h:37-102).  The object-graph
  * walking (MapPoint flags, mutex-guarded getters, camera projection) stays in the

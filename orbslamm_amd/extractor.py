@@ -217,6 +217,13 @@ class ORBextractor:
         check(self._L.orbx_host_alloc_frames(self._h, int(B), int(w), int(h), C.byref(p), C.byref(st), C.byref(pitch)))
         return PinnedFrames(self, p.value, B, w, h, st.value, pitch.value)
 
+    def link_rate(self, up_bytes, down_bytes, reps=40):
+        """orbx_debug_link_rate: GB/s of plain pinned copies -- (h2d alone, d2h alone, h2d and d2h while both run)"""
+        a, b, c, d = C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(0)
+        check(self._L.orbx_debug_link_rate(self._h, C.c_size_t(int(up_bytes)), C.c_size_t(int(down_bytes)), int(reps),
+                                           C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
     # ---- device-resident path (frames already in HBM)
     def upload_frames(self, frames, stride=None):
         """copy [B,H,W] uint8 host frames into a device buffer with 64-byte aligned rows;
