@@ -825,6 +825,18 @@ def run_rank(args):
         sq_src = _latest_profile("pmc_sq.json")
         traffic_tab = json.load(open(traffic_src)) if traffic_src else {}
         sq_tab = json.load(open(sq_src)) if sq_src else {}
+        # the replayed PMC tables carry the hash of the kernel sources they were measured on
+        sys.path.insert(0, os.path.join(_ROOT, "tools"))
+        from kernels_sha import kernels_sha
+        sha_now = kernels_sha()
+        replay = {"kernels_sha16_now": sha_now,
+                  "traffic": {"source": os.path.basename(traffic_src) if traffic_src else None, "kernels_sha16": traffic_tab.pop("_kernels_sha16", None)},
+                  "issue": {"source": os.path.basename(sq_src) if sq_src else None, "kernels_sha16": sq_tab.get("kernels_sha16")}}
+        for k in ("traffic", "issue"):
+            replay[k]["stale"] = replay[k]["kernels_sha16"] != sha_now   # (tables older than round 4 carry no hash: stale by definition)
+        if replay["traffic"]["stale"] or replay["issue"]["stale"]:
+            sys.stderr.write("bench.py: the replayed PMC tables (%s, %s) were not taken on the current kernel sources: roofline.traffic / roofline.issue are from an older build\n"
+                             % (replay["traffic"]["source"], replay["issue"]["source"]))
 
         def roofline_of(prof, dom=None, nsteps=args.steps):
             kern = {k: v for k, v in prof.items() if v[1] > 0 and k.startswith("k_")}
@@ -905,6 +917,7 @@ def run_rank(args):
                 out["parity_check"]["per_rank_ok"] = [bool(g[4] > 0) for g in gathered]
         if world == 1 and not args.no_tracking_path and hasattr(ex, "extract_match_host"):
             out["tracking_path"] = tracking_path(ex, cfg, first_batch, dargs)
+        out["replayed_pmc"] = replay
         if ls is not None:
             out["live_streams"] = ls
         if world == 1 and not args.no_cpu_baseline:

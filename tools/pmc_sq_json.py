@@ -40,6 +40,10 @@ for db in sys.argv[2:]:
     for k, n, d in c.execute("select kernel_name, count(*), avg(duration) from counters_collection group by kernel_name"):
         pass
 out["clock_ghz"] = round(sum(clock) / len(clock), 3) if clock else 2.4
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernels_sha import kernels_sha  # noqa: E402
+out["kernels_sha16"] = kernels_sha()   # bench.py replays this table: it says so when the kernels have changed since
 json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {a: round(b) for a, b in v.items()} for k, v in out["kernels"].items()}, indent=1))
 print("clock_ghz", out["clock_ghz"])

@@ -17,9 +17,9 @@ def per_step(rows):
     """rows: (kernel, dispatches, average value per dispatch) -> KB per 64-frame STEP.  A kernel that is dispatched
     more than once per step (k_fast: level 0, then levels 1-7) must be summed over its dispatches: the per-dispatch
     average of such a kernel is a fraction of the step's traffic (it made bench.py's `traffic` of k_fast 2x too small).
-    Steps profiled = dispatches of k_blur, which runs once per step in ORBX_SERIAL=1."""
+    Steps profiled = dispatches of k_pyramid, which runs once per step in ORBX_SERIAL=1."""
     rows = [(short(k), n, v) for k, n, v in rows]
-    nsteps = max(n for k, n, v in rows if k == "k_blur")
+    nsteps = max(n for k, n, v in rows if k == "k_pyramid")   # one launch per step when ORBX_SERIAL=1 (the blur's name depends on its form)
     out = {}
     for k, n, v in rows:
         out[k] = out.get(k, 0.0) + v * n / nsteps
@@ -46,5 +46,9 @@ fetch = load(sys.argv[1], "FETCH_SIZE")
 write = load(sys.argv[2], "WRITE_SIZE")
 res = {k: {"fetch_kb": fetch[k], "fetch_scale": 2.0, "write_kb": write.get(k, 0.0), "frames_per_launch": 64}
        for k in fetch if not k.startswith("__amd")}
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernels_sha import kernels_sha  # noqa: E402
+res["_kernels_sha16"] = kernels_sha()   # bench.py replays this table: it says so when the kernels have changed since
 json.dump(res, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
