@@ -655,6 +655,14 @@ def run_rank(args):
     force_dist = os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"  # world 1 through the N > 1 initialisation path
     distributed = world > 1 or force_dist
     backend = os.environ.get("ORBX_DIST_BACKEND", "nccl")  # "gloo": plumbing test of N ranks on a box with fewer GPUs
+    # The live-stream block runs FIRST, before this process has as much as initialised the HIP runtime: its robots are to
+    # be measured the way they would be deployed -- their process alone on the device.  (With this process's runtime up,
+    # even before it owns a stream, 8 cameras read 18.6 k frames/s instead of 30 k: the GPU runs about four queues at a
+    # time and every queue a process holds takes part in the rotation, idle or not -- docs/experiments.md, round 4.)
+    # It is no part of the timed region either way.
+    ls = None
+    if world == 1 and not distributed and not os.environ.get("ORBX_BENCH_EXTRACTOR") and not args.no_live_streams and not args.no_tracking_path:
+        ls = live_streams(cfg, 0)
     ndev = device_count()
     if backend == "nccl" and distributed and local_rank >= max(ndev, 1):
         sys.stderr.write("bench.py: rank %d has no GPU of its own (%d visible); one process per GPU\n" % (rank, ndev))
@@ -679,13 +687,6 @@ def run_rank(args):
     stream_id = streams.stream_of_rank(rank)[0]  # this rank's camera stream
     pool = max(1, args.pool)
     pin = pin_to_gpu_numa(dev_index) if distributed else {"pinned": False, "why": "single process: left to the caller's cpuset"}
-    # The live-stream block runs FIRST, before this process owns a queue on the GPU: its robots are to be measured the way
-    # they would be deployed -- their process alone on the device.  (Measured behind the headline, beside this process's
-    # dozen idle hardware queues, 8 cameras read 18.6 k frames/s instead of 30 k: the GPU runs about four queues at a time
-    # and idle ones still take part in the rotation.)  It is no part of the timed region either way.
-    ls = None
-    if world == 1 and not distributed and not os.environ.get("ORBX_BENCH_EXTRACTOR") and not args.no_live_streams and not args.no_tracking_path:
-        ls = live_streams(cfg, dev_index)
     ex = make_extractor(cfg, B, dev_index)
     canvas = synth.make_scene(W, H, stream_id)
     dargs = []
