@@ -1816,6 +1816,18 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
 }
 
 // ------------------------------------------------------------------ small movers of the host path
+// One or two host frames into HBM by a KERNEL instead of the DMA engine (the one-frame-per-call entry): the frames sit in
+// pinned host memory the device can address, every lane fetches 16 bytes over the link, all loads independent.  The
+// copy is no faster than the engine's (~12 against 16 us for a 1241x376 frame) -- but the chain's first kernel follows
+// it in the same queue with nothing in between, where the engine's completion reaches the compute queue ~20 us late
+// (tools/live_dma_gap.sh).
+__global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) ((u32x4*)dst)[i] = __builtin_nontemporal_load((const u32x4*)src + i);
+}
+
 // The stream's last frame becomes the previous frame of the next batch: slot `src` of one result set -> slot 0 of the
 // other (one launch instead of three device-to-device copies in front of the download).
 __global__ __launch_bounds__(256) void k_roll_prev(const uint32_t* __restrict__ kpsSrc, const uint32_t* __restrict__ descSrc,

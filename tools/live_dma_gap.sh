@@ -12,7 +12,7 @@ ev = [(s, e, "COPY") for s, e in c.execute("select start, end from memory_copies
 ev += [(s, e, n.split("(")[0].split("::")[-1][:22]) for s, e, n in c.execute("select start, end, name from kernels")]
 ev.sort()
 ev = ev[len(ev) * 2 // 3:]
-i0 = next(i for i, x in enumerate(ev) if x[2] == "COPY")
+i0 = next(i for i, x in enumerate(ev) if x[2] in ("COPY", "k_upload"))
 t0 = ev[i0][0]
 for s, e, n in ev[i0:i0 + 26]:
     print("%9.1f %9.1f %7.1f  %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, n))
