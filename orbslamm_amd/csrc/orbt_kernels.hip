@@ -228,6 +228,7 @@ struct ProjCommon {
     int32_t stageCap;  // candidates: entries (8 bytes) of a slice's staging buffer in LDS behind the grid
     int32_t qCap;      // resolve: queries whose tables fit in LDS   } more of either: the rounds work in memory
     int32_t ldsCand;   // resolve: candidate entries that fit in LDS }
+    int32_t interleave;  // candidates: deal the queries to the slices wave by wave instead of in consecutive runs (few pairs)
 };
 
 constexpr int kCandThreads = 512;
@@ -330,14 +331,18 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     const int tid = threadIdx.x, lc = tid & (kCandLanes - 1);
     const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
     const int nq = min(P.nqPtr ? *P.nqPtr : P.nq, kMaxQueryIters * kThreads);
-    if (nt <= 0 || slice * kCandQueries >= nq) return;
+    if (nt <= 0 || (c.interleave ? slice * 16 : slice * kCandQueries) >= nq) return;
     ORBT_MARK(4);
     const int ncell = min(P.grid.cols * P.grid.rows, c.cellCap - 1);
     for (int ci = tid; ci <= ncell; ci += kCandThreads) cst[ci] = (uint16_t)P.cellStart[ci];
     const int ngrid = min(P.cellStart[ncell], nt);
     for (int j = tid; j < ngrid; j += kCandThreads) rec[j] = P.trec[j];
     // the query's search window; !ok = the reference skips this query before GetFeaturesInArea
-    const int q = slice * kCandQueries + (tid >> 2);
+    // Few pairs (a live stream): the slices INTERLEAVE the queries, in units of a wave's 16.  Queries come ordered by pyramid
+    // level and a coarse-level window holds many times the features of a fine one: with consecutive runs the last
+    // workgroups of a frame pair walked for 26 us while the first were done after 11 (tools/proj_phases.sh).  A wave's lanes
+    // still walk windows of one size.  Many pairs keep the consecutive runs (workgroups abound; 7 % faster there).
+    const int q = c.interleave ? (((tid >> 6) * (int)gridDim.x + slice) << 4) + ((tid >> 2) & 15) : slice * kCandQueries + (tid >> 2);
     float u = 0.f, v = 0.f, r = 0.f; int minL = 0, maxL = 0;
     bool ok = q < nq && !(P.qvalid && !P.qvalid[q]);
     if (ok) {
