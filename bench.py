@@ -481,6 +481,22 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
                                     "matches": int(gn3[0]), "rounds": fs.stats(0)[0], "candidates": fs.stats(0)[1],
                                     "cpu_oracle_ms": cpu_ms, "parity_ok": bool(int(gn3[0]) == wn3 and np.array_equal(ga3[0, :len(kc)], wa3))}
         out["local_map"] = lm
+        # TrackWithMotionModel's search with the caller's projections (orbm_track_frame_projected): LastFrame's descriptors
+        # and angles stay in HBM, 14 bytes per feature go up -- here the identity projection, so that the table must equal
+        # orbm_track_frames'
+        uvrp = np.stack([kl["x"], kl["y"], (np.float32(15.0) * sf[kl["octave"]]).astype(np.float32)], axis=1).astype(np.float32)
+        lvlp = np.stack([kl["octave"] - 1, kl["octave"] + 1], axis=1).astype(np.int8)
+        tp = []
+        for _ in range(80):
+            t0 = time.perf_counter()
+            fs.track_projected(B - 1, B - 2, uvrp, lvlp)
+            gap, gnp = fs.results()
+            tp.append(time.perf_counter() - t0)
+        tp = np.array(tp[8:]) * 1e3
+        out["projected_pose"] = {"ms_median": float(np.median(tp)), "ms_mean": float(tp.mean()), "matches": int(gnp[0]),
+                                 "parity_ok": bool(int(gnp[0]) == gn and np.array_equal(gap[0, :len(kc)], ga)),
+                                 "what": "orbm_track_frame_projected: SearchByProjection(Cur, Last, th = 15) with the caller's projections of LastFrame's features "
+                                         "(u, v, radius, octave window from host memory), both frames resident; per call, table behind the flag"}
     except Exception as e:  # never lose the record over the secondary block
         out["local_map"] = {"error": repr(e)}
     # ---- TrackReferenceKeyFrame's pair (Tracking.cc:805-812): Frame::ComputeBoW on the new frame, then

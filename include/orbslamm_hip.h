@@ -436,6 +436,16 @@ int orbm_track_frames(orbm_frameset_t* fs, const OrbmProjParams* pp, float th, c
  * query angles here).  nq <= slots * cap. */
 int orbm_track_local_points(orbm_frameset_t* fs, int slot, const OrbmProjParams* pp, const float* q_uvr, const int8_t* q_lvl,
                             const uint8_t* qdesc, const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq, const uint8_t* t_occ);
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
+ * src/ORBmatcher.cc:1330-1472 as Tracking::TrackWithMotionModel calls it (src/Tracking.cc:925-936) with a REAL pose:
+ * the caller projects LastFrame's MapPoints with CurrentFrame.mTcw (:1362-1378 -- cv::Mat algebra, stays on the host) and
+ * passes, per LastFrame feature i < nq: q_uvr = u, v, radius = th * mvScaleFactors[octave]; q_lvl = the octave window
+ * (:1381-1392); qvalid = holds a MapPoint that is no outlier, projects with positive depth into the image bounds
+ * (:1349-1378); q_obs_pos (NULL: all); t_occ[cap] as orbm_track_local_points.  LastFrame's descriptors and angles
+ * (rotation check, pp->check_ori) and CurrentFrame's grid stay in HBM: 14 bytes per feature go up.  pp->mode 4 (or 5: the
+ * relocalisation search, same shape).  Asynchronous; the table comes back through orbm_track_results as ONE pair. */
+int orbm_track_frame_projected(orbm_frameset_t* fs, int cur_slot, int last_slot, const OrbmProjParams* pp, const float* q_uvr,
+                               const int8_t* q_lvl, const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq, const uint8_t* t_occ);
 int orbm_track_results(orbm_frameset_t* fs, int back, const int32_t** assign, const int32_t** nmatches, int* npairs, int* cap);
 int orbm_track_stats(orbm_frameset_t* fs, int pair, int* rounds, int* candidates);
 

@@ -74,7 +74,7 @@ EXPORTS = [
     "orbm_frame_download_keys_un", "orbm_search_by_projection_frame", "orbm_frame_compute_bow", "orbm_search_by_bow_frames", "orbm_search_for_initialization_frames", "orbm_window_best_frame", "orbm_search_for_triangulation_frames",
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_transform",
     "orbm_last_search_stats", "orbm_frameset_create", "orbm_frameset_destroy", "orbm_frameset_build", "orbm_frameset_build_from_extractor",
-    "orbm_frameset_sync", "orbm_frameset_attach", "orbm_frameset_download", "orbm_track_frames", "orbm_track_local_points", "orbm_track_results", "orbm_track_stats",
+    "orbm_frameset_sync", "orbm_frameset_attach", "orbm_frameset_download", "orbm_track_frames", "orbm_track_local_points", "orbm_track_frame_projected", "orbm_track_results", "orbm_track_stats",
     "orbm_frameset_compute_bow", "orbm_frameset_bow_vector", "orbm_bow_frames", "orbm_bow_results",
 ]
 

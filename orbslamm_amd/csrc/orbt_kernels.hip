@@ -194,7 +194,7 @@ struct ProjPair {
     // ... or derived from a frame's undistorted keys (quvr == null): u, v = pt (identity pose), radius = th *
     // mvScaleFactors[octave], levels octave-1 .. octave+1 (ORBmatcher.cc:1381-1392), inside the image bounds (:1375-1378)
     const KeyDev* qkeys;
-    const int32_t* nqPtr; int32_t nq;
+    const int32_t* nqPtr; int32_t nq;            // nqPtr: count read on the device (capped by nq when nq > 0), else nq
     float th; float minX, maxX, minY, maxY;
     // in / out per train feature
     const uint8_t* toccIn; uint8_t* toccOut;     // toccIn null: nothing occupied
@@ -330,7 +330,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     uint16_t* cst = (uint16_t*)(stage + c.stageCap);
     const int tid = threadIdx.x, lc = tid & (kCandLanes - 1);
     const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
-    const int nq = min(P.nqPtr ? *P.nqPtr : P.nq, kMaxQueryIters * kThreads);
+    const int nq = min(P.nqPtr ? (P.nq > 0 ? min(*P.nqPtr, P.nq) : *P.nqPtr) : P.nq, kMaxQueryIters * kThreads);
     if (nt <= 0 || (c.interleave ? slice * 16 : slice * kCandQueries) >= nq) return;
     ORBT_MARK(4);
     const int ncell = min(P.grid.cols * P.grid.rows, c.cellCap - 1);
@@ -681,7 +681,7 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
     int32_t* qtab = occBy + 4 * c.tCap;
     const int tid = threadIdx.x;
     const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
-    const int nq = min(P.nqPtr ? *P.nqPtr : P.nq, kMaxQueryIters * kThreads);
+    const int nq = min(P.nqPtr ? (P.nq > 0 ? min(*P.nqPtr, P.nq) : *P.nqPtr) : P.nq, kMaxQueryIters * kThreads);
     const int total = (nq > 0 && nt > 0) ? *P.total : 0;
     ORBT_MARK(0);
     for (int t = tid; t < nt; t += kThreads) {

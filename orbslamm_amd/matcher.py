@@ -379,6 +379,20 @@ class FrameSet:
             occ[:len(t_occ)] = t_occ
         check(self._L.orbm_track_local_points(self._h, int(slot), C.byref(pp), ptr(uvr), ptr(lvl), ptr(qd), ptr(qv), ptr(qo), uvr.shape[0], ptr(occ)))
 
+    def track_projected(self, cur_slot, last_slot, q_uvr, q_lvl, qvalid=None, q_obs_pos=None, t_occ=None, th_dist=100, nnratio=0.9,
+                        check_ori=True, mode=4):
+        """orbm_track_frame_projected: SearchByProjection(Cur, Last) with the caller's projections of LastFrame's features"""
+        pp = OrbmProjParams(int(mode), float(nnratio), int(bool(check_ori)), int(th_dist))
+        uvr = np.ascontiguousarray(q_uvr, dtype=np.float32)
+        lvl = np.ascontiguousarray(q_lvl, dtype=np.int8)
+        qv = None if qvalid is None else np.ascontiguousarray(qvalid, dtype=np.uint8)
+        qo = None if q_obs_pos is None else np.ascontiguousarray(q_obs_pos, dtype=np.uint8)
+        occ = None
+        if t_occ is not None:
+            occ = np.zeros(self.cap, np.uint8)
+            occ[:len(t_occ)] = t_occ
+        check(self._L.orbm_track_frame_projected(self._h, int(cur_slot), int(last_slot), C.byref(pp), ptr(uvr), ptr(lvl), ptr(qv), ptr(qo), uvr.shape[0], ptr(occ)))
+
     def results(self, back=0):
         """waits for the last (back=0) or last-but-one (back=1) track(); (assign[npairs][cap] view of the pinned result
         block, nmatches[npairs])"""

@@ -359,3 +359,42 @@ def test_search_local_points_against_a_resident_frame(gpu, oracle, attached):
         total += wn
     assert total > 1500
     fs.close(); m.close(); gex.close()
+
+
+def test_track_with_projections_from_the_host(gpu, oracle):
+    """TrackWithMotionModel's search with a REAL pose (orbm_track_frame_projected): LastFrame's features stay in HBM, the
+    caller's projections of them (here: a small similarity -- shift, in-plane rotation, scale -- applied to the undistorted
+    keypoints, radius th * scale[octave], some MapPoints missing / behind the camera / without observations) go up; mode 4
+    with and without the rotation check, mode 5 (the relocalisation search) and features already taken"""
+    from orbslamm_amd import ORBextractor, ORBmatcher, make_grid, synth
+    w, h, nf = 1241, 376, 2000
+    fr = synth.make_frames(w, h, 2, stream=41)
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2, device=0)
+    sf = np.array(gex.GetScaleFactors(), np.float32)
+    bounds = [0.0, float(w), 0.0, float(h)]
+    g = make_grid(0.0, 0.0, float(w), float(h))
+    gp = oracle.make_grid_params(0.0, 0.0, float(w), float(h))
+    m = ORBmatcher(0.9, True, device=0)
+    fs = m.frame_set(2, gex.max_keypoints, KITTI_K, [0, 0, 0, 0, 0], g, bounds, sf)
+    gex.extract_batch_device(*gex.upload_frames(fr))
+    fs.build_from_extractor(0, gex)
+    (kl, dl), (kc, dc) = gex.download(0), gex.download(1)
+    start, idx = oracle.grid_build(gp, kc)
+    rng = np.random.default_rng(4141)
+    total = 0
+    for mode, th, ori, thd, with_occ in ((4, 15.0, True, 100, False), (4, 7.0, False, 100, True), (5, 10.0, True, 64, False)):
+        a = np.deg2rad(0.4)
+        u = (np.cos(a) * (kl["x"] - 600) - np.sin(a) * (kl["y"] - 180)) * 1.004 + 600 + 1.5
+        v = (np.sin(a) * (kl["x"] - 600) + np.cos(a) * (kl["y"] - 180)) * 1.004 + 180 - 0.8
+        uvr = np.stack([u, v, np.float32(th) * sf[kl["octave"]]], axis=1).astype(np.float32)
+        lvl = np.stack([kl["octave"] - 1, kl["octave"] + 1], axis=1).astype(np.int8)
+        qv = ((rng.random(len(kl)) < 0.85) & (u >= 0) & (u <= w) & (v >= 0) & (v <= h)).astype(np.uint8)
+        qo = (rng.random(len(kl)) < 0.9).astype(np.uint8)
+        occ = (rng.random(len(kc)) < 0.2).astype(np.uint8) if with_occ else np.zeros(len(kc), np.uint8)
+        fs.track_projected(1, 0, uvr, lvl, qv, qo, occ if with_occ else None, th_dist=thd, nnratio=0.9, check_ori=ori, mode=mode)
+        assign, nm = fs.results()
+        wa, _, wn = oracle.search_by_projection(mode, 0.9, ori, thd, uvr, lvl, dl, kl["angle"], qv, qo, gp, kc, start, idx, dc, occ, np.full(len(kc), -1, np.int32))
+        assert nm[0] == wn and np.array_equal(assign[0, :len(kc)], wa), (mode, th, nm[0], wn)
+        total += wn
+    assert total > 1500
+    fs.close(); m.close(); gex.close()
