@@ -18,7 +18,7 @@
 //
 // build:  hipcc -O2 -std=c++17 examples/multi_robot.cpp -Iinclude -Lorbslamm_amd -lorbslamm_hip -lrccl -Wl,-rpath,'$ORIGIN/../orbslamm_amd' -o examples/multi_robot
 // usage:  multi_robot [--gpus N] [--robots R] [--frames F] [--warmup W] [--mode track|bf|extract] [--depth 1|2]
-//                     [--per-call 1|2 (cameras whose frames one thread puts through the chain together)] [--attach 0|1] [--pinned 0|1] [--w 1241 --h 376 --nfeat 2000] [--interval 200] [--json]
+//                     [--per-call 1|2 (cameras whose frames one thread puts through the chain together)] [--attach 0|1] [--pinned 0|1] [--w 1241 --h 376 --nfeat 2000] [--interval 200] [--json] [--dump FILE]
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -41,7 +41,7 @@ namespace {
 
 struct Args {
     int gpus = 1, robots = 1, per_call = 1, frames = 600, warmup = 30, depth = 1, attach = 1, pinned = 1, w = 1241, h = 376, nfeat = 2000, interval = 200;
-    std::string mode = "track";
+    std::string mode = "track", dump;
     bool json = false;
 };
 
@@ -162,13 +162,29 @@ struct Robot {
                 cs = cs * 31 + (uint64_t)nLast * 1315423911ull;
                 if (nLast > 0) { uint32_t d0; memcpy(&d0, v.desc + ((size_t)j * v.cap + (nLast - 1)) * 32, 4); cs ^= d0; }
             }
+            // --dump: camera 0 of thread 0 writes its first eight timed frames with everything that came back for them -- the
+            // test suite replays them through the CPU oracle (tests/test_gpu_example.py): this program holds no checker
+            FILE* df = nullptr;
+            if (robot == 0 && !A.dump.empty() && idx >= A.warmup && idx < A.warmup + 8) df = fopen(A.dump.c_str(), idx == A.warmup ? "wb" : "ab");
+            const int n0 = v.n[0];
+            if (df) {
+                const int32_t hdr[6] = {idx, n0, A.w, A.h, bf ? 1 : (track ? 2 : 0), P};
+                fwrite(hdr, sizeof hdr, 1, df);
+                const uint8_t* fr0 = ring + (size_t)(idx % nring) * pitch;
+                for (int y = 0; y < A.h; y++) fwrite(fr0 + (size_t)y * stride, 1, (size_t)A.w, df);
+                fwrite(v.kps, sizeof(OrbxKeyPoint), (size_t)n0, df);
+                fwrite(v.desc, 32, (size_t)n0, df);
+                if (bf) { fwrite(v.match, 4, (size_t)n0, df); fwrite(v.nmatch, 4, 1, df); }
+            }
             OX(orbx_release(ex, ticket));
             if (track && idx > 0) {
                 const int32_t *assign, *nmp; int np, c2;
                 OX(orbm_track_results(fs, back, &assign, &nmp, &np, &c2));
                 for (int j = 0; j < P; j++) nm += nmp[j];
                 if (nLast > 0) cs ^= (uint64_t)(uint32_t)assign[(size_t)(P - 1) * c2 + nLast - 1] << 32;
+                if (df) { fwrite(assign, 4, (size_t)n0, df); fwrite(nmp, 4, 1, df); }
             }
+            if (df) fclose(df);
             const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
             if (idx >= A.warmup) {
                 lat_ms.push_back(ms);
@@ -233,6 +249,7 @@ int main(int argc, char** argv)
         else if (k == "--warmup") A.warmup = atoi(val()); else if (k == "--mode") A.mode = val(); else if (k == "--depth") A.depth = atoi(val());
         else if (k == "--attach") A.attach = atoi(val()); else if (k == "--pinned") A.pinned = atoi(val()); else if (k == "--w") A.w = atoi(val());
         else if (k == "--h") A.h = atoi(val()); else if (k == "--nfeat") A.nfeat = atoi(val()); else if (k == "--interval") A.interval = atoi(val());
+        else if (k == "--dump") A.dump = val();
         else if (k == "--json") A.json = true;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }

@@ -50,3 +50,54 @@ def test_several_robots_on_one_gpu(gpu):
     pairs = _run("--mode", "track", "--robots", 2, "--per-call", 2, "--w", 640, "--h", 480, "--nfeat", 1000)
     assert pairs["gathered_frames"] == 160
     assert abs(pairs["keypoints_mean"] - four["keypoints_mean"]) < 1e-9 and abs(pairs["matches_mean"] - four["matches_mean"]) < 1e-9
+
+
+def _read_dump(path, mode):
+    import numpy as np
+    from orbslamm_amd._lib import KP_DTYPE
+    recs, b, o = [], open(path, "rb").read(), 0
+    while o < len(b):
+        idx, n, w, h, m, P = np.frombuffer(b, np.int32, 6, o); o += 24
+        fr = np.frombuffer(b, np.uint8, w * h, o).reshape(h, w); o += w * h
+        kps = np.frombuffer(b, KP_DTYPE, n, o); o += 28 * n
+        desc = np.frombuffer(b, np.uint8, 32 * n, o).reshape(n, 32); o += 32 * n
+        table, cnt = None, None
+        if m == 1 or (m == 2 and idx > 0):
+            table = np.frombuffer(b, np.int32, n, o); o += 4 * n
+            cnt = int(np.frombuffer(b, np.int32, 1, o)[0]); o += 4
+        recs.append(dict(idx=int(idx), frame=fr, kps=kps, desc=desc, table=table, count=cnt))
+    return recs
+
+
+@pytest.mark.parametrize("mode,extra", [("track", []), ("track", ["--per-call", "2", "--depth", "2"]), ("bf", []), ("bf", ["--pinned", "0"])])
+def test_what_the_native_loop_got_back_is_what_the_oracle_computes(gpu, oracle, tmp_path, mode, extra):
+    """--dump: eight consecutive frames of robot 0 with the keypoints, descriptors and match tables the live loop handed to its
+    caller, replayed through the CPU oracle byte for byte -- the native program's own results, not a Python re-run of them"""
+    import numpy as np
+    path = str(tmp_path / "dump.bin")
+    _run("--mode", mode, "--w", 640, "--h", 480, "--nfeat", 1000, "--dump", path, *extra)
+    recs = _read_dump(path, mode)
+    assert len(recs) == 8 and [r["idx"] for r in recs] == list(range(recs[0]["idx"], recs[0]["idx"] + 8))
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    sf = np.array(oex.scale_factors(), np.float32)
+    gp = oracle.make_grid_params(0.0, 0.0, 640.0, 480.0)
+    prev, checked = None, 0
+    for r in recs:
+        ref = oex(np.ascontiguousarray(r["frame"]))
+        assert len(ref["kps"]) == len(r["kps"]) > 500
+        assert ref["kps"].tobytes() == r["kps"].tobytes() and ref["desc"].tobytes() == r["desc"].tobytes()
+        if prev is not None:
+            if mode == "bf":
+                wm, wn = oracle.match_bruteforce(ref["desc"], ref["kps"]["angle"], prev["desc"], prev["kps"]["angle"], 0.7, 50, True)
+                assert r["count"] == wn and np.array_equal(r["table"], wm)
+            else:
+                kl, kc = prev["kps"], ref["kps"]
+                uvr = np.stack([kl["x"], kl["y"], (np.float32(15.0) * sf[kl["octave"]]).astype(np.float32)], axis=1).astype(np.float32)
+                lvl = np.stack([kl["octave"] - 1, kl["octave"] + 1], axis=1).astype(np.int8)
+                start, idx = oracle.grid_build(gp, kc)
+                wa, _, wn = oracle.search_by_projection(4, 0.9, True, 100, uvr, lvl, prev["desc"], kl["angle"], None, None, gp, kc, start, idx, ref["desc"],
+                                                        np.zeros(len(kc), np.uint8), np.full(len(kc), -1, np.int32))
+                assert r["count"] == wn and np.array_equal(r["table"], wa)
+            checked += 1
+        prev = ref
+    assert checked == 7
