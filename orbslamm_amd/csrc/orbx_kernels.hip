@@ -1603,7 +1603,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
                                                     const uint64_t* __restrict__ kept,
                                                     const int32_t* __restrict__ keptCount,
                                                     OrbxKeyPointDev* __restrict__ outKps,
-                                                    uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount, int nframes)
+                                                    uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount, int nframes,
+                                                    uint8_t* __restrict__ outX, int64_t xPitch)
 {
 #ifdef ORBX_ORIENT_TIMING
     uint64_t ts[10]; int nts = 0;
@@ -1799,6 +1800,31 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     if (lane == 0 && wave == 0 && fr == 0 && (bx % 29) == 0)
         printf("ORIENT bx %d l %d: barrier %.2f counts %.2f rec %.2f moments %.2f trig %.2f brief %.2f us\n", bx, l, (ts[1]-ts[0])/100.0, (ts[2]-ts[1])/100.0, (ts[3]-ts[2])/100.0, (ts[4]-ts[3])/100.0, (ts[5]-ts[4])/100.0, (ts[6]-ts[5])/100.0);
 #endif
+    // The +-1 form the stream matcher's matrix-core scan reads (orbm_kernels.hip: E2M1 nibbles in MFMA tile order, 128 bytes
+    // per descriptor), written here instead of by a launch of its own (k_expand_desc: 41 MB of traffic and a kernel per step).
+    // The wave's four descriptors go through its OWN patch words in LDS (no block barrier: nobody else reads them), then
+    // lane (keypoint kq, 32-bit chunk c) expands one chunk to 16 bytes at block (o >> 5), item c * 32 + (o & 31).
+    if (outX) {
+        uint16_t* const sw = (uint16_t*)&spatch[wave * 4 + q][0];
+        sw[ql] = (uint16_t)myWord;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int kq = (lane >> 3) & 3, c = lane & 7;
+        const int oq = __shfl(o, 16 * kq);
+        const bool aq = __shfl((int)active, 16 * kq) != 0;
+        if (lane < 32 && aq) {
+            const uint32_t bits = spatch[wave * 4 + kq][c];
+            auto pm1 = [](uint32_t b8) {  // 8 bits -> 8 nibbles, set = +1 (0x2), clear = -1 (0xA)
+                uint32_t x = (b8 | (b8 << 12)) & 0x000F000Fu;
+                x = (x | (x << 6)) & 0x03030303u;
+                x = (x | (x << 3)) & 0x11111111u;
+                return 0x22222222u | ((x ^ 0x11111111u) << 3);
+            };
+            const uint4 e = make_uint4(pm1(bits & 255), pm1((bits >> 8) & 255), pm1((bits >> 16) & 255), pm1(bits >> 24));
+            *(uint4*)(outX + (int64_t)f * xPitch + (int64_t)(oq >> 5) * 4096 + (int64_t)(c * 32 + (oq & 31)) * 16) = e;
+        }
+    }
     if (active) {
         ((uint16_t*)(outDesc + ((int64_t)f * g->maxKp + o) * 32))[ql] = (uint16_t)myWord;
         if (ql == 0) {
@@ -1832,12 +1858,17 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ src, u
 // other (one launch instead of three device-to-device copies in front of the download).
 __global__ __launch_bounds__(256) void k_roll_prev(const uint32_t* __restrict__ kpsSrc, const uint32_t* __restrict__ descSrc,
                                                   const int32_t* __restrict__ countSrc, uint32_t* __restrict__ kpsDst,
-                                                  uint32_t* __restrict__ descDst, int32_t* __restrict__ countDst)
+                                                  uint32_t* __restrict__ descDst, int32_t* __restrict__ countDst,
+                                                  const uint4* __restrict__ xSrc, uint4* __restrict__ xDst)
 {
     const int n = *countSrc;
     const int t = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
     for (int i = t; i < 7 * n; i += step) kpsDst[i] = kpsSrc[i];
     for (int i = t; i < 8 * n; i += step) descDst[i] = descSrc[i];
+    if (xSrc) {  // the +-1 form travels with the descriptors (whole 32-feature blocks of 4 KiB)
+        const int n16 = ((n + 31) >> 5) * 256;
+        for (int i = t; i < n16; i += step) xDst[i] = xSrc[i];
+    }
     if (t == 0) *countDst = n;
 }
 
