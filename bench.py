@@ -567,6 +567,7 @@ def live_streams(cfg, dev_index=0, frames=600):
       one_robot.track_d2    the same with the next frame submitted before this one is collected (tickets two deep)
       one_robot.track_d2_two_queues   two deep, frame set NOT attached: the next frame's extraction on the extractor's
                             queue runs beside this frame's search on the matcher's
+      one_robot.track_plus_local_map   track, then SearchByProjection(Frame, 3 000 local MapPoints) (Tracking.cc:1242-1249) on the same frame
       one_robot.bf          extract + brute-force match vs previous frame (BASELINE.json's pair), one frame per call
       robots_on_one_gpu     K robots = K threads on the one GPU, one frame per robot per call, and 8 cameras fed two per
                             call by 4 threads (the GPU runs about four queues at a time: tools/live_scale_probe.sh)"""
@@ -596,6 +597,9 @@ def live_streams(cfg, dev_index=0, frames=600):
                # (ORBX_LAT_PRIO=0: the extractor's queue at the matcher's priority -- a high- and a normal-priority queue busy
                # at the same time are time-sliced in ~50 us quanta, tools/live_d2_trace.sh: 2.7 k frames/s instead of 8.2 k)
                "track_d2_two_queues": run("--mode", "track", "--depth", 2, "--attach", 0, more_env={"ORBX_LAT_PRIO": "0"}),
+               # the whole front-end of one Tracking iteration: the chain above + Tracking::SearchLocalPoints' search of 3 000 local
+               # MapPoints against the same resident frame, collected one after the other as Tracking needs them
+               "track_plus_local_map": run("--mode", "full"),
                "bf": run("--mode", "bf"),
                "bf_pageable_frames": run("--mode", "bf", "--pinned", 0),
                "extract": run("--mode", "extract")},

@@ -9,7 +9,8 @@
 //   Frame::Frame        ExtractORB -> UndistortKeyPoints -> AssignFeaturesToGrid   (src/Frame.cc:175-210)
 //   TrackWithMotionModel SearchByProjection(CurrentFrame, LastFrame, th = 15, mono)  (src/Tracking.cc:925-936)
 // with keypoints + descriptors and the match table back on the host (--mode track), or extract + brute-force match
-// against the previous frame (--mode bf, BASELINE.json's headline pair), or extraction alone (--mode extract).
+// against the previous frame (--mode bf, BASELINE.json's headline pair), or extraction alone (--mode extract), or the whole
+// front-end of a Tracking iteration (--mode full: track + SearchByProjection(Frame, 3000 local MapPoints), Tracking.cc:1242-1249).
 // The GPUs exchange nothing on the data path; once per reporting interval the robots' counters (a 64-byte record per
 // GPU) are gathered with ONE ncclAllGather over RCCL -- the only collective there is.
 //
@@ -17,7 +18,7 @@
 // (the shape SURVEY.md 8d describes; SplitMix64, no Python).
 //
 // build:  hipcc -O2 -std=c++17 examples/multi_robot.cpp -Iinclude -Lorbslamm_amd -lorbslamm_hip -lrccl -Wl,-rpath,'$ORIGIN/../orbslamm_amd' -o examples/multi_robot
-// usage:  multi_robot [--gpus N] [--robots R] [--frames F] [--warmup W] [--mode track|bf|extract] [--depth 1|2]
+// usage:  multi_robot [--gpus N] [--robots R] [--frames F] [--warmup W] [--mode track|bf|extract|full] [--depth 1|2]
 //                     [--per-call 1|2 (cameras whose frames one thread puts through the chain together)] [--attach 0|1] [--pinned 0|1] [--w 1241 --h 376 --nfeat 2000] [--interval 200] [--json] [--dump FILE]
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -111,7 +112,8 @@ struct Robot {
     void run(std::atomic<int>& ready, std::atomic<bool>& go)
     {
         const Args& A = *a;
-        const bool track = A.mode == "track", bf = A.mode == "bf";
+        const bool full = A.mode == "full";   // track + Tracking::SearchLocalPoints' search: the whole front-end of one Tracking iteration
+        const bool track = A.mode == "track" || full, bf = A.mode == "bf";
         OrbxParams prm{A.nfeat, 1.2f, 8, 20, 7};
         orbx_t* ex = nullptr;
         const int P = A.per_call;   // cameras this thread feeds per call (their frames go through the chain together)
@@ -148,6 +150,17 @@ struct Robot {
         ready.fetch_add(1);
         while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
 
+        // --mode full: the "local map" of frame i = the keypoints of the two frames before it (what the ring held there), as
+        // projected MapPoints: u, v = the keypoint, radius = 4 * th * scale[level] (RadiusByViewingCos, th = 1), window
+        // [level - 1, level], its descriptor -- at most 3000.  Built once per ring position during the warm-up (the ring
+        // repeats), so the timed frames pass ready arrays: in the reference they come from Frame::isInFrustum on the host.
+        struct LocalMap { std::vector<float> uvr; std::vector<int8_t> lvl; std::vector<uint8_t> desc; int n = 0; };
+        std::vector<LocalMap> lmap(full ? nring : 0);
+        std::vector<std::vector<OrbxKeyPoint>> rkps(full ? nring : 0);
+        std::vector<std::vector<uint8_t>> rdesc(full ? nring : 0);
+        float sfl[ORBX_MAX_LEVELS] = {0};
+        if (full) OX(orbx_scale_tables(ex, sfl, nullptr, nullptr, nullptr));
+        OrbmProjParams pp3{3, 0.8f, 0, 100};
         using clk = std::chrono::steady_clock;
         int pendingTicket = -1, pendingIdx = -1;
         clk::time_point pendingT0{};
@@ -176,6 +189,26 @@ struct Robot {
                 fwrite(v.desc, 32, (size_t)n0, df);
                 if (bf) { fwrite(v.match, 4, (size_t)n0, df); fwrite(v.nmatch, 4, 1, df); }
             }
+            if (full && rkps[idx % nring].empty() && n0 > 0) {   // (warm-up, first pass over the ring)
+                rkps[idx % nring].assign(v.kps, v.kps + n0);
+                rdesc[idx % nring].assign(v.desc, v.desc + (size_t)n0 * 32);
+                const int r = idx % nring, a1 = (r + nring - 1) % nring, a2 = (r + nring - 2) % nring;
+                for (int rr = 0; rr < nring; rr++) {   // any ring position whose two predecessors are known now gets its local map
+                    const int p1 = (rr + nring - 1) % nring, p2 = (rr + nring - 2) % nring;
+                    if (lmap[rr].n || rkps[p1].empty() || rkps[p2].empty()) continue;
+                    LocalMap& lm = lmap[rr];
+                    for (int src = 0; src < 2 && lm.n < 3000; src++) {
+                        const auto& K = rkps[src ? p2 : p1]; const auto& D = rdesc[src ? p2 : p1];
+                        for (size_t k = 0; k < K.size() && lm.n < 3000; k++, lm.n++) {
+                            const int lv = K[k].octave;
+                            lm.uvr.push_back(K[k].x); lm.uvr.push_back(K[k].y); lm.uvr.push_back(4.0f * sfl[lv]);
+                            lm.lvl.push_back((int8_t)(lv - 1)); lm.lvl.push_back((int8_t)lv);
+                            lm.desc.insert(lm.desc.end(), D.begin() + k * 32, D.begin() + (k + 1) * 32);
+                        }
+                    }
+                }
+                (void)a1; (void)a2;
+            }
             OX(orbx_release(ex, ticket));
             if (track && idx > 0) {
                 const int32_t *assign, *nmp; int np, c2;
@@ -185,6 +218,16 @@ struct Robot {
                 if (df) { fwrite(assign, 4, (size_t)n0, df); fwrite(nmp, 4, 1, df); }
             }
             if (df) fclose(df);
+            if (full) {
+                LocalMap& lm = lmap[idx % nring];
+                if (lm.n > 0) {   // Tracking::SearchLocalPoints (Tracking.cc:1242-1249): the second search of the iteration, against the same resident frame
+                    OX(orbm_track_local_points(fs, (idx & 3) * P, &pp3, lm.uvr.data(), lm.lvl.data(), lm.desc.data(), nullptr, nullptr, lm.n, nullptr));
+                    const int32_t *a3, *n3; int np3, c3;
+                    OX(orbm_track_results(fs, 0, &a3, &n3, &np3, &c3));
+                    nm += n3[0];
+                    cs ^= (uint64_t)(uint32_t)n3[0] * 2654435761ull;
+                }
+            }
             const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
             if (idx >= A.warmup) {
                 lat_ms.push_back(ms);
@@ -257,7 +300,9 @@ int main(int argc, char** argv)
     if (ndev < 1) { fprintf(stderr, "no HIP device: the ORB front-end has no CPU fallback\n"); return 3; }
     if (A.gpus < 1 || A.gpus > ndev) { fprintf(stderr, "--gpus %d but %d device(s) visible\n", A.gpus, ndev); return 2; }
     if (A.robots < A.gpus) A.robots = A.gpus;
-    if (A.mode != "track" && A.mode != "bf" && A.mode != "extract") { fprintf(stderr, "--mode track|bf|extract\n"); return 2; }
+    if (A.mode != "track" && A.mode != "bf" && A.mode != "extract" && A.mode != "full") { fprintf(stderr, "--mode track|bf|extract|full\n"); return 2; }
+    if (A.mode == "full" && (A.per_call != 1 || A.depth != 1)) { fprintf(stderr, "--mode full: one camera per call, one ticket deep\n"); return 2; }
+    if (A.mode == "full" && A.warmup < 12) A.warmup = 12;   // the ring's local maps are built during the warm-up
     if (A.depth != 1 && A.depth != 2) { fprintf(stderr, "--depth 1|2\n"); return 2; }
     if (A.per_call < 1 || A.per_call > 2 || (A.per_call > 1 && A.mode == "bf")) { fprintf(stderr, "--per-call 1|2 (2: modes track and extract -- the brute-force match is against the SAME camera's previous frame)\n"); return 2; }
 
