@@ -548,8 +548,35 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
                               "frame, Frame), nnratio 0.7, rotation check) + orbm_bow_results (table in pinned host memory); b1 = one frame per call, batched = B frames "
                               "and B - 1 pairs per step; vocabulary: synthetic complete tree k=10, L=6 (1.1 M nodes)"}
         G.close()
+        # the same on a RAGGED tree of the published ORBvoc.txt's size (1.06 M nodes, words at different depths; the file
+        # itself is absent from the reference checkout) and on a strongly ragged one (2 .. 10 children, 10 % early leaves)
+        for tag, rg in (("orbvoc_sized_ragged", 0.994), ("strongly_ragged", True)):
+            vr = synth.make_vocabulary(10, 6, ragged=rg)
+            Gr = ORBVocabulary(10, 6, 0, 0, vr["parent"], vr["is_leaf"], vr["desc"], vr["weight"], device=ex.device)
+            fs.compute_bow(Gr, base, B, 4)
+            fs.sync()
+            tr = []
+            for i in range(40):
+                t0 = time.perf_counter()
+                fs.compute_bow(Gr, base + B - 1, 1, 4)
+                fs.search_by_bow([base + B - 2], [base + B - 1], 0.7, True)
+                gmr, gnr = fs.bow_results()
+                tr.append(time.perf_counter() - t0)
+            gmr, gnr = gmr[0].copy(), int(gnr[0])
+            reps, t0 = 50, time.perf_counter()
+            for _ in range(reps):
+                fs.compute_bow(Gr, base, B, 4); fs.search_by_bow(kfs, curs, 0.7, True)
+            fs.bow_results()
+            dtr = (time.perf_counter() - t0) / reps
+            Or = ob.Vocabulary(10, 6, 0, 0, vr["parent"], vr["is_leaf"], vr["desc"], vr["weight"])
+            _, fvc_r = Or.transform(dc, 4)
+            _, fvl_r = Or.transform(dl, 4)
+            wmr, wnr = ob.search_by_bow(dl, kl["angle"], None, fvl_r, dc, kc["angle"], None, fvc_r, 0.7, True, True)
+            out["bow"][tag] = {"nodes": int(len(vr["parent"])), "words": int(vr["is_leaf"].sum()), "b1_ms_median": float(np.median(np.array(tr[5:]) * 1e3)),
+                               "batched_frames_per_s": B / dtr, "matches": gnr, "parity_ok": bool(gnr == wnr and np.array_equal(gmr[:len(kc)], wmr))}
+            Gr.close()
     except Exception as e:  # never lose the record over the secondary block
-        out["bow"] = {"error": repr(e)}
+        out["bow"] = dict(out.get("bow") or {}, error=repr(e))
     fs.close()
     m.close()
     return out
