@@ -157,9 +157,17 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* keys, uint64_t* tmp, i
         const uint64_t k = keys[i];
         if (k != ~0ull) { const int b = bucket(k); tmp[cnt[b] + atomicAdd(&cur[b], 1)] = k; }
     }
+    // Crowded buckets -- many features on ONE word or vocabulary node (the linear map cannot part them: a ragged tree's
+    // early leaves collect hundreds of a frame's features) -- are not left to one thread's insertion sort (quadratic: a
+    // bucket of 500 keys cost 1.5 ms) but rank-sorted by the whole workgroup, one after the other.
+    constexpr int kCrowd = 16;
+    __shared__ int sBigN;
+    __shared__ uint16_t sBig[256];   // more than kCrowd keys each: at most P / 17 <= 240 of them (P <= 4096 here)
+    if (tid == 0) sBigN = 0;
     __syncthreads();
     for (int b = tid; b < P; b += kAggThreads) {
         const int s0 = cnt[b], e0 = s0 + cur[b];
+        if (e0 - s0 > kCrowd) { const int at = atomicAdd(&sBigN, 1); if (at < 256) sBig[at] = (uint16_t)b; continue; }
         for (int i = s0 + 1; i < e0; i++) {
             const uint64_t x = tmp[i];
             int j = i - 1;
@@ -168,6 +176,19 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* keys, uint64_t* tmp, i
         }
     }
     __syncthreads();
+    const int nBig = min(sBigN, 256);
+    for (int bi = 0; bi < nBig; bi++) {   // (keys[] is free since the scatter: the sorted run is built there, then moved back)
+        const int b = sBig[bi], s0 = cnt[b], k = cur[b];
+        for (int e = tid; e < k; e += kAggThreads) {
+            const uint64_t x = tmp[s0 + e];
+            int rank = 0;
+            for (int j = 0; j < k; j++) rank += tmp[s0 + j] < x ? 1 : 0;   // keys are distinct (the feature index is part of them)
+            keys[s0 + rank] = x;
+        }
+        __syncthreads();
+        for (int e = tid; e < k; e += kAggThreads) tmp[s0 + e] = keys[s0 + e];
+        __syncthreads();
+    }
     for (int i = tid; i < P; i += kAggThreads) keys[i] = i < m ? tmp[i] : ~0ull;
     __syncthreads();
 }
