@@ -379,7 +379,30 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
     out["b1"] = {"ms_median": float(np.median(lat)), "ms_mean": float(lat.mean()), "fps": float(1e3 / lat.mean()), "frames": int(len(lat)),
                  "search_ms_median": float(np.median(lat_search)), "search_ms_mean": float(lat_search.mean()),
                  "matches_mean": float(np.mean(nm)), "rounds_last": fs.stats(0)[0], "candidates_last": fs.stats(0)[1],
-                 "what": "orbx_extract_match_batch(B=1, no brute-force match) + orbm_frameset_build_from_extractor + orbm_track_frames + orbm_track_results; search_ms = the last three"}
+                 "what": "round 3's call sequence, kept for comparison: orbx_extract_match_batch(B=1, no brute-force match), THEN orbm_frameset_build_from_extractor + "
+                         "orbm_track_frames + orbm_track_results on the matcher's stream (a host hop and a cross-stream hand-over in between); search_ms = the last three"}
+    # the same through the round-4 form: the frame set attached to the extractor, frame + build + search submitted together (one
+    # chain on the device), still through this Python mirror and from a pageable frame (live_streams has the native caller)
+    if hasattr(fs, "attach") and hasattr(ex, "submit_host"):
+        fs.attach(ex)
+        lat2 = []
+        for i in range(400):
+            f = frames[i % len(frames)]
+            slot, prev = i & 1, (i & 1) ^ 1
+            t0 = time.perf_counter()
+            tk = ex.submit_host(f[None], match=False)
+            fs.build_from_extractor(slot, ex)
+            if i:
+                fs.track([slot], [prev], th=15.0)
+            ex.collect_host(tk, view=True)
+            if i:
+                fs.results()
+            lat2.append(time.perf_counter() - t0)
+        fs.attach(None)
+        lat2 = np.array(lat2[20:]) * 1e3
+        out["b1_attached"] = {"ms_median": float(np.median(lat2)), "ms_mean": float(lat2.mean()), "fps": float(1e3 / lat2.mean()),
+                              "what": "orbm_frameset_attach, then per frame orbx_submit_batch(B=1) + orbm_frameset_build_from_extractor + orbm_track_frames + "
+                                      "orbx_collect_view + orbm_track_results (Python mirror, pageable frame)"}
     # ---- batched: B resident frames per step; pair p = (frame p, frame p-1), the first against the previous step's last
     pool = len(dargs)
 
