@@ -524,6 +524,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     for (;; round++) {
         int32_t* minUnd = minUnd0 + (round & 1) * c.tCap;
         int32_t* idle = minUnd0 + ((round + 1) & 1) * c.tCap;
+        if (round == 1) ORBT_MARK(11);
         if constexpr (L) {
             // over the LIVE entries only (those of undecided queries whose train feature is still free for them -- both
             // conditions are final once false), compacting the list for the next round on the way: a round costs what is
@@ -531,27 +532,37 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
             const uint16_t* lv = live0 + (round & 1) * c.ldsCand;
             uint16_t* nx = live0 + ((round + 1) & 1) * c.ldsCand;
             const int nLive = sLive[round & 1];
-            for (int i0 = 0; i0 < nLive; i0 += kThreads) {
-                const int i = i0 + tid;
-                bool keep = false;
-                int k = 0;
-                if (i < nLive) {
-                    k = lv[i];
-                    const uint32_t ex = candL[k];
-                    const int q = ownL[k], d = (int)(ex >> 20), t = (int)(ex & 0xFFFF);
-                    const uint8_t st = qst[q];
-                    keep = !(st & kQDecided) && d <= dMax && occBy[t] >= q;
-                    if (keep) {
-                        if ((st & kQBlocking) && d <= c.thDist) atomicMin(&minUnd[t], q);
-                        atomicMin(&best1[q], (d << 22) | (k - qoff[q]));
-                    }
+            // two entries per thread and trip, their LDS reads issued side by side: a round is a chain of LDS round trips
+            // (live slot -> entry, owner -> state, occupancy), and with one entry per trip the slowest wave of a
+            // 1024-thread workgroup spent 2.2 us here in an early round (tools/resolve_round_phases.py)
+            for (int i0 = 0; i0 < nLive; i0 += 2 * kThreads) {
+                const int ia = i0 + tid, ib = ia + kThreads;
+                const bool ina = ia < nLive, inb = ib < nLive;
+                const int ka = lv[ina ? ia : 0], kb = lv[inb ? ib : 0];
+                const uint32_t exa = candL[ka], exb = candL[kb];
+                const int qa = ownL[ka], qb = ownL[kb];
+                const int da = (int)(exa >> 20), ta = (int)(exa & 0xFFFF), db = (int)(exb >> 20), tb = (int)(exb & 0xFFFF);
+                const uint8_t sa = qst[qa], sb = qst[qb];
+                const int oa = occBy[ta], ob = occBy[tb];
+                const int fa = qoff[qa], fb = qoff[qb];
+                const bool keepa = ina && !(sa & kQDecided) && da <= dMax && oa >= qa;
+                const bool keepb = inb && !(sb & kQDecided) && db <= dMax && ob >= qb;
+                if (keepa) {
+                    if ((sa & kQBlocking) && da <= c.thDist) atomicMin(&minUnd[ta], qa);
+                    atomicMin(&best1[qa], (da << 22) | (ka - fa));
                 }
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(keep);
-                if (bal) {
+                if (keepb) {
+                    if ((sb & kQBlocking) && db <= c.thDist) atomicMin(&minUnd[tb], qb);
+                    atomicMin(&best1[qb], (db << 22) | (kb - fb));
+                }
+                const uint64_t bala = __builtin_amdgcn_ballot_w64(keepa), balb = __builtin_amdgcn_ballot_w64(keepb);
+                if (bala | balb) {
+                    const int na = __popcll(bala);
                     int base = 0;
-                    if ((tid & 63) == 0) base = atomicAdd(&sLive[(round + 1) & 1], __popcll(bal));
+                    if ((tid & 63) == 0) base = atomicAdd(&sLive[(round + 1) & 1], na + __popcll(balb));
                     base = __shfl(base, 0);
-                    if (keep) nx[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0))] = (uint16_t)k;
+                    if (keepa) nx[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bala >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bala, 0))] = (uint16_t)ka;
+                    if (keepb) nx[base + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(balb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)balb, 0))] = (uint16_t)kb;
                 }
             }
         } else {
@@ -566,7 +577,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
                 atomicMin(&best1[q], (d << 22) | (k - qoff[q]));
             }
         }
-        if (tid == 0) sPending[(round + 1) % 3] = 0;  // three counters in rotation: the one being read after a round's last barrier is not reset before the round after next
+        if (round == 1) ORBT_MARK(12);
         __syncthreads();
         if (c.mode == 3) {  // the runner-up: the best of what is left (ORBmatcher.cc:102-114)
             const int nIt = L ? sLive[(round + 1) & 1] : total;
@@ -581,33 +592,60 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
             }
             __syncthreads();
         }
+        if (round == 1) ORBT_MARK(13);
         int pend = 0;
-        for (int q = tid; q < nq; q += kThreads) {
-            const uint8_t st = qst[q];
-            if (st & kQDecided) continue;
-            const int k1 = best1[q], k2 = best2[q];
-            best1[q] = kFree; best2[q] = kFree;
-            const int b1 = k1 == kFree ? 256 : k1 >> 22;
-            if (b1 > c.thDist || b1 >= 256) { qst[q] = st | kQDecided; continue; }  // can only get worse: no match
-            const uint32_t e1 = entry(qoff[q] + (k1 & 0x3FFFFF)).x;
-            const int t1 = (int)(e1 & 0xFFFF);
-            const bool has2 = c.mode == 3 && k2 != kFree;
-            const uint32_t e2 = has2 ? entry(qoff[q] + (k2 & 0x3FFFFF)).x : 0u;
-            const bool stable = minUnd[t1] >= q && (!has2 || minUnd[e2 & 0xFFFF] >= q);
-            if (!stable) { pend++; continue; }
-            qst[q] = st | kQDecided;
-            if (has2 && ((e1 >> 16) & 15) == ((e2 >> 16) & 15) &&
-                (float)b1 > __fmul_rn(c.nnratio, (float)(k2 >> 22))) continue;  // ORBmatcher.cc:120-121
-            nAcc++;
-            atomicMax(&winner[t1], q);
-            if (st & kQBlocking) occBy[t1] = q;
-            qres[q] = t1;
+        // two queries per thread and trip (independent of each other: nothing written here is read here), their reads -- state
+        // and bests, list offset, the entries, the posts on them -- issued side by side
+        for (int q0 = tid; q0 < nq; q0 += 2 * kThreads) {
+            int qq[2]; bool und[2], go[2], has2[2]; uint8_t st[2]; int k1[2], k2[2], b1[2]; uint32_t e1[2], e2[2]; int m1[2], m2[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int q = q0 + u * kThreads;
+                const bool in = q < nq;
+                qq[u] = in ? q : q0;
+                st[u] = qst[qq[u]]; k1[u] = best1[qq[u]]; k2[u] = best2[qq[u]];
+                und[u] = in && !(st[u] & kQDecided);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                b1[u] = k1[u] == kFree ? 256 : k1[u] >> 22;
+                go[u] = und[u] && !(b1[u] > c.thDist || b1[u] >= 256);
+                has2[u] = go[u] && c.mode == 3 && k2[u] != kFree;
+                const int off = qoff[qq[u]];
+                e1[u] = go[u] ? entry(off + (k1[u] & 0x3FFFFF)).x : 0u;
+                e2[u] = has2[u] ? entry(off + (k2[u] & 0x3FFFFF)).x : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                m1[u] = go[u] ? minUnd[e1[u] & 0xFFFF] : 0;
+                m2[u] = has2[u] ? minUnd[e2[u] & 0xFFFF] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (!und[u]) continue;
+                const int q = qq[u];
+                best1[q] = kFree; best2[q] = kFree;
+                if (!go[u]) { qst[q] = st[u] | kQDecided; continue; }  // can only get worse: no match
+                const int t1 = (int)(e1[u] & 0xFFFF);
+                const bool stable = m1[u] >= q && (!has2[u] || m2[u] >= q);
+                if (!stable) { pend++; continue; }
+                qst[q] = st[u] | kQDecided;
+                if (has2[u] && ((e1[u] >> 16) & 15) == ((e2[u] >> 16) & 15) &&
+                    (float)b1[u] > __fmul_rn(c.nnratio, (float)(k2[u] >> 22))) continue;  // ORBmatcher.cc:120-121
+                nAcc++;
+                atomicMax(&winner[t1], q);
+                if (st[u] & kQBlocking) occBy[t1] = q;
+                qres[q] = t1;
+            }
         }
+        if (round == 1) ORBT_MARK(14);
         for (int t = tid; t < nt; t += kThreads) idle[t] = kFree;
         if (L && tid == 0) sLive[round & 1] = 0;   // read in this round's first pass, filled again by the next round's
-        if (pend) atomicAdd(&sPending[round % 3], pend);
-        __syncthreads();
-        if (sPending[round % 3] == 0) break;
+        // "anybody still undecided?" rides on the round's last barrier (every thread with pending queries used to add to ONE
+        // LDS word: up to a thousand serialised atomics, 2 us of an early round)
+        const int anyPend = __syncthreads_or(pend);
+        if (round == 1) ORBT_MARK(15);
+        if (!anyPend) break;
     }
     ORBT_MARK(2);
 
@@ -622,17 +660,20 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
             best1[q] = bin;  // (the table is free now)
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) {   // (the first wave: its lanes fetch the bins in ONE LDS trip, lane 0 then walks them in registers --
+                          // thirty dependent LDS reads by one thread were 3 us with the whole workgroup waiting)
+            const int hl = hist[tid & 31];
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+#pragma unroll
             for (int i = 0; i < orbm::kHistoLength; i++) {
-                const int s = hist[i];
+                const int s = __builtin_amdgcn_readlane(hl, i);
                 if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
                 else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
                 else if (s > max3) { max3 = s; ind3 = i; }
             }
             if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
             else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-            sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
+            if (tid == 0) { sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3; }
         }
         __syncthreads();
     }
