@@ -42,6 +42,26 @@ __device__ __forceinline__ int rot_bin(float aq, float at)
     return bin;
 }
 
+// ComputeThreeMaxima (ORBmatcher.cc:1603-1644) over the 30 rotation bins in sh[0..31], by the workgroup's FIRST WAVE (call it
+// with tid < 64, all 64 lanes): the bins come in with one LDS trip, the walk -- strict >, ties keep the earlier bin, second /
+// third dropped below a tenth of the first -- runs on wave-uniform values (v_readlane).  One thread reading the bins one
+// after the other cost thirty dependent LDS round trips (3 us) with the whole workgroup waiting at the barrier behind it.
+__device__ __forceinline__ void three_maxima_wave(const int* sh, int* sInd)
+{
+    const int hl = sh[threadIdx.x & 31];
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+#pragma unroll
+    for (int i = 0; i < kHistoLength; i++) {  // :1609-1633
+        const int s = __builtin_amdgcn_readlane(hl, i);
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+    if ((threadIdx.x & 63) == 0) { sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3; }
+}
+
 // Brute-force best/second over a CHUNK of the train descriptors.
 // grid (queryBlocks, frames, chunks): chunking multiplies the wave count (2000 queries are
 // only 32 waves per frame) and the scalar loads of U train descriptors are issued one
@@ -451,18 +471,7 @@ __global__ __launch_bounds__(256) void k_match_prune(MatchIO q, int qslot0, int 
     if (tid < 32) { sh[tid] = hist[f * 32 + tid]; hist[f * 32 + tid] = 0; }
     if (tid == 0) sCnt = 0;
     __syncthreads();
-    if (tid == 0) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < kHistoLength; i++) {  // :1609-1633
-            const int s = sh[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
-        }
-        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
-    }
+    if (tid < 64) three_maxima_wave(sh, sInd);
     __syncthreads();
     int local = 0;
     for (int i = tid; i < nq; i += 256) {
@@ -511,18 +520,7 @@ __global__ __launch_bounds__(1024) void k_match_accept_prune(AcceptArgs a, int n
         if (bin >= 0) { a.binOf[(int64_t)f * a.matchPitch + qi] = (uint8_t)bin; atomicAdd(&sh[bin], 1); }
     }
     __syncthreads();
-    if (tid == 0) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < kHistoLength; i++) {  // :1609-1633
-            const int s = sh[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
-        }
-        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
-    }
+    if (tid < 64) three_maxima_wave(sh, sInd);
     __syncthreads();
     int local = 0;
     for (int qi = tid; qi < nq; qi += 1024) {  // the thread re-reads what it wrote above
@@ -800,18 +798,7 @@ __global__ __launch_bounds__(256) void k_bow_prune_set(BowSetArgs s, int32_t* __
     if (s.checkOri)
         for (int i = tid; i < n; i += 256) if (s.match[p * C + i] >= 0) atomicAdd(&sh[s.binOf[p * C + i]], 1);
     __syncthreads();
-    if (tid == 0) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < kHistoLength; i++) {
-            const int v = sh[i];
-            if (v > max1) { max3 = max2; max2 = max1; max1 = v; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (v > max2) { max3 = max2; max2 = v; ind3 = ind2; ind2 = i; }
-            else if (v > max3) { max3 = v; ind3 = i; }
-        }
-        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
-    }
+    if (tid < 64) three_maxima_wave(sh, sInd);
     __syncthreads();
     int local = 0;
     for (int i = tid; i < n; i += 256) {
@@ -845,18 +832,7 @@ __global__ __launch_bounds__(256) void k_prune_flat(int32_t* __restrict__ match,
     if (checkOri)
         for (int i = tid; i < n; i += 256) if (match[i] >= 0) atomicAdd(&sh[binOf[i]], 1);
     __syncthreads();
-    if (tid == 0) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < kHistoLength; i++) {
-            const int s = sh[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
-        }
-        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-        sInd[0] = ind1; sInd[1] = ind2; sInd[2] = ind3;
-    }
+    if (tid < 64) three_maxima_wave(sh, sInd);
     __syncthreads();
     int local = 0;
     for (int i = tid; i < n; i += 256) {
