@@ -1854,6 +1854,13 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ src, u
     if (i < n16) ((u32x4*)dst)[i] = __builtin_nontemporal_load((const u32x4*)src + i);
 }
 
+// raised behind a copy kernel that wrote a caller's results into pinned host memory: the host polls it instead of waiting
+// for the stream
+__global__ void k_raise_flag(int32_t* flag, int32_t value)
+{
+    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
+
 // The stream's last frame becomes the previous frame of the next batch: slot `src` of one result set -> slot 0 of the
 // other (one launch instead of three device-to-device copies in front of the download).
 __global__ __launch_bounds__(256) void k_roll_prev(const uint32_t* __restrict__ kpsSrc, const uint32_t* __restrict__ descSrc,
