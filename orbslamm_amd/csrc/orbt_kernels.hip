@@ -36,8 +36,12 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kFree = 0x7FFFFFFF;
 constexpr int kMaxQueryIters = 32;  // decided-bit per (thread, iteration): nq <= 32 * 1024
 
+#ifndef ORBT_ROUND
+#define ORBT_ROUND 1   // the round whose phases ORBT_MARK(11..15) time
+#endif
 #ifdef ORBT_PHASE_TIMING  // tools/proj_phases.sh: where a workgroup of the resolve / candidates kernels spends its time (100 MHz wall clock)
 __device__ unsigned long long g_orbtPhase[16];
+__device__ int g_orbtCensus[64][2];   // per round of the resolve: live entries, undecided queries at its head
 #define ORBT_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_orbtPhase[i] = wall_clock64(); } while (0)
 #else
 #define ORBT_MARK(i) do { } while (0)
@@ -228,6 +232,7 @@ struct ProjCommon {
     int32_t stageCap;  // candidates: entries (8 bytes) of a slice's staging buffer in LDS behind the grid
     int32_t qCap;      // resolve: queries whose tables fit in LDS   } more of either: the rounds work in memory
     int32_t ldsCand;   // resolve: candidate entries that fit in LDS }
+    int32_t waveTail;    // resolve: the last rounds by the first wave alone (0: the whole workgroup to the end)
     int32_t interleave;  // candidates: deal the queries to the slices wave by wave instead of in consecutive runs (few pairs)
 };
 
@@ -480,11 +485,12 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
 // reads its best (mode 3: a second flat pass finds the runner-up), checks that nobody lower has posted on it and
 // commits.  A thread-per-query walk of the lists costs every wave its longest list, a chain of dependent LDS reads per
 // entry, in every round; the flat loop keeps all lanes busy and its reads independent.
-// LDS (dynamic): occBy, minUnd[2], winner (4 * tCap dwords) | per query: offset, best, second, result (4 * qCap dwords)
-// | candidates (ldsCand dwords) | their queries (ldsCand halves) | two live lists (2 * ldsCand halves) | per query: state
-// byte (qCap bytes).
+// LDS (dynamic): occBy, minUnd (+ tCap dwords unused since the table is keyed by round), winner (4 * tCap dwords) | per
+// query: offset, best, second, result (4 * qCap dwords) | candidates (ldsCand dwords) | their queries (ldsCand halves) |
+// two live lists (2 * ldsCand halves) | per query: state byte (qCap bytes) | two lists of undecided queries (2 * qCap halves).
 // L = false: the per-query tables and the lists stay in memory (more queries or candidates than the LDS plan holds).
 constexpr uint8_t kQDecided = 1, kQBlocking = 2;
+constexpr int kTailLive = 512, kTailQueries = 128;   // at most this much left: the first wave runs the remaining rounds alone
 
 template <bool L>
 __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const ProjCommon& c, int nq, int nt, int total,
@@ -499,12 +505,14 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     const int dMax = c.mode == 3 ? 256 : c.thDist;
     int32_t *qoff, *best1, *best2, *qres;
     uint32_t* candL = nullptr; uint16_t* ownL = nullptr; uint16_t* live0 = nullptr; uint8_t* qst;
+    uint16_t* pend0 = nullptr;   // L: the undecided queries, two lists used by alternate rounds (a round costs what is still open)
     if constexpr (L) {
         qoff = qtab; best1 = qtab + c.qCap; best2 = qtab + 2 * c.qCap; qres = qtab + 3 * c.qCap;
         candL = (uint32_t*)(qtab + 4 * c.qCap);
         ownL = (uint16_t*)(candL + c.ldsCand);
         live0 = ownL + c.ldsCand;
         qst = (uint8_t*)(live0 + 2 * c.ldsCand);
+        pend0 = (uint16_t*)(qst + c.qCap);
         for (int k = tid; k < total; k += kThreads) { const uint2 e = P.cand[k]; candL[k] = e.x; ownL[k] = (uint16_t)e.y; live0[k] = (uint16_t)k; }
         if (tid == 0) { sLive[0] = total; sLive[1] = 0; }
     } else {
@@ -520,11 +528,28 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     __syncthreads();
     ORBT_MARK(1);
 
-    int nAcc = 0, round = 0;
-    for (;; round++) {
-        int32_t* minUnd = minUnd0 + (round & 1) * c.tCap;
-        int32_t* idle = minUnd0 + ((round + 1) & 1) * c.tCap;
-        if (round == 1) ORBT_MARK(11);
+    // One round, run by the first G threads of the workgroup: all 1024, or -- in the tail, where a handful of live entries and
+    // undecided queries are left and a round is nothing but its chain of ~10 dependent LDS round trips and two barriers --
+    // the first wave alone: no s_barrier, no other waves in the LDS queue (tools/resolve_round_phases.py: 1.8 us per
+    // round for the workgroup however little is left).  Returns whether anybody is still undecided.
+    int nAcc = 0;
+    auto one_round = [&](auto gc, const int round) -> int {
+        constexpr int G = decltype(gc)::value;
+        auto bar = [&]() {
+            if constexpr (G == kThreads) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+        };
+        // minUnd[t]: the lowest blocking query that posted on train feature t in THIS round, kept as round + 1 << 16 | 0xFFFF - q
+        // under atomicMax -- what an earlier round left is simply older, nothing to clear between rounds (a pass over
+        // the table and its share of a barrier: 0.7 of a round's ~2.2 us)
+        uint32_t* minUnd = (uint32_t*)minUnd0;
+        const uint32_t rkey = (uint32_t)(round + 1) << 16;
+        auto posted = [&](uint32_t t) -> int { const uint32_t m = minUnd[t]; return (m & 0xFFFF0000u) == rkey ? (int)(0xFFFFu - (m & 0xFFFFu)) : kFree; };
+        const int nPendList = L ? sPending[round & 1] : 0;   // (final since the last round's closing barrier)
+#ifdef ORBT_PHASE_TIMING
+        if (L && threadIdx.x == 0 && blockIdx.x == 0 && round < 64) { g_orbtCensus[round][0] = sLive[round & 1]; g_orbtCensus[round][1] = round ? nPendList : nq; if (round < 63) g_orbtCensus[round + 1][0] = -1; }
+#endif
+        if (round == ORBT_ROUND) ORBT_MARK(11);
         if constexpr (L) {
             // over the LIVE entries only (those of undecided queries whose train feature is still free for them -- both
             // conditions are final once false), compacting the list for the next round on the way: a round costs what is
@@ -535,8 +560,8 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
             // two entries per thread and trip, their LDS reads issued side by side: a round is a chain of LDS round trips
             // (live slot -> entry, owner -> state, occupancy), and with one entry per trip the slowest wave of a
             // 1024-thread workgroup spent 2.2 us here in an early round (tools/resolve_round_phases.py)
-            for (int i0 = 0; i0 < nLive; i0 += 2 * kThreads) {
-                const int ia = i0 + tid, ib = ia + kThreads;
+            for (int i0 = 0; i0 < nLive; i0 += 2 * G) {
+                const int ia = i0 + tid, ib = ia + G;
                 const bool ina = ia < nLive, inb = ib < nLive;
                 const int ka = lv[ina ? ia : 0], kb = lv[inb ? ib : 0];
                 const uint32_t exa = candL[ka], exb = candL[kb];
@@ -548,11 +573,11 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
                 const bool keepa = ina && !(sa & kQDecided) && da <= dMax && oa >= qa;
                 const bool keepb = inb && !(sb & kQDecided) && db <= dMax && ob >= qb;
                 if (keepa) {
-                    if ((sa & kQBlocking) && da <= c.thDist) atomicMin(&minUnd[ta], qa);
+                    if ((sa & kQBlocking) && da <= c.thDist) atomicMax(&minUnd[ta], rkey | (uint32_t)(0xFFFF - qa));
                     atomicMin(&best1[qa], (da << 22) | (ka - fa));
                 }
                 if (keepb) {
-                    if ((sb & kQBlocking) && db <= c.thDist) atomicMin(&minUnd[tb], qb);
+                    if ((sb & kQBlocking) && db <= c.thDist) atomicMax(&minUnd[tb], rkey | (uint32_t)(0xFFFF - qb));
                     atomicMin(&best1[qb], (db << 22) | (kb - fb));
                 }
                 const uint64_t bala = __builtin_amdgcn_ballot_w64(keepa), balb = __builtin_amdgcn_ballot_w64(keepb);
@@ -566,22 +591,22 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
                 }
             }
         } else {
-        for (int k = tid; k < total; k += kThreads) {
+        for (int k = tid; k < total; k += G) {
                 const uint2 e = entry(k);
                 const int q = (int)e.y, d = (int)(e.x >> 20), t = (int)(e.x & 0xFFFF);
                 const uint8_t st = qst[q];
                 if ((st & kQDecided) || d > dMax) continue;
                 if (occBy[t] < q) continue;  // taken before this query's turn (or occupied on entry)
                 // a query without observations takes nothing away from anybody; nobody can take what is beyond the threshold
-                if ((st & kQBlocking) && d <= c.thDist) atomicMin(&minUnd[t], q);
+                if ((st & kQBlocking) && d <= c.thDist) atomicMax(&minUnd[t], rkey | (uint32_t)(0xFFFF - q));
                 atomicMin(&best1[q], (d << 22) | (k - qoff[q]));
             }
         }
-        if (round == 1) ORBT_MARK(12);
-        __syncthreads();
+        if (round == ORBT_ROUND) ORBT_MARK(12);
+        bar();
         if (c.mode == 3) {  // the runner-up: the best of what is left (ORBmatcher.cc:102-114)
             const int nIt = L ? sLive[(round + 1) & 1] : total;
-            for (int i = tid; i < nIt; i += kThreads) {
+            for (int i = tid; i < nIt; i += G) {
                 int k = i;
                 if constexpr (L) k = (live0 + ((round + 1) & 1) * c.ldsCand)[i];
                 const uint2 e = entry(k);
@@ -590,21 +615,29 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
                 const int key = ((int)(e.x >> 20) << 22) | (k - qoff[q]);
                 if (key != best1[q]) atomicMin(&best2[q], key);
             }
-            __syncthreads();
+            bar();
         }
-        if (round == 1) ORBT_MARK(13);
+        if (round == ORBT_ROUND) ORBT_MARK(13);
         int pend = 0;
         // two queries per thread and trip (independent of each other: nothing written here is read here), their reads -- state
-        // and bests, list offset, the entries, the posts on them -- issued side by side
-        for (int q0 = tid; q0 < nq; q0 += 2 * kThreads) {
-            int qq[2]; bool und[2], go[2], has2[2]; uint8_t st[2]; int k1[2], k2[2], b1[2]; uint32_t e1[2], e2[2]; int m1[2], m2[2];
+        // and bests, list offset, the entries, the posts on them -- issued side by side.  From the second round on the
+        // trips run over the list of queries the round before left undecided (L), not over all of them.
+        const bool fromList = L && round > 0;
+        const int nIter = fromList ? nPendList : nq;
+        const uint16_t* pl = pend0 + (round & 1) * c.qCap;
+        uint16_t* pn = pend0 + ((round + 1) & 1) * c.qCap;
+        if (L && tid == 0) sPending[round & 1] = 0;   // (read at the head of the round, filled again by the next one)
+        for (int i0 = 0; i0 < nIter; i0 += 2 * G) {
+            int qq[2]; bool und[2], go[2], has2[2], wait[2]; uint8_t st[2]; int k1[2], k2[2], b1[2]; uint32_t e1[2], e2[2]; int m1[2], m2[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int q = q0 + u * kThreads;
-                const bool in = q < nq;
-                qq[u] = in ? q : q0;
+                const int i = i0 + u * G + tid;
+                const bool in = i < nIter;
+                if constexpr (L) qq[u] = fromList ? pl[in ? i : 0] : (in ? i : 0);
+                else qq[u] = in ? i : 0;
                 st[u] = qst[qq[u]]; k1[u] = best1[qq[u]]; k2[u] = best2[qq[u]];
                 und[u] = in && !(st[u] & kQDecided);
+                wait[u] = false;
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -617,8 +650,8 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                m1[u] = go[u] ? minUnd[e1[u] & 0xFFFF] : 0;
-                m2[u] = has2[u] ? minUnd[e2[u] & 0xFFFF] : 0;
+                m1[u] = go[u] ? posted(e1[u] & 0xFFFF) : 0;
+                m2[u] = has2[u] ? posted(e2[u] & 0xFFFF) : 0;
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -628,7 +661,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
                 if (!go[u]) { qst[q] = st[u] | kQDecided; continue; }  // can only get worse: no match
                 const int t1 = (int)(e1[u] & 0xFFFF);
                 const bool stable = m1[u] >= q && (!has2[u] || m2[u] >= q);
-                if (!stable) { pend++; continue; }
+                if (!stable) { pend++; wait[u] = true; continue; }
                 qst[q] = st[u] | kQDecided;
                 if (has2[u] && ((e1[u] >> 16) & 15) == ((e2[u] >> 16) & 15) &&
                     (float)b1[u] > __fmul_rn(c.nnratio, (float)(k2[u] >> 22))) continue;  // ORBmatcher.cc:120-121
@@ -637,15 +670,40 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
                 if (st[u] & kQBlocking) occBy[t1] = q;
                 qres[q] = t1;
             }
+            if constexpr (L) {
+                const uint64_t bala = __builtin_amdgcn_ballot_w64(wait[0]), balb = __builtin_amdgcn_ballot_w64(wait[1]);
+                if (bala | balb) {
+                    const int na = __popcll(bala);
+                    int base = 0;
+                    if ((tid & 63) == 0) base = atomicAdd(&sPending[(round + 1) & 1], na + __popcll(balb));
+                    base = __shfl(base, 0);
+                    if (wait[0]) pn[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bala >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bala, 0))] = (uint16_t)qq[0];
+                    if (wait[1]) pn[base + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(balb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)balb, 0))] = (uint16_t)qq[1];
+                }
+            }
         }
-        if (round == 1) ORBT_MARK(14);
-        for (int t = tid; t < nt; t += kThreads) idle[t] = kFree;
+        if (round == ORBT_ROUND) ORBT_MARK(14);
         if (L && tid == 0) sLive[round & 1] = 0;   // read in this round's first pass, filled again by the next round's
         // "anybody still undecided?" rides on the round's last barrier (every thread with pending queries used to add to ONE
         // LDS word: up to a thousand serialised atomics, 2 us of an early round)
-        const int anyPend = __syncthreads_or(pend);
-        if (round == 1) ORBT_MARK(15);
-        if (!anyPend) break;
+        int anyPend;
+        if constexpr (G == kThreads) anyPend = __syncthreads_or(pend);
+        else { bar(); anyPend = __builtin_amdgcn_ballot_w64(pend != 0) != 0; }
+        if (round == ORBT_ROUND) ORBT_MARK(15);
+        return anyPend;
+    };
+    int round = 0;
+    bool tail = false;   // the first wave finishes alone
+    for (;; round++) {
+        if (!one_round(std::integral_constant<int, kThreads>{}, round)) break;
+        if constexpr (L) {
+            // (both counts are final behind the round's closing barrier, and the same for every thread)
+            if (c.waveTail && sLive[(round + 1) & 1] <= kTailLive && sPending[(round + 1) & 1] <= kTailQueries) { tail = true; break; }
+        }
+    }
+    if (tail) {
+        if (tid < 64) for (round++;; round++) if (!one_round(std::integral_constant<int, 64>{}, round)) break;
+        __syncthreads();
     }
     ORBT_MARK(2);
 
@@ -727,7 +785,7 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
     ORBT_MARK(0);
     for (int t = tid; t < nt; t += kThreads) {
         occBy[t] = (P.toccIn && P.toccIn[t]) ? -1 : kFree;
-        minUnd0[t] = kFree; minUnd0[c.tCap + t] = kFree;
+        minUnd0[t] = 0;   // (no round has posted yet; the table's second tCap dwords are not used any more)
         winner[t] = -1;
     }
     if (tid < 32) hist[tid] = 0;

@@ -20,3 +20,9 @@ for th in (15.0, 30.0):
         if rep >= 5: acc += np.array(list(us))
     acc /= 15
     print("th=%g round 1: post loop %.2f, barrier(+runner-up) %.2f, decide loop %.2f, clear+barrier %.2f us; init %.1f rounds %.1f writeback %.1f" % (th, acc[11], acc[12], acc[13], acc[14], acc[0], acc[1], acc[2]))
+    cen = (C.c_int32 * 128)(); L.orbm_debug_round_census(cen, 64)
+    rows = []
+    for i in range(64):
+        if cen[2 * i] < 0: break
+        rows.append("%d/%d" % (cen[2 * i], cen[2 * i + 1]))
+    print("   live entries / undecided queries per round:", " ".join(rows))
