@@ -233,13 +233,16 @@ struct ProjCommon {
     int32_t qCap;      // resolve: queries whose tables fit in LDS   } more of either: the rounds work in memory
     int32_t ldsCand;   // resolve: candidate entries that fit in LDS }
     int32_t waveTail;    // resolve: the last rounds by the first wave alone (0: the whole workgroup to the end)
+    int32_t lanes;       // candidates: lanes per query, kCandLanes or kCandLanesWide (the host sizes the grid of slices by it)
     int32_t interleave;  // candidates: deal the queries to the slices wave by wave instead of in consecutive runs (few pairs)
 };
 
 constexpr int kCandThreads = 512;
-constexpr int kCandLanes = 4;                            // lanes per query: the grid columns of its window are dealt round-robin
-constexpr int kCandQueries = kCandThreads / kCandLanes;  // queries per workgroup (a "slice")
-constexpr int kCandPasses = 4;                           // columns per lane; a wider window is walked by lane 0 alone
+constexpr int kCandCols = 4;                             // column slots per query: the grid columns of its window are dealt round-robin
+constexpr int kCandLanes = 4;                            // lanes per query, throughput form: one per column slot
+constexpr int kCandLanesWide = 16;                       // latency form (few pairs): four lanes per column slot, each a quarter of the column's run
+constexpr int kCandQueries = kCandThreads / kCandLanes;  // queries per workgroup (a "slice") in the throughput form
+constexpr int kCandPasses = 4;                           // columns per slot; a wider window is walked by lane 0 alone
 
 // The train frame's grid in LDS: its features in GRID order as {x, y, index | octave << 24, 0} (one 16-byte read per
 // visit) and the cell starts (uint16).  GetFeaturesInArea becomes a walk at LDS latency, and since cells are stored
@@ -268,10 +271,15 @@ __device__ __forceinline__ bool area_window(const GridDev& g, float x, float y, 
 
 template <class F>
 __device__ __forceinline__ void area_column(const GridDev& g, const uint4* rec, const uint16_t* cst, const AreaWin& w, int ix,
-                                            float x, float y, float r, int minLevel, int maxLevel, F f)
+                                            float x, float y, float r, int minLevel, int maxLevel, int seg, int nseg, F f)
 {
-    const int j1 = cst[ix * g.rows + w.y1 + 1];
-    for (int j = cst[ix * g.rows + w.y0]; j < j1; j++) {
+    int j0 = cst[ix * g.rows + w.y0], j1 = cst[ix * g.rows + w.y1 + 1];
+    if (nseg > 1) {   // this lane's part of the column's run (parts in lane order = the run's order)
+        const int len = j1 - j0, per = (len + nseg - 1) / nseg;
+        j1 = j0 + min((seg + 1) * per, len);
+        j0 = j0 + min(seg * per, len);
+    }
+    for (int j = j0; j < j1; j++) {
         const uint4 e = rec[j];
         const int oct = (int)(e.z >> 24);
         if (w.check) {
@@ -309,13 +317,14 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* wsum, int* total)
     return woff + incl - v;
 }
 
-// exclusive prefix over the kCandLanes lanes of a query, *tot = their sum
+// exclusive prefix over the LANES lanes of a query, *tot = their sum
+template <int LANES>
 __device__ __forceinline__ int quad_scan_excl(int v, int c, int* tot)
 {
     int incl = v;
-    int t = __shfl_up(incl, 1, kCandLanes); if (c >= 1) incl += t;
-    t = __shfl_up(incl, 2, kCandLanes); if (c >= 2) incl += t;
-    *tot = __shfl(incl, kCandLanes - 1, kCandLanes);
+#pragma unroll
+    for (int d = 1; d < LANES; d <<= 1) { const int t = __shfl_up(incl, d, LANES); if (c >= d) incl += t; }
+    *tot = __shfl(incl, LANES - 1, LANES);
     return incl - v;
 }
 
@@ -325,18 +334,22 @@ __device__ __forceinline__ int quad_scan_excl(int v, int c, int* tot)
 // -- one entry per thread and step, all loads independent (inside the divergent window walk every gather would cost the
 // whole wave a memory round trip) -- and what lies within the threshold goes to a chunk of the pair's arena allocated
 // with one atomicAdd.  Lists keep the reference's scan order (GetFeaturesInArea, Frame.cc:327-380): column by column.
+template <int LANES>
 __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const ProjCommon& c, int slice)
 {
+    constexpr int kSeg = LANES / kCandCols;     // lanes per column slot
+    constexpr int kWaveQ = 64 / LANES;          // queries per wave
+    constexpr int kSliceQ = kCandThreads / LANES;
     extern __shared__ int32_t tl[];
     __shared__ int wsum[kCandThreads / 64];
     __shared__ int sBase;
     uint4* rec = (uint4*)tl;
     uint2* stage = (uint2*)(rec + c.tCap);
     uint16_t* cst = (uint16_t*)(stage + c.stageCap);
-    const int tid = threadIdx.x, lc = tid & (kCandLanes - 1);
+    const int tid = threadIdx.x, lc = tid & (LANES - 1), lcol = lc / kSeg, lseg = lc % kSeg;
     const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
     const int nq = min(P.nqPtr ? (P.nq > 0 ? min(*P.nqPtr, P.nq) : *P.nqPtr) : P.nq, kMaxQueryIters * kThreads);
-    if (nt <= 0 || (c.interleave ? slice * 16 : slice * kCandQueries) >= nq) return;
+    if (nt <= 0 || (c.interleave ? slice * kWaveQ : slice * kSliceQ) >= nq) return;
     ORBT_MARK(4);
     const int ncell = min(P.grid.cols * P.grid.rows, c.cellCap - 1);
     for (int ci = tid; ci <= ncell; ci += kCandThreads) cst[ci] = (uint16_t)P.cellStart[ci];
@@ -347,7 +360,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     // level and a coarse-level window holds many times the features of a fine one: with consecutive runs the last
     // workgroups of a frame pair walked for 26 us while the first were done after 11 (tools/proj_phases.sh).  A wave's lanes
     // still walk windows of one size.  Many pairs keep the consecutive runs (workgroups abound; 7 % faster there).
-    const int q = c.interleave ? (((tid >> 6) * (int)gridDim.x + slice) << 4) + ((tid >> 2) & 15) : slice * kCandQueries + (tid >> 2);
+    const int q = c.interleave ? ((tid >> 6) * (int)gridDim.x + slice) * kWaveQ + (tid & 63) / LANES : slice * kSliceQ + tid / LANES;
     float u = 0.f, v = 0.f, r = 0.f; int minL = 0, maxL = 0;
     bool ok = q < nq && !(P.qvalid && !P.qvalid[q]);
     if (ok) {
@@ -365,7 +378,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     }
     AreaWin w{};
     if (ok) ok = area_window(P.grid, u, v, r, minL, maxL, w);
-    const bool wide = ok && (w.x1 - w.x0 + 1 > kCandLanes * kCandPasses);
+    const bool wide = ok && (w.x1 - w.x0 + 1 > kCandCols * kCandPasses);
     const float qur = (ok && P.turight) ? P.qur[q] : 0.f;
     auto stereo_ok = [&](int t) {
         if (!P.turight) return true;
@@ -377,14 +390,14 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
         if (!ok) return;
         if (wide) { if (lc == 0) for (int ix = w.x0; ix <= w.x1; ix++) f(0, ix); return; }
 #pragma unroll
-        for (int pi = 0; pi < kCandPasses; pi++) { const int ix = w.x0 + pi * kCandLanes + lc; if (ix <= w.x1) f(pi, ix); }
+        for (int pi = 0; pi < kCandPasses; pi++) { const int ix = w.x0 + pi * kCandCols + lcol; if (ix <= w.x1) f(pi, ix); }
     };
     __syncthreads();
     ORBT_MARK(5);
     int cnt[kCandPasses] = {0, 0, 0, 0};
     my_columns([&](int pi, int ix) {
         int n = 0;
-        area_column(P.grid, rec, cst, w, ix, u, v, r, minL, maxL, [&](int t, int) { if (stereo_ok(t)) n++; });
+        area_column(P.grid, rec, cst, w, ix, u, v, r, minL, maxL, lseg, wide ? 1 : kSeg, [&](int t, int) { if (stereo_ok(t)) n++; });
 #pragma unroll
         for (int k = 0; k < kCandPasses; k++) if (k == pi) cnt[k] += n;
     });
@@ -394,11 +407,11 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
 #pragma unroll
     for (int pi = 0; pi < kCandPasses; pi++) {
         int ptot;
-        off[pi] = qtot + quad_scan_excl(cnt[pi], lc, &ptot);
+        off[pi] = qtot + quad_scan_excl<LANES>(cnt[pi], lc, &ptot);
         qtot += ptot;
     }
     int tot;
-    const int qoff = __shfl(wg_scan_excl(lc == 0 ? qtot : 0, wsum, &tot), 0, kCandLanes);
+    const int qoff = __shfl(wg_scan_excl(lc == 0 ? qtot : 0, wsum, &tot), 0, LANES);
     if (tot == 0) {  // uniform
         if (q < nq && lc == 0) { P.candOff[q] = 0; P.candCnt[q] = 0; }
         return;
@@ -426,7 +439,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
 #pragma unroll
             for (int k = 0; k < kCandPasses; k++) if (k == pi) pos = qoff + off[k];
         }
-        area_column(P.grid, rec, cst, w, ix, u, v, r, minL, maxL, [&](int t, int oct) {
+        area_column(P.grid, rec, cst, w, ix, u, v, r, minL, maxL, lseg, wide ? 1 : kSeg, [&](int t, int oct) {
             if (!stereo_ok(t)) return;
             list[pos++] = make_uint2(((uint32_t)(oct & 15) << 16) | (uint32_t)t, (uint32_t)q);
         });
@@ -455,14 +468,14 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     }
     ORBT_MARK(9);
     // compaction: each lane takes a quarter of its query's list
-    const int seg = (qtot + kCandLanes - 1) / kCandLanes;
+    const int seg = (qtot + LANES - 1) / LANES;
     const int k0 = qoff + min(lc * seg, qtot), k1 = qoff + min((lc + 1) * seg, qtot);
     int keep = 0;
     for (int k = k0; k < k1; k++) keep += (int)(stage[k].x >> 20) <= dMax;
     int qkeep;
-    const int kofs = quad_scan_excl(keep, lc, &qkeep);
+    const int kofs = quad_scan_excl<LANES>(keep, lc, &qkeep);
     int ktot;
-    const int kex = __shfl(wg_scan_excl(lc == 0 ? qkeep : 0, wsum, &ktot), 0, kCandLanes);
+    const int kex = __shfl(wg_scan_excl(lc == 0 ? qkeep : 0, wsum, &ktot), 0, LANES);
     if (tid == 0) sBase = ktot ? atomicAdd(P.total, ktot) : 0;
     __syncthreads();
     base = sBase;
@@ -485,8 +498,8 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
 // reads its best (mode 3: a second flat pass finds the runner-up), checks that nobody lower has posted on it and
 // commits.  A thread-per-query walk of the lists costs every wave its longest list, a chain of dependent LDS reads per
 // entry, in every round; the flat loop keeps all lanes busy and its reads independent.
-// LDS (dynamic): occBy, minUnd (+ tCap dwords unused since the table is keyed by round), winner (4 * tCap dwords) | per
-// query: offset, best, second, result (4 * qCap dwords) | candidates (ldsCand dwords) | their queries (ldsCand halves) |
+// LDS (dynamic): occBy, minUnd, winner (3 * tCap dwords) | per
+// query: offset, best, second = result (3 * qCap dwords) | candidates (ldsCand dwords) | their queries (ldsCand halves) |
 // two live lists (2 * ldsCand halves) | per query: state byte (qCap bytes) | two lists of undecided queries (2 * qCap halves).
 // L = false: the per-query tables and the lists stay in memory (more queries or candidates than the LDS plan holds).
 constexpr uint8_t kQDecided = 1, kQBlocking = 2;
@@ -507,8 +520,9 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     uint32_t* candL = nullptr; uint16_t* ownL = nullptr; uint16_t* live0 = nullptr; uint8_t* qst;
     uint16_t* pend0 = nullptr;   // L: the undecided queries, two lists used by alternate rounds (a round costs what is still open)
     if constexpr (L) {
-        qoff = qtab; best1 = qtab + c.qCap; best2 = qtab + 2 * c.qCap; qres = qtab + 3 * c.qCap;
-        candL = (uint32_t*)(qtab + 4 * c.qCap);
+        // (the result shares the runner-up's word: a decided query's bests are never touched again, and kFree there reads "none")
+        qoff = qtab; best1 = qtab + c.qCap; best2 = qtab + 2 * c.qCap; qres = best2;
+        candL = (uint32_t*)(qtab + 3 * c.qCap);
         ownL = (uint16_t*)(candL + c.ldsCand);
         live0 = ownL + c.ldsCand;
         qst = (uint8_t*)(live0 + 2 * c.ldsCand);
@@ -522,7 +536,8 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     for (int q = tid; q < nq; q += kThreads) {
         const int cnt = nt > 0 ? P.candCnt[q] : 0;
         if constexpr (L) qoff[q] = P.candOff[q];
-        best1[q] = kFree; best2[q] = kFree; qres[q] = -1;
+        best1[q] = kFree; best2[q] = kFree;
+        if constexpr (!L) qres[q] = -1;
         qst[q] = (cnt == 0 ? kQDecided : 0) | ((!obsRule || !P.qobs || P.qobs[q]) ? kQBlocking : 0);
     }
     __syncthreads();
@@ -712,7 +727,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     if (useRot) {
         for (int q = tid; q < nq; q += kThreads) {
             const int t1 = qres[q];
-            if (t1 < 0) continue;
+            if (t1 < 0 || t1 == kFree) continue;
             const int bin = orbm::rot_bin(P.qang ? P.qang[q] : P.qkeys[q].angle, P.tkeys[t1].angle);
             atomicAdd(&hist[bin], 1);
             best1[q] = bin;  // (the table is free now)
@@ -740,7 +755,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     if (useRot) {
         for (int q = tid; q < nq; q += kThreads) {
             const int t1 = qres[q];
-            if (t1 < 0) continue;
+            if (t1 < 0 || t1 == kFree) continue;
             const int bin = best1[q];
             if (bin != sInd[0] && bin != sInd[1] && bin != sInd[2]) { winner[t1] = -2; nPruned++; }
         }
@@ -775,9 +790,9 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
     __shared__ int sCount;
     __shared__ int sLive[2];
     int32_t* occBy = tl;                   // kFree, -1 (occupied on entry) or the blocking query that took the feature
-    int32_t* minUnd0 = occBy + c.tCap;     // two copies, used by alternate rounds (the idle one is cleared meanwhile)
-    int32_t* winner = occBy + 3 * c.tCap;  // last query (in query order) that took the feature in this call
-    int32_t* qtab = occBy + 4 * c.tCap;
+    int32_t* minUnd0 = occBy + c.tCap;     // keyed by round (proj_resolve_rounds)
+    int32_t* winner = occBy + 2 * c.tCap;  // last query (in query order) that took the feature in this call
+    int32_t* qtab = occBy + 3 * c.tCap;
     const int tid = threadIdx.x;
     const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
     const int nq = min(P.nqPtr ? (P.nq > 0 ? min(*P.nqPtr, P.nq) : *P.nqPtr) : P.nq, kMaxQueryIters * kThreads);
@@ -785,7 +800,7 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
     ORBT_MARK(0);
     for (int t = tid; t < nt; t += kThreads) {
         occBy[t] = (P.toccIn && P.toccIn[t]) ? -1 : kFree;
-        minUnd0[t] = 0;   // (no round has posted yet; the table's second tCap dwords are not used any more)
+        minUnd0[t] = 0;   // (no round has posted yet)
         winner[t] = -1;
     }
     if (tid < 32) hist[tid] = 0;
@@ -804,7 +819,8 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
 __global__ __launch_bounds__(kCandThreads) void k_proj_candidates(const ProjPair* __restrict__ pairs, ProjCommon c)
 {
     const ProjPair P = pairs[blockIdx.y];
-    proj_candidates_body(P, c, blockIdx.x);
+    if (c.lanes == kCandLanesWide) proj_candidates_body<kCandLanesWide>(P, c, blockIdx.x);
+    else proj_candidates_body<kCandLanes>(P, c, blockIdx.x);
 }
 
 __global__ __launch_bounds__(kThreads) void k_proj_resolve(const ProjPair* __restrict__ pairs, ProjCommon c)
@@ -853,7 +869,8 @@ __device__ __forceinline__ ProjPair track_pair(const TrackArgs& a, int b)
 __global__ __launch_bounds__(kCandThreads) void k_track_candidates(TrackArgs a, ProjCommon c)
 {
     const ProjPair P = track_pair(a, blockIdx.y);
-    proj_candidates_body(P, c, blockIdx.x);
+    if (c.lanes == kCandLanesWide) proj_candidates_body<kCandLanesWide>(P, c, blockIdx.x);
+    else proj_candidates_body<kCandLanes>(P, c, blockIdx.x);
 }
 
 __global__ __launch_bounds__(kThreads) void k_track_resolve(TrackArgs a, ProjCommon c)
