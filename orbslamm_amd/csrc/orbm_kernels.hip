@@ -1072,7 +1072,7 @@ __global__ void k_window_best(WinArgs a)
 // far lives in LDS.  Candidates/distances come from k_proj_candidates (window, octave 0).
 __global__ __launch_bounds__(64) void k_init_resolve(ProjArgs a, int32_t* __restrict__ m12, int32_t* __restrict__ m21)
 {
-    extern __shared__ uint32_t ilds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t ilds[];
     uint16_t* matchedDist = (uint16_t*)ilds;  // [nt], 0xFFFF = INT_MAX
     __shared__ int hist[32];
     const int lane = threadIdx.x;
@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(64) void k_triangulation_pairs(TriArgs a)
 __global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ start,
                                                    int32_t* __restrict__ bestIdx)
 {
-    extern __shared__ int32_t rowd[];  // N distances of the current row
+    extern __shared__ __attribute__((aligned(16))) int32_t rowd[];  // N distances of the current row
     const int p = blockIdx.x, lane = threadIdx.x;
     const int s0 = start[p], N = start[p + 1] - s0;
     if (N <= 0) { if (lane == 0) bestIdx[p] = -1; return; }

@@ -113,7 +113,7 @@ __device__ __forceinline__ void undistort_point(const UndistArgs& a, float& px, 
 // chain of short phases and a memory round trip per phase was most of its 31 us.
 __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
 {
-    extern __shared__ int32_t gl[];
+    extern __shared__ __attribute__((aligned(16))) int32_t gl[];
     __shared__ int wsum[kWaves];
     const int capE = (a.fs.cap + 1) & ~1;
     int32_t* cnt = gl;
@@ -340,7 +340,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     constexpr int kSeg = LANES / kCandCols;     // lanes per column slot
     constexpr int kWaveQ = 64 / LANES;          // queries per wave
     constexpr int kSliceQ = kCandThreads / LANES;
-    extern __shared__ int32_t tl[];
+    extern __shared__ __attribute__((aligned(16))) int32_t tl[];
     __shared__ int wsum[kCandThreads / 64];
     __shared__ int sBase;
     uint4* rec = (uint4*)tl;
@@ -783,7 +783,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
 
 __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjCommon& c)
 {
-    extern __shared__ int32_t tl[];
+    extern __shared__ __attribute__((aligned(16))) int32_t tl[];
     __shared__ int hist[32];
     __shared__ int sPending[3];
     __shared__ int sInd[3];

@@ -201,7 +201,7 @@ __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P
                                                    uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
                                                    int32_t* __restrict__ fvIdx, int32_t* __restrict__ counts)
 {
-    extern __shared__ uint64_t alds[];
+    extern __shared__ __attribute__((aligned(16))) uint64_t alds[];
     uint64_t* keys = alds;
     uint32_t* pos = (uint32_t*)(alds + P);
     double* accL = ACC_LDS ? (double*)(alds + P + P / 2) : outW;   // P >= 2

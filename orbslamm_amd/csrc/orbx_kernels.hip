@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
                                                 int tabCap)
 {
     // one LDS array addressed with integer offsets (keeps every access in the LDS address space)
-    extern __shared__ uint32_t plds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t plds[];
     uint8_t* const ldsb = (uint8_t*)plds;
     const int offBuf[2] = {0, bufAWords * 4};            // even / odd levels (bytes)
     uint2* const sxt = (uint2*)(plds + bufAWords + bufBWords);  // staged {sx,a0 | a1,interp}
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                                             int32_t* __restrict__ cellCount, int32_t* __restrict__ errFlag,
                                             int tileRows, int listCap, int smapPitch, int nframes, int cell0)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int TSD = TSB / 4;
     int bx, fr;
     if (!xcd_block_frame(nframes, bx, fr)) return;
@@ -706,13 +706,13 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                                                             uint32_t* __restrict__ gscratch, int scratchWords, int l0)
 {
 #ifdef ORBX_DIST_TIMING  // phase timestamps of the level-0 block of frame 0, printed at the end (tools/dist_timing.py)
-    __shared__ uint64_t sStamp[96]; __shared__ int sStampId[96]; __shared__ int sNStamp;
+    __shared__ uint64_t sStamp[96]; __shared__ uint64_t sCyc[96]; __shared__ int sStampId[96]; __shared__ int sNStamp;
     if (threadIdx.x == 0) sNStamp = 0;
-#define STAMP(id) do { if (threadIdx.x == 0 && sNStamp < 96) { sStampId[sNStamp] = (id); sStamp[sNStamp++] = wall_clock64(); } } while (0)
+#define STAMP(id) do { if (threadIdx.x == 0 && sNStamp < 96) { sStampId[sNStamp] = (id); sCyc[sNStamp] = clock64(); sStamp[sNStamp++] = wall_clock64(); } } while (0)
 #else
 #define STAMP(id) do {} while (0)
 #endif
-    extern __shared__ uint32_t smem_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_lds[];
     // the launch covers levels [l0, l0 + gridDim.x): level 0 may go ahead of the others (it needs no pyramid)
     const int l = blockIdx.x + l0, f = blockIdx.y + f0;
     uint32_t* const smem = LDS ? smem_lds : gscratch + (int64_t)(blockIdx.y * g->nlevels + l) * scratchWords;
@@ -815,6 +815,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         }
         return code;
     };
+    STAMP(30);
     if (useLut) {
         for (int i = tid; i < L.winW; i += kDistThreads) lutx[i] = (uint16_t)code_x(i);
         for (int i = tid; i < L.winH; i += kDistThreads) luty[i] = (uint16_t)code_y(i);
@@ -827,6 +828,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // flat index -> (cell, slot) by binary search in the cell prefix.  A chunk is 16 keys per thread, all loads
     // in flight together; a level that fits one chunk (<= 8192 candidates, every shipped shape) keeps its keys
     // in registers between the count and the scatter, larger ones read them twice.
+    STAMP(31);
     constexpr int KPT = 16;
     // two-level search: firstCell[k] = cell of flat position 64k (one full search per 64 positions), then a key only
     // searches the few cells its 64-block spans -- the search is LDS-issue bound (8 of the block's 70 us went here)
@@ -853,6 +855,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         topStep = 1;
         while (topStep * 2 <= sSpan) topStep *= 2;
     }
+    STAMP(32);
     auto load_chunk = [&](int base, uint64_t (&key)[KPT], uint32_t (&code)[KPT]) {
         int lo[KPT], pp[KPT];
 #pragma unroll
@@ -900,9 +903,10 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     if (n <= kChunk) {
         uint64_t key[KPT];
         uint32_t code[KPT];
-        if (n > 0) { load_chunk(0, key, code); count_chunk(0, code); }
+        if (n > 0) { load_chunk(0, key, code); STAMP(33); count_chunk(0, code); }
         tree_sums_and_starts();
         if (n > 0) scatter_chunk(0, key, code);
+        STAMP(34);
     } else {
         for (int base = 0; base < n; base += kChunk) { uint64_t key[KPT]; uint32_t code[KPT]; load_chunk(base, key, code); count_chunk(base, code); }
         tree_sums_and_starts();
@@ -918,6 +922,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // So: tally, find the first round r* after which the reference stops or turns careful (or the histogram ends),
     // one scan over the concatenated (depth, complemented code) sequence = every node's list position.  Replaces r*
     // rounds of ~5 us (a dozen barriers each) by one of ~3.
+    STAMP(35);
     __shared__ int sTal[6][3];         // per depth: nodes, nodes with one key, nodes with more
     uint32_t* const sq = sortScratch;
     if (tid < 18) (&sTal[0][0])[tid] = 0;
@@ -1002,6 +1007,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         if (E == 0) break;  // size unchanged -> finish (:669 / :733)
         for (int i = tid; i < m; i += kDistThreads) if (tA[i]) ord[tB[i]] = i;
         __syncthreads();
+        STAMP(20);
         if (careful) {
             // sort by (count desc, list position asc) == reference's (size, creation) ascending
             // sort walked from the back (:684-685, tie-break see DESIGN.md)
@@ -1030,25 +1036,37 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                 tA[e] = e < E ? ((ncB[cur * cap + i] & 0x7FFFFFFFu) << 13) | (8191u - i) : 0u;
             }
             __syncthreads();
+            STAMP(21);
             int parts = 1;
             while (parts < 8 && E * parts * 2 <= kDistThreads) parts *= 2;
             const int per = ((E + parts - 1) / parts + 3) & ~3;
+            STAMP(23);
             for (int e0 = 0; e0 < E; e0 += kDistThreads / parts) {
                 const int e = e0 + tid / parts, sub = tid % parts;
                 uint32_t rank = 0;
                 if (e < E) {
                     const uint32_t ke = tA[e];
-                    const int lim = min(E4, (sub + 1) * per);
+                    // The lanes walk their part of the table ROTATED by their lane number: at any moment a wave reads 64 different
+                    // uint4s.  All lanes on the same uint4 is not a broadcast for a 128-bit read -- the wave's 32 reads took 5.5 us
+                    // (tools/dist_timing.py), a sixth of this block's life.  Keys are below 2^31 (count < 2^18, << 13): "ke < k" is
+                    // the sign of the difference.
+                    const int base4 = sub * per / 4, n4 = (min(E4, (sub + 1) * per) - sub * per) / 4;
+                    int idx = n4 > 0 ? (lane / parts) % n4 : 0;
 #pragma unroll 4
-                    for (int e2 = sub * per; e2 < lim; e2 += 4) {
-                        const uint4 k4 = *(const uint4*)&tA[e2];
-                        rank += (ke < k4.x) + (ke < k4.y) + (ke < k4.z) + (ke < k4.w);
+                    for (int j = 0; j < n4; j++) {
+                        const uint4 k4 = ((const uint4*)tA)[base4 + idx];
+                        rank += ((ke - k4.x) >> 31) + ((ke - k4.y) >> 31) + ((ke - k4.z) >> 31) + ((ke - k4.w) >> 31);
+                        if (++idx == n4) idx = 0;
                     }
                 }
+                STAMP(24);
                 for (int d = 1; d < parts; d <<= 1) rank += __shfl_xor(rank, d);
+                STAMP(25);
                 if (e < E && sub == 0) ord2[rank] = ord[e];
             }
+            STAMP(26);
             __syncthreads();
+            STAMP(22);
             }
             for (int e = tid; e < E; e += kDistThreads) ord[e] = ord2[e];
             __syncthreads();
@@ -1209,7 +1227,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         uint64_t prev = sStamp[0];
         for (int i = 0; i < sNStamp; i++) {
             if (sStampId[i] >= 1000) printf("   -> m=%d E=%d\n", sStampId[i] - 1000, (int)sStamp[i]);
-            else { printf(" id %3d  +%6.2f us\n", sStampId[i], (double)(sStamp[i] - prev) / 100.0); prev = sStamp[i]; }
+            else { printf(" id %3d  +%6.2f us  %6lld cycles\n", sStampId[i], (double)(sStamp[i] - prev) / 100.0, i ? (long long)(sCyc[i] - sCyc[i - 1]) : 0ll); prev = sStamp[i]; }
         }
     }
 #endif
@@ -2059,7 +2077,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
 __global__ __launch_bounds__(1024) void k_stereo_median(const int32_t* __restrict__ nL, const int32_t* __restrict__ sad,
                                                        float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ nAccepted)
 {
-    extern __shared__ uint32_t keys[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t keys[];
     __shared__ int sN;
     __shared__ uint32_t sMedian;
     const int N = *nL, tid = threadIdx.x;
