@@ -51,9 +51,7 @@ __device__ int g_orbtCensus[64][2];   // per round of the resolve: live entries,
 __device__ __forceinline__ int block_scan_excl(int v, int* wsum, int* total)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    const int incl = orbx::wave_incl_scan(v);
     __syncthreads();  // wsum may still be read from the previous use
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -304,9 +302,7 @@ __device__ __forceinline__ int hamming_rows(const uint8_t* __restrict__ qd, uint
 __device__ __forceinline__ int wg_scan_excl(int v, int* wsum, int* total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    const int incl = orbx::wave_incl_scan(v);
     __syncthreads();  // wsum may still be read from the previous use
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -321,9 +317,16 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* wsum, int* total)
 template <int LANES>
 __device__ __forceinline__ int quad_scan_excl(int v, int c, int* tot)
 {
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < LANES; d <<= 1) { const int t = __shfl_up(incl, d, LANES); if (c >= d) incl += t; }
+    // (row_shr on the DPP path instead of __shfl_up through the LDS unit; a group never straddles a row of 16 lanes, and the
+    // lanes that would read a neighbouring group's value do not add it)
+    static_assert(LANES == 4 || LANES == 16, "groups of 4 or 16 lanes");
+    int incl = v, t;
+    t = __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false); if (c >= 1) incl += t;
+    t = __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false); if (c >= 2) incl += t;
+    if constexpr (LANES == 16) {
+        t = __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false); if (c >= 4) incl += t;
+        t = __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false); if (c >= 8) incl += t;
+    }
     *tot = __shfl(incl, LANES - 1, LANES);
     return incl - v;
 }

@@ -90,4 +90,20 @@ struct OrbxKeyPointDev {
     int32_t octave, class_id;
 };
 
+
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP path (row_shr 1/2/4/8 inside a row of 16, then row_bcast:15
+// and row_bcast:31 across the rows): six VALU adds.  The same with __shfl_up is six ds_bpermute round trips through the
+// LDS unit (~100 cycles each), and the single-workgroup kernels of a live stream's chain (quadtree, frame build,
+// candidates) are strings of such scans.  All 64 lanes must be active.
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 }  // namespace orbx

@@ -620,12 +620,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t* a, int m, uint32_t
     const int b = min(tid * per, m), e = min(b + per, m);
     uint32_t s = 0;
     for (int i = b; i < e; i++) s += a[i];
-    uint32_t incl = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
+    const uint32_t incl = (uint32_t)wave_incl_scan((int)s);
     __syncthreads();
     if (lane == 63) wtmp[wave] = incl;
     __syncthreads();
@@ -830,58 +825,65 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     // in registers between the count and the scatter, larger ones read them twice.
     STAMP(31);
     constexpr int KPT = 16;
-    // two-level search: firstCell[k] = cell of flat position 64k (one full search per 64 positions), then a key only
-    // searches the few cells its 64-block spans -- the search is LDS-issue bound (8 of the block's 70 us went here)
-    __shared__ int sSpan;
-    const int nblk = (n + 63) >> 6;
+    // flat index -> (cell, slot).  A thread takes its KPT positions as four runs of four CONSECUTIVE ones (run r of thread t:
+    // base + r * 4 T + 4 t ..): one table lookup and a short walk over the cell boundaries per run -- it used to be a
+    // binary search for each of 16 strided positions, and the chunk load was instruction bound (5.5 of this block's 35 us) --
+    // while a wave's lanes still read 2 KB in one piece (16 consecutive positions per thread: every lane on a cache line of
+    // its own, the loads then wait for the texture unit's line rate).  firstCell[k] = cell of flat position k << fshift,
+    // written by the cells themselves (a cell marks the blocks that start inside it: no search, no dependent chain).
+    int fshift = 4;
+    while (fshift < 6 && ((n + (1 << fshift) - 1) >> fshift) > kFirstCap) fshift++;
+    const int nblk = (n + (1 << fshift) - 1) >> fshift;
     const bool twoLevel = nblk <= kFirstCap && nCells <= 65535;
     int topStep = 1;
     while (topStep * 2 < nCells) topStep *= 2;
     if (twoLevel) {
-        if (tid == 0) sSpan = 1;
-        __syncthreads();
-        for (int k = tid; k <= nblk; k += kDistThreads) {
-            const uint32_t p = (uint32_t)min(64 * k, max(n - 1, 0));
-            int lo = 0;
-            for (int step = topStep; step > 0; step >>= 1) {
-                const int c = lo + step;
-                if (c < nCells && cellPref[c] <= p) lo = c;
-            }
-            firstCell[k] = (uint16_t)lo;
+        const uint32_t fm = (1u << fshift) - 1;
+        for (int c = tid; c < nCells; c += kDistThreads) {
+            const uint32_t a = cellPref[c], b = cellPref[c + 1];
+            for (uint32_t k = (a + fm) >> fshift; (k << fshift) < b; k++) firstCell[k] = (uint16_t)c;
         }
         __syncthreads();
-        for (int k = tid; k < nblk; k += kDistThreads) atomicMax(&sSpan, (int)firstCell[k + 1] - (int)firstCell[k]);
-        __syncthreads();
-        topStep = 1;
-        while (topStep * 2 <= sSpan) topStep *= 2;
     }
     STAMP(32);
+    constexpr int kRun = 4;
+    auto chunk_pos = [&](int base, int u) { return base + (u / kRun) * (kRun * kDistThreads) + tid * kRun + (u % kRun); };
     auto load_chunk = [&](int base, uint64_t (&key)[KPT], uint32_t (&code)[KPT]) {
-        int lo[KPT], pp[KPT];
 #pragma unroll
-        for (int u = 0; u < KPT; u++) { pp[u] = min(base + tid + u * kDistThreads, n - 1); lo[u] = twoLevel ? (int)firstCell[pp[u] >> 6] : 0; }
-        // largest c with cellPref[c] <= p: fixed-trip search, the 16 chains advance side by side
-        for (int step = topStep; step > 0; step >>= 1) {
+        for (int r = 0; r < KPT / kRun; r++) {
+            const int ps = min(chunk_pos(base, r * kRun), n - 1);
+            int lo;
+            if (twoLevel) {
+                lo = (int)firstCell[ps >> fshift];
+            } else {  // largest c with cellPref[c] <= ps
+                lo = 0;
+                for (int step = topStep; step > 0; step >>= 1) {
+                    const int c = lo + step;
+                    if (c < nCells && cellPref[c] <= (uint32_t)ps) lo = c;
+                }
+            }
+            uint32_t cnext = cellPref[lo + 1];
+            while ((uint32_t)ps >= cnext) { lo++; cnext = cellPref[lo + 1]; }   // (ps < n = cellPref[nCells]: ends inside the table)
+            uint32_t cstart = cellPref[lo], off = cellOffs[lo];
 #pragma unroll
-            for (int u = 0; u < KPT; u++) {
-                const int c = lo[u] + step;
-                if (c < nCells && cellPref[c] <= (uint32_t)pp[u]) lo[u] = c;
+            for (int j = 0; j < kRun; j++) {
+                const uint32_t pp = (uint32_t)min(chunk_pos(base, r * kRun + j), n - 1);
+                while (pp >= cnext) { lo++; cstart = cnext; cnext = cellPref[lo + 1]; off = cellOffs[lo]; }
+                key[r * kRun + j] = srcb[off + (pp - cstart)];
             }
         }
-#pragma unroll
-        for (int u = 0; u < KPT; u++) key[u] = srcb[cellOffs[lo[u]] + (pp[u] - cellPref[lo[u]])];
 #pragma unroll
         for (int u = 0; u < KPT; u++) code[u] = (uint32_t)path_code(key[u]);
     };
     auto count_chunk = [&](int base, const uint32_t (&code)[KPT]) {
 #pragma unroll
         for (int u = 0; u < KPT; u++)
-            if (base + tid + u * kDistThreads < n) atomicAdd(&hst[hoff(D) + code[u]], 1u);
+            if (chunk_pos(base, u) < n) atomicAdd(&hst[hoff(D) + code[u]], 1u);
     };
     auto scatter_chunk = [&](int base, const uint64_t (&key)[KPT], const uint32_t (&code)[KPT]) {
 #pragma unroll
         for (int u = 0; u < KPT; u++)
-            if (base + tid + u * kDistThreads < n) bufs[1][atomicAdd(&hfill[code[u]], 1u)] = key[u];
+            if (chunk_pos(base, u) < n) bufs[1][atomicAdd(&hfill[code[u]], 1u)] = key[u];
     };
     auto tree_sums_and_starts = [&]() {
         __syncthreads();
@@ -929,11 +931,20 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     __syncthreads();
     auto depth_of = [&](int idx, int& code) { int d = 0; while (d < D && idx >= hoff(d + 1)) d++; code = idx - hoff(d); return d; };
     auto is_node = [&](int d, int code, uint32_t cnt) { return cnt >= 1 && (d == 0 || hst[hoff(d - 1) + (code >> 2)] > 1); };
-    for (int idx = tid; idx < hTotal; idx += kDistThreads) {
-        int code;
-        const int d = depth_of(idx, code);
-        const uint32_t cnt = hst[idx];
-        if (is_node(d, code, cnt)) { atomicAdd(&sTal[d][0], 1); atomicAdd(&sTal[d][cnt == 1 ? 1 : 2], 1); }
+    // a thread's (at most three) histogram entries: depth, code, count and "is a node" are worked out once, here, and kept
+    // for the two passes below (each used to redo the depth search and the parent lookup)
+    constexpr int kIdxPer = (1368 + kDistThreads - 1) / kDistThreads;
+    int eD[kIdxPer], eCode[kIdxPer]; uint32_t eCnt[kIdxPer]; bool eNode[kIdxPer];
+#pragma unroll
+    for (int k = 0; k < kIdxPer; k++) {
+        const int idx = tid + k * kDistThreads;
+        eD[k] = 0; eCode[k] = 0; eCnt[k] = 0; eNode[k] = false;
+        if (idx < hTotal) {
+            eD[k] = depth_of(idx, eCode[k]);
+            eCnt[k] = hst[idx];
+            eNode[k] = is_node(eD[k], eCode[k], eCnt[k]);
+            if (eNode[k]) { atomicAdd(&sTal[eD[k]][0], 1); atomicAdd(&sTal[eD[k]][eCnt[k] == 1 ? 1 : 2], 1); }
+        }
     }
     __syncthreads();
     int rstar = 0;
@@ -959,24 +970,30 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
         return base + ((((d & 1) ? nIni - 1 - root : root) << (2 * d)) | ((code & low) ^ (0x333 & low)));
     };
     const int seqLen = hoff(rstar) + (nIni << (2 * rstar));
-    for (int i = tid; i < seqLen; i += kDistThreads) sq[i] = 0;
-    __syncthreads();
-    for (int idx = tid; idx < seqLen; idx += kDistThreads) {
-        int code;
-        const int d = depth_of(idx, code);
-        const uint32_t cnt = hst[idx];
-        if (is_node(d, code, cnt) && (d == rstar || cnt == 1)) sq[seq_index(d, code)] = 1;
+    // (d, code) -> seq_index is one-to-one onto [0, seqLen) for the entries of depth <= r*: every slot is written, no clearing pass
+    int eSeq[kIdxPer];
+#pragma unroll
+    for (int k = 0; k < kIdxPer; k++) {
+        const int idx = tid + k * kDistThreads;
+        eSeq[k] = 0;
+        if (idx < seqLen) {
+            eSeq[k] = seq_index(eD[k], eCode[k]);
+            eNode[k] = eNode[k] && (eD[k] == rstar || eCnt[k] == 1);   // from here on: "is in the list"
+            sq[eSeq[k]] = eNode[k] ? 1u : 0u;
+        } else {
+            eNode[k] = false;
+        }
     }
     __syncthreads();
     int m = (int)block_excl_scan(sq, seqLen, wtmp);
     int cur = 0;
     if (m > cap) { if (tid == 0) atomicOr(errFlag, 2); return; }  // cannot happen (size <= max(N + 2, 4 * nIni)); guard anyway
-    for (int idx = tid; idx < seqLen; idx += kDistThreads) {
-        int code;
-        const int d = depth_of(idx, code);
-        const uint32_t cnt = hst[idx];
-        if (!(is_node(d, code, cnt) && (d == rstar || cnt == 1))) continue;
-        const int pos = (int)sq[seq_index(d, code)];
+#pragma unroll
+    for (int k = 0; k < kIdxPer; k++) {
+        if (!eNode[k]) continue;
+        const int d = eD[k], code = eCode[k];
+        const uint32_t cnt = eCnt[k];
+        const int pos = (int)sq[eSeq[k]];
         const int root = code >> (2 * d);
         int x0 = (short)(int)__fmul_rn(hX, (float)root), x1 = (short)(int)__fmul_rn(hX, (float)(root + 1)), y0 = 0, y1 = (short)L.winH;
         for (int t = 1; t <= d; t++) {
@@ -1046,17 +1063,13 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
                 uint32_t rank = 0;
                 if (e < E) {
                     const uint32_t ke = tA[e];
-                    // The lanes walk their part of the table ROTATED by their lane number: at any moment a wave reads 64 different
-                    // uint4s.  All lanes on the same uint4 is not a broadcast for a 128-bit read -- the wave's 32 reads took 5.5 us
-                    // (tools/dist_timing.py), a sixth of this block's life.  Keys are below 2^31 (count < 2^18, << 13): "ke < k" is
-                    // the sign of the difference.
+                    // (all lanes of a part on the same uint4: a broadcast.)  Keys are below 2^31 (count < 2^18, << 13): "ke < k" is the
+                    // sign of the difference, taken with a shift -- as compares the compiler routes every one through an SGPR pair
                     const int base4 = sub * per / 4, n4 = (min(E4, (sub + 1) * per) - sub * per) / 4;
-                    int idx = n4 > 0 ? (lane / parts) % n4 : 0;
 #pragma unroll 4
                     for (int j = 0; j < n4; j++) {
-                        const uint4 k4 = ((const uint4*)tA)[base4 + idx];
+                        const uint4 k4 = ((const uint4*)tA)[base4 + j];
                         rank += ((ke - k4.x) >> 31) + ((ke - k4.y) >> 31) + ((ke - k4.z) >> 31) + ((ke - k4.w) >> 31);
-                        if (++idx == n4) idx = 0;
                     }
                 }
                 STAMP(24);
