@@ -603,7 +603,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
                     const int na = __popcll(bala);
                     int base = 0;
                     if ((tid & 63) == 0) base = atomicAdd(&sLive[(round + 1) & 1], na + __popcll(balb));
-                    base = __shfl(base, 0);
+                    base = __builtin_amdgcn_readfirstlane(base);   // (not a ds_bpermute round trip)
                     if (keepa) nx[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bala >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bala, 0))] = (uint16_t)ka;
                     if (keepb) nx[base + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(balb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)balb, 0))] = (uint16_t)kb;
                 }
@@ -694,7 +694,7 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
                     const int na = __popcll(bala);
                     int base = 0;
                     if ((tid & 63) == 0) base = atomicAdd(&sPending[(round + 1) & 1], na + __popcll(balb));
-                    base = __shfl(base, 0);
+                    base = __builtin_amdgcn_readfirstlane(base);   // (not a ds_bpermute round trip)
                     if (wait[0]) pn[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bala >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bala, 0))] = (uint16_t)qq[0];
                     if (wait[1]) pn[base + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(balb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)balb, 0))] = (uint16_t)qq[1];
                 }
