@@ -41,10 +41,13 @@ constexpr int kMaxQueryIters = 32;  // decided-bit per (thread, iteration): nq <
 #endif
 #ifdef ORBT_PHASE_TIMING  // tools/proj_phases.sh: where a workgroup of the resolve / candidates kernels spends its time (100 MHz wall clock)
 __device__ unsigned long long g_orbtPhase[16];
-__device__ int g_orbtCensus[64][2];   // per round of the resolve: live entries, undecided queries at its head
+__device__ int g_orbtCensus[64][2];
+__device__ unsigned long long g_orbtBuild[12];   // phases of k_frame_build (block 0)
+#define ORBT_BMARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_orbtBuild[i] = wall_clock64(); } while (0)   // per round of the resolve: live entries, undecided queries at its head
 #define ORBT_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_orbtPhase[i] = wall_clock64(); } while (0)
 #else
 #define ORBT_MARK(i) do { } while (0)
+#define ORBT_BMARK(i) do { } while (0)
 #endif
 
 // exclusive scan of one value per thread over the workgroup; returns the exclusive prefix, *total = sum
@@ -113,6 +116,9 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t gl[];
     __shared__ int wsum[kWaves];
+    constexpr int kBigCells = 64;
+    __shared__ int sBigN;
+    __shared__ uint16_t sBig[kBigCells];
     const int capE = (a.fs.cap + 1) & ~1;
     int32_t* cnt = gl;
     int32_t* cur = gl + a.fs.ncell;
@@ -130,8 +136,11 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
     int32_t* __restrict__ cs = a.fs.cellStart + (int64_t)slot * (a.fs.ncell + 1);
     int32_t* __restrict__ ci = a.fs.cellIdx + (int64_t)slot * a.fs.cap;
     uint4* __restrict__ rec = a.fs.rec + (int64_t)slot * a.fs.cap;
+    ORBT_BMARK(0);
+    if (tid == 0) sBigN = 0;
     for (int c = tid; c < a.fs.ncell; c += kThreads) { cnt[c] = 0; cur[c] = 0; }
     __syncthreads();
+    ORBT_BMARK(1);
     for (int i = tid; i < n; i += kThreads) {
         KeyDev kp = sk[i];
         if (a.undistort) undistort_point(a.und, kp.x, kp.y);
@@ -144,20 +153,26 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
     {   // descriptors: 32 bytes per feature as two 16-byte lanes
         const uint4* __restrict__ s4 = (const uint4*)(a.srcDesc + (int64_t)src * a.srcCap * 32);
         uint4* __restrict__ d4 = (uint4*)(a.fs.desc + (int64_t)slot * a.fs.cap * 32);
+        ORBT_BMARK(2);
         for (int i = tid; i < 2 * n; i += kThreads) d4[i] = s4[i];
     }
+    ORBT_BMARK(3);
     __syncthreads();
+    ORBT_BMARK(4);
+    // cell starts: ONE scan over the workgroup, a thread owning a run of consecutive cells (3 at 64 x 48 cells) -- it was a
+    // scan (two barriers) per 1024 cells
     int carry = 0;
-    for (int base = 0; base < a.fs.ncell; base += kThreads) {
-        const int c = base + tid;
-        const int v = c < a.fs.ncell ? cnt[c] : 0;
-        int tot;
-        const int ex = block_scan_excl(v, wsum, &tot);
-        if (c < a.fs.ncell) { cnt[c] = carry + ex; cs[c] = carry + ex; }
-        carry += tot;
+    {
+        const int per = (a.fs.ncell + kThreads - 1) / kThreads;
+        const int c0 = min(tid * per, a.fs.ncell), c1 = min(c0 + per, a.fs.ncell);
+        int sum = 0;
+        for (int c = c0; c < c1; c++) sum += cnt[c];
+        int run = block_scan_excl(sum, wsum, &carry);
+        for (int c = c0; c < c1; c++) { const int v = cnt[c]; cnt[c] = run; cs[c] = run; run += v; }
     }
     if (tid == 0) { cs[a.fs.ncell] = carry; a.fs.n[slot] = n; }
     __syncthreads();
+    ORBT_BMARK(5);
     for (int i = tid; i < n; i += kThreads) {
         int px, py;
         if (orbm::pos_in_grid(a.grid, kx[i], ky[i], px, py)) {
@@ -166,21 +181,70 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
         }
     }
     __syncthreads();
-    for (int c = tid; c < a.fs.ncell; c += kThreads) {  // restore insertion order inside every cell
-        const int s = cnt[c], e = s + cur[c];
-        for (int i = s + 1; i < e; i++) {
-            const uint16_t v = lst[i];
-            int j = i - 1;
-            while (j >= s && lst[j] > v) { lst[j + 1] = lst[j]; j--; }
-            lst[j + 1] = v;
+    ORBT_BMARK(6);
+    // restore insertion order inside every cell.  A thread sorts its cell's few entries by insertion; a crowded cell (a corner
+    // cluster: 20 features in one 19 x 8 px cell) would cost that one thread ~n^2 / 2 dependent LDS accesses with the
+    // other 1023 waiting -- 4 of this kernel's 12 us -- so cells above kSmall go to a list and are rank-sorted by a wave each.
+    constexpr int kSmall = 8;
+    for (int c = tid; c < a.fs.ncell; c += kThreads) {
+        const int s = cnt[c], k = cur[c];
+        if (k < 2) continue;
+        if (k > kSmall) {
+            const int p = atomicAdd(&sBigN, 1);
+            if (p < kBigCells) { sBig[p] = (uint16_t)c; continue; }
+            for (int i = s + 1; i < s + k; i++) {   // (more crowded cells than the list holds: sorted here after all)
+                const uint16_t v = lst[i];
+                int j = i - 1;
+                while (j >= s && lst[j] > v) { lst[j + 1] = lst[j]; j--; }
+                lst[j + 1] = v;
+            }
+            continue;
+        }
+        // up to eight entries: into registers (independent loads), a 19-exchange sorting network, back -- two LDS round trips
+        // where the insertion sort made a dependent one per comparison
+        uint32_t v[kSmall];
+#pragma unroll
+        for (int i = 0; i < kSmall; i++) v[i] = i < k ? (uint32_t)lst[s + i] : 0xFFFFFFFFu;
+#define ORBT_CX(i, j) do { const uint32_t lo_ = min(v[i], v[j]), hi_ = max(v[i], v[j]); v[i] = lo_; v[j] = hi_; } while (0)
+        ORBT_CX(0, 1); ORBT_CX(2, 3); ORBT_CX(4, 5); ORBT_CX(6, 7);
+        ORBT_CX(0, 2); ORBT_CX(1, 3); ORBT_CX(4, 6); ORBT_CX(5, 7);
+        ORBT_CX(1, 2); ORBT_CX(5, 6); ORBT_CX(0, 4); ORBT_CX(3, 7);
+        ORBT_CX(1, 5); ORBT_CX(2, 6);
+        ORBT_CX(1, 4); ORBT_CX(3, 6);
+        ORBT_CX(2, 4); ORBT_CX(3, 5);
+        ORBT_CX(3, 4);
+#undef ORBT_CX
+#pragma unroll
+        for (int i = 0; i < kSmall; i++) if (i < k) lst[s + i] = (uint16_t)v[i];
+    }
+    __syncthreads();
+    {
+        const int nBig = min(sBigN, kBigCells), lane = tid & 63;
+        for (int b = tid >> 6; b < nBig; b += kWaves) {
+            const int c = sBig[b], s = cnt[c], k = cur[c];
+            if (k <= 64) {   // one entry per lane; its rank = the entries below it (all different)
+                const int v = lane < k ? (int)lst[s + lane] : 0x7FFFFFFF;
+                int rank = 0;
+                for (int j = 0; j < k; j++) rank += __builtin_amdgcn_readlane(v, j) < v;
+                if (lane < k) lst[s + rank] = (uint16_t)v;   // (every lane read its entry before any lane writes: one load instruction above)
+            } else if (lane == 0) {
+                for (int i = s + 1; i < s + k; i++) {
+                    const uint16_t v = lst[i];
+                    int j = i - 1;
+                    while (j >= s && lst[j] > v) { lst[j + 1] = lst[j]; j--; }
+                    lst[j + 1] = v;
+                }
+            }
         }
     }
     __syncthreads();
+    ORBT_BMARK(7);
     for (int j = tid; j < carry; j += kThreads) {
         const int i = lst[j];
         ci[j] = i;
         rec[j] = make_uint4(__float_as_uint(kx[i]), __float_as_uint(ky[i]), (uint32_t)i | ((uint32_t)ko[i] << 24), 0u);
     }
+    ORBT_BMARK(8);
 }
 
 // ------------------------------------------------------------------ SearchByProjection, batched: candidates + resolve

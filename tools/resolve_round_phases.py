@@ -26,3 +26,5 @@ for th in (15.0, 30.0):
         if cen[2 * i] < 0: break
         rows.append("%d/%d" % (cen[2 * i], cen[2 * i + 1]))
     print("   live entries / undecided queries per round:", " ".join(rows))
+bu = (C.c_double * 11)(); L.orbm_debug_build_phases(bu, 8)
+print("k_frame_build: clear %.2f, keys + undistort + count %.2f, descriptor copy %.2f, barrier %.2f, scan %.2f, scatter %.2f, sort %.2f, write %.2f us" % tuple(list(bu)[:8]))
