@@ -689,17 +689,25 @@ __device__ __forceinline__ void wave_divide(const uint64_t* __restrict__ srcb, u
 
 // LDS = true: node list and scratch live in LDS (every shipped configuration);
 // LDS = false: same code over a per-block global scratch region, for very large per-level targets.
+struct DistArgs {
+    const Geom* g; const uint64_t* candRaw; uint64_t* candA; uint64_t* candB; const Cell* cells; const int32_t* cellCount;
+    int32_t* candCount; uint64_t* kept; int32_t* keptCount; int32_t* errFlag; int cap, f0; uint32_t* gscratch; int scratchWords, l0;
+};
+
+// the body of k_distribute for block (bxLevel, by) of a (levels, frames) grid
 template <bool LDS>
-__global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restrict__ g,
-                                                            const uint64_t* __restrict__ candRaw,
-                                                            uint64_t* __restrict__ candA, uint64_t* __restrict__ candB,
-                                                            const Cell* __restrict__ cells,
-                                                            const int32_t* __restrict__ cellCount,
-                                                            int32_t* __restrict__ candCount,
-                                                            uint64_t* __restrict__ kept, int32_t* __restrict__ keptCount,
-                                                            int32_t* __restrict__ errFlag, int cap, int f0,
-                                                            uint32_t* __restrict__ gscratch, int scratchWords, int l0)
+__device__ __forceinline__ void distribute_body(const DistArgs& da, const int bxLevel, const int by)
 {
+    const Geom* __restrict__ g = da.g;
+    const uint64_t* __restrict__ candRaw = da.candRaw;
+    uint64_t* __restrict__ candA = da.candA; uint64_t* __restrict__ candB = da.candB;
+    const Cell* __restrict__ cells = da.cells;
+    const int32_t* __restrict__ cellCount = da.cellCount;
+    int32_t* __restrict__ candCount = da.candCount;
+    uint64_t* __restrict__ kept = da.kept; int32_t* __restrict__ keptCount = da.keptCount;
+    int32_t* __restrict__ errFlag = da.errFlag;
+    const int cap = da.cap, f0 = da.f0, scratchWords = da.scratchWords, l0 = da.l0;
+    uint32_t* __restrict__ gscratch = da.gscratch;
 #ifdef ORBX_DIST_TIMING  // phase timestamps of the level-0 block of frame 0, printed at the end (tools/dist_timing.py)
     __shared__ uint64_t sStamp[96]; __shared__ uint64_t sCyc[96]; __shared__ int sStampId[96]; __shared__ int sNStamp;
     if (threadIdx.x == 0) sNStamp = 0;
@@ -709,8 +717,8 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
 #endif
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_lds[];
     // the launch covers levels [l0, l0 + gridDim.x): level 0 may go ahead of the others (it needs no pyramid)
-    const int l = blockIdx.x + l0, f = blockIdx.y + f0;
-    uint32_t* const smem = LDS ? smem_lds : gscratch + (int64_t)(blockIdx.y * g->nlevels + l) * scratchWords;
+    const int l = bxLevel + l0, f = by + f0;
+    uint32_t* const smem = LDS ? smem_lds : gscratch + (int64_t)(by * g->nlevels + l) * scratchWords;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kDistThreads / 64;
     const LevelGeom& L = g->lv[l];
@@ -1235,7 +1243,7 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
 #ifdef ORBX_DIST_TIMING
     __syncthreads();
     STAMP(99);
-    if (tid == 0 && l == 0 && blockIdx.y == 0) {
+    if (tid == 0 && l == 0 && by == 0) {
         printf("DIST n=%d N=%d D=%d\n", n, N, D);
         uint64_t prev = sStamp[0];
         for (int i = 0; i < sNStamp; i++) {
@@ -1245,6 +1253,12 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(const Geom* __restr
     }
 #endif
 #undef STAMP
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kDistThreads) void k_distribute(DistArgs da)
+{
+    distribute_body<LDS>(da, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------ Gaussian 7x7 sigma 2
@@ -1492,17 +1506,19 @@ __device__ const BlurOps kBlurOps = make_blur_ops();
 //                scaled by 256), joined by one v_lshl_add; the presets carry the 128*257 offsets and the 2^15 rounding.
 // Tile rows 32 .. 37 (the lower halo) are a second, mostly empty 32-row product on both sides.  Results leave as
 // bytes into an LDS tile (ds_write_b8_d16_hi takes bits 16 .. 23 of the saturated sum) and are stored as row dwords.
-__global__ __launch_bounds__(256, 2) void k_blur_mfma(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt, int nframes)
+constexpr int kBlurMfmaInStride = 36;      // dwords: 144-byte rows keep the 16-byte fragment reads conflict free
+constexpr int kBlurMfmaOutStride = 33;     // dwords per output row (128 bytes + 4)
+constexpr int kBlurMfmaInWords = (kBlurTH + 6) * kBlurMfmaInStride + 8, kBlurMfmaOutWords = kBlurTH * kBlurMfmaOutStride;
+
+// one tile (bx of frame fr) by the 256 threads `tid`; ONE workgroup barrier inside, reached by every thread (valid or not)
+__device__ __forceinline__ void blur_mfma_tile(const Geom* __restrict__ g, const FrameSrc& src, const BlurTiles& bt, const int bx, const int fr,
+                                               const bool valid, const int tid, uint32_t* in, uint32_t* outT)
 {
     constexpr int TW = kBlurTW, TH = kBlurTH;
-    constexpr int IN_STRIDE = 36;             // dwords: 144-byte rows keep the 16-byte fragment reads conflict free
-    constexpr int OUT_STRIDE = 33;            // dwords per output row (128 bytes + 4)
+    constexpr int IN_STRIDE = kBlurMfmaInStride, OUT_STRIDE = kBlurMfmaOutStride;
     typedef int b4i __attribute__((ext_vector_type(4)));
     typedef int b16i __attribute__((ext_vector_type(16)));
-    __shared__ __attribute__((aligned(16))) uint32_t in[(TH + 6) * IN_STRIDE + 8];
-    __shared__ uint32_t outT[TH * OUT_STRIDE];
-    int bx, fr;
-    if (!xcd_block_frame(nframes, bx, fr)) return;
+    if (!valid) { __syncthreads(); return; }
     const int f = fr + src.f0;
     int l = 0;
     while (l + 1 < g->nlevels && bx >= bt.base[l + 1]) l++;
@@ -1512,7 +1528,6 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const Geom* __restrict__ g
     const int w = L.w, h = L.h;
     int stride;
     const uint8_t* S = level_ptr(g, src, f, l, stride);
-    const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, hh = lane >> 5, m = lane & 31;
     const b4i* ops = (const b4i*)kBlurOps.v;
     const b4i hB0 = ops[lane], hB1 = ops[64 + lane], vA0 = ops[128 + lane], vA1 = ops[192 + lane];
@@ -1574,6 +1589,32 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const Geom* __restrict__ g
 #pragma unroll
     for (int k = 0; k < TH / 8; k++)
         if (rq + 8 * k < nrows) *(uint32_t*)(D + (int64_t)(8 * k) * L.blurStride) = outT[(rq + 8 * k) * OUT_STRIDE + cq];
+}
+
+__global__ __launch_bounds__(256, 2) void k_blur_mfma(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt, int nframes)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t in[kBlurMfmaInWords];
+    __shared__ uint32_t outT[kBlurMfmaOutWords];
+    int bx, fr;
+    if (!xcd_block_frame(nframes, bx, fr)) return;
+    blur_mfma_tile(g, src, bt, bx, fr, true, (int)threadIdx.x, in, outT);
+}
+
+// The quadtree and the Gaussian of a robot's live frame in ONE launch: the first blocks of the grid are k_distribute's (one per
+// level), the others blur two tiles each (a half of the 512 threads per tile).  The two do not depend on each other -- the
+// quadtree needs FAST's candidates, the blur the pyramid -- but in the one queue a live chain runs on they could only follow
+// each other: 5.6 us of blur behind 28 us of quadtree that keeps 8 of the 256 CUs busy.  (Two queues cost an event each
+// way, ~5 us apiece; hipExtAnyOrderLaunch is ignored on gfx9.)  Latency mode only: grid (levels + ceil(tiles / 2), frames).
+__global__ __launch_bounds__(kDistThreads) void k_distribute_blur(DistArgs da, FrameSrc src, BlurTiles bt, int nTiles)
+{
+    static_assert(kDistThreads == 512, "two blur tiles of 256 threads per block");
+    const int nl = da.g->nlevels;
+    if ((int)blockIdx.x < nl) { distribute_body<true>(da, (int)blockIdx.x, (int)blockIdx.y); return; }
+    __shared__ __attribute__((aligned(16))) uint32_t in2[2][kBlurMfmaInWords];
+    __shared__ uint32_t outT2[2][kBlurMfmaOutWords];
+    const int half = (int)threadIdx.x >> 8;
+    const int tile = 2 * ((int)blockIdx.x - nl) + half;
+    blur_mfma_tile(da.g, src, bt, tile, (int)blockIdx.y, tile < nTiles, (int)threadIdx.x & 255, in2[half], outT2[half]);
 }
 
 // ------------------------------------------------------------------ orientation + rBRIEF + pack
