@@ -19,7 +19,8 @@
 //
 // build:  hipcc -O2 -std=c++17 examples/multi_robot.cpp -Iinclude -Lorbslamm_amd -lorbslamm_hip -lrccl -Wl,-rpath,'$ORIGIN/../orbslamm_amd' -o examples/multi_robot
 // usage:  multi_robot [--gpus N] [--robots R] [--frames F] [--warmup W] [--mode track|bf|extract|full] [--depth 1|2]
-//                     [--per-call 1|2 (cameras whose frames one thread puts through the chain together)] [--attach 0|1] [--pinned 0|1] [--w 1241 --h 376 --nfeat 2000] [--interval 200] [--json] [--dump FILE]
+//                     [--hub P (robots in groups of P share one orbslamm::CameraHub: still one thread per robot, the frames that wait together go through one chain) --hub-wait US]
+//                     [--per-call 1..8 (cameras whose frames one thread puts through the chain together)] [--attach 0|1] [--pinned 0|1] [--w 1241 --h 376 --nfeat 2000] [--interval 200] [--json] [--dump FILE]
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -31,17 +32,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "orbslamm_hip.h"
+#include "orbslamm_hub.hpp"
 
 namespace {
 
 struct Args {
-    int gpus = 1, robots = 1, per_call = 1, frames = 600, warmup = 30, depth = 1, attach = 1, pinned = 1, w = 1241, h = 376, nfeat = 2000, interval = 200;
+    int gpus = 1, robots = 1, per_call = 1, hub = 0, hub_wait = 40, frames = 600, warmup = 30, depth = 1, attach = 1, pinned = 1, w = 1241, h = 376, nfeat = 2000, interval = 200;
     std::string mode = "track", dump;
     bool json = false;
 };
@@ -107,7 +110,72 @@ struct Robot {
     Stats st{};
     bool failed = false;
     std::atomic<int64_t> live_frames{0}, live_kps{0}, live_matches{0};
+    orbslamm::CameraHub* hub = nullptr; int cam = 0;   // --hub: this robot is camera `cam` of a hub shared with its neighbours
+    double batch_mean = 0;
     double us_submit = 0, us_enqueue = 0, us_wait = 0;   // host time in orbx_submit_batch | build + track calls | collect + results (waiting included)
+
+    // --hub: the robot's loop is what it was -- one blocking call per frame -- but the call goes to a hub that puts the frames
+    // of the robots waiting at that moment through ONE chain (include/orbslamm_hub.hpp)
+    void run_hub(std::atomic<int>& ready, std::atomic<bool>& go)
+    {
+        const Args& A = *a;
+        const int nring = 8, cap = hub->cap();
+        uint8_t* ring = nullptr; int stride = A.w; size_t pitch = (size_t)A.w * A.h;
+        std::vector<uint8_t> pageable;
+        if (A.pinned) OX(orbx_host_alloc_frames(hub->extractor(), nring, A.w, A.h, &ring, &stride, &pitch));
+        else { pageable.resize(pitch * nring); ring = pageable.data(); }
+        {
+            int cw, ch;
+            const std::vector<uint8_t> scene = make_scene(A.w, A.h, robot, cw, ch);
+            for (int t = 0; t < nring; t++) make_frame(scene, cw, A.w, A.h, robot, t, ring + (size_t)t * pitch, stride);
+        }
+        std::vector<OrbxKeyPoint> kps((size_t)cap);
+        std::vector<uint8_t> desc((size_t)cap * 32);
+        std::vector<int32_t> assign((size_t)cap);
+        const int total = A.warmup + A.frames;
+        lat_ms.reserve(A.frames);
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        using clk = std::chrono::steady_clock;
+        clk::time_point tTimed = clk::now();
+        int64_t batchSum = 0;
+        for (int i = 0; i < total; i++) {
+            if (i == A.warmup) tTimed = clk::now();
+            const uint8_t* fr0 = ring + (size_t)(i % nring) * pitch;
+            const auto t0 = clk::now();
+            orbslamm::CameraHub::Result res;
+            OX(hub->track(cam, fr0, stride, kps.data(), desc.data(), assign.data(), &res));
+            const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+            const int n = res.n;
+            uint64_t cs = (uint64_t)n * 1315423911ull;   // the same per-frame word the loop below forms for one camera per call
+            if (n > 0) { uint32_t d0; memcpy(&d0, desc.data() + (size_t)(n - 1) * 32, 4); cs ^= d0; }
+            if (res.nmatches >= 0 && n > 0) cs ^= (uint64_t)(uint32_t)assign[n - 1] << 32;
+            if (robot == 0 && !A.dump.empty() && i >= A.warmup && i < A.warmup + 8) {
+                FILE* df = fopen(A.dump.c_str(), i == A.warmup ? "wb" : "ab");
+                if (df) {
+                    const int32_t hdr[6] = {i, n, A.w, A.h, 2, 1};
+                    fwrite(hdr, sizeof hdr, 1, df);
+                    for (int y = 0; y < A.h; y++) fwrite(fr0 + (size_t)y * stride, 1, (size_t)A.w, df);
+                    fwrite(kps.data(), sizeof(OrbxKeyPoint), (size_t)n, df);
+                    fwrite(desc.data(), 32, (size_t)n, df);
+                    if (i > 0) { const int32_t nm = res.nmatches; fwrite(assign.data(), 4, (size_t)n, df); fwrite(&nm, 4, 1, df); }
+                    fclose(df);
+                }
+            }
+            if (i >= A.warmup) {
+                lat_ms.push_back(ms);
+                const int nm = std::max(0, res.nmatches);
+                st.frames += 1; st.keypoints += n; st.matches += nm; st.checksum = st.checksum * 1099511628211ull ^ cs;
+                batchSum += res.batch;
+                live_frames.fetch_add(1, std::memory_order_relaxed); live_kps.fetch_add(n, std::memory_order_relaxed); live_matches.fetch_add(nm, std::memory_order_relaxed);
+            }
+        }
+        hub->leave(cam);
+        st.frames = (int64_t)lat_ms.size();
+        batch_mean = (double)batchSum / std::max<size_t>(1, lat_ms.size());
+        st.ns_busy = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tTimed).count();
+        if (A.pinned) orbx_host_free(hub->extractor(), ring);
+    }
 
     void run(std::atomic<int>& ready, std::atomic<bool>& go)
     {
@@ -293,6 +361,7 @@ int main(int argc, char** argv)
         else if (k == "--attach") A.attach = atoi(val()); else if (k == "--pinned") A.pinned = atoi(val()); else if (k == "--w") A.w = atoi(val());
         else if (k == "--h") A.h = atoi(val()); else if (k == "--nfeat") A.nfeat = atoi(val()); else if (k == "--interval") A.interval = atoi(val());
         else if (k == "--dump") A.dump = val();
+        else if (k == "--hub") A.hub = atoi(val()); else if (k == "--hub-wait") A.hub_wait = atoi(val());
         else if (k == "--json") A.json = true;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
@@ -304,7 +373,7 @@ int main(int argc, char** argv)
     if (A.mode == "full" && (A.per_call != 1 || A.depth != 1)) { fprintf(stderr, "--mode full: one camera per call, one ticket deep\n"); return 2; }
     if (A.mode == "full" && A.warmup < 12) A.warmup = 12;   // the ring's local maps are built during the warm-up
     if (A.depth != 1 && A.depth != 2) { fprintf(stderr, "--depth 1|2\n"); return 2; }
-    if (A.per_call < 1 || A.per_call > 2 || (A.per_call > 1 && A.mode == "bf")) { fprintf(stderr, "--per-call 1|2 (2: modes track and extract -- the brute-force match is against the SAME camera's previous frame)\n"); return 2; }
+    if (A.per_call < 1 || A.per_call > 8 || (A.per_call > 1 && A.mode == "bf")) { fprintf(stderr, "--per-call 1..8 (> 1: modes track and extract -- the brute-force match is against the SAME camera's previous frame)\n"); return 2; }
 
     // RCCL: one communicator per GPU in this one process (the reference is one process, one thread per robot)
     std::vector<ncclComm_t> comms(A.gpus);
@@ -318,12 +387,33 @@ int main(int argc, char** argv)
             hipMalloc(&d_send[d], sizeof(Stats)) != hipSuccess || hipMalloc(&d_recv[d], sizeof(Stats) * A.gpus) != hipSuccess) { fprintf(stderr, "hip setup failed\n"); return 4; }
     }
 
+    if (A.hub < 0 || A.hub > orbslamm::CameraHub::kMaxCameras || (A.hub > 0 && (A.mode != "track" || A.per_call != 1 || A.depth != 1))) { fprintf(stderr, "--hub 1..8: mode track, one camera per robot, one ticket deep\n"); return 2; }
+    // --hub P: on every GPU the robots are dealt to hubs of P cameras in the order they come
+    std::vector<std::unique_ptr<orbslamm::CameraHub>> hubs;
     std::vector<Robot> robots(A.robots);
+    if (A.hub > 0) {
+        for (int d = 0; d < A.gpus; d++) {
+            int k = 0;
+            for (int r = d; r < A.robots; r += A.gpus, k++) {
+                if (k % A.hub == 0) {
+                    int left = 0; for (int q = r; q < A.robots; q += A.gpus) left++;
+                    orbslamm::CameraHub::Config c;
+                    c.prm = OrbxParams{A.nfeat, 1.2f, 8, 20, 7}; c.w = A.w; c.h = A.h; c.cameras = std::min(A.hub, left); c.device = d; c.wait_us = A.hub_wait;
+                    const float K[4] = {718.856f, 718.856f, 607.1928f, 185.2157f};
+                    memcpy(c.K, K, sizeof K);
+                    hubs.emplace_back(new orbslamm::CameraHub());
+                    const int rc = hubs.back()->open(c);
+                    if (rc) { fprintf(stderr, "hub on GPU %d: open failed (%d): %s\n", d, rc, orbx_last_error()); return 4; }
+                }
+                robots[r].hub = hubs.back().get(); robots[r].cam = k % A.hub;
+            }
+        }
+    }
     std::atomic<int> ready{0};
     std::atomic<bool> go{false};
     std::vector<std::thread> th;
     for (int r = 0; r < A.robots; r++) { robots[r].robot = r; robots[r].device = r % A.gpus; robots[r].a = &A; }
-    for (int r = 0; r < A.robots; r++) th.emplace_back([&, r] { robots[r].run(ready, go); if (robots[r].failed) ready.fetch_add(1 << 16); });
+    for (int r = 0; r < A.robots; r++) th.emplace_back([&, r] { if (robots[r].hub) robots[r].run_hub(ready, go); else robots[r].run(ready, go); if (robots[r].failed) ready.fetch_add(1 << 16); });
     while ((ready.load() & 0xFFFF) + (ready.load() >> 16) < A.robots) std::this_thread::yield();
     const auto t0 = std::chrono::steady_clock::now();
     go.store(true, std::memory_order_release);
@@ -374,16 +464,17 @@ int main(int argc, char** argv)
     int64_t gframes = 0; for (auto& s : gathered) gframes += s.frames;
     double mean = 0; for (double v : all) mean += v; mean /= std::max<size_t>(1, all.size());
     const double fps = frames / (ns_max * 1e-9);
-    double usSub = 0, usEnq = 0;
+    double usSub = 0, usEnq = 0, hubBatch = 0;
+    for (auto& r : robots) hubBatch += r.batch_mean / A.robots;
     for (auto& r : robots) { usSub += r.us_submit / A.robots; usEnq += r.us_enqueue / A.robots; }
     std::sort(all.begin(), all.end());
     const double p95 = all.empty() ? 0 : all[all.size() * 95 / 100], p99 = all.empty() ? 0 : all[all.size() * 99 / 100], pmax = all.empty() ? 0 : all.back();
     if (A.json) {
         printf("{\"mode\": \"%s\", \"gpus\": %d, \"robots\": %d, \"cameras_per_call\": %d, \"depth\": %d, \"attach\": %d, \"pinned\": %d, \"w\": %d, \"h\": %d, \"nfeat\": %d, \"frames_per_robot\": %d, "
                "\"frames_per_s\": %.1f, \"ms_median\": %.4f, \"ms_mean\": %.4f, \"ms_p95\": %.4f, \"ms_p99\": %.4f, \"ms_max\": %.4f, \"host_us_submit\": %.1f, \"host_us_enqueue\": %.1f, \"keypoints_mean\": %.1f, \"matches_mean\": %.1f, \"wall_s\": %.3f, "
-               "\"rccl_allgathers\": %d, \"gathered_frames\": %lld, \"checksum\": \"%016llx\"}\n",
+               "\"rccl_allgathers\": %d, \"gathered_frames\": %lld, \"hub\": %d, \"hub_batch_mean\": %.2f, \"checksum\": \"%016llx\"}\n",
                A.mode.c_str(), A.gpus, A.robots, A.per_call, A.depth, A.attach, A.pinned, A.w, A.h, A.nfeat, A.frames, fps, median(all), mean, p95, p99, pmax, usSub, usEnq,
-               (double)kps / std::max<int64_t>(1, frames), (double)matches / std::max<int64_t>(1, frames), wall_s, gathers, (long long)gframes, (unsigned long long)cs);
+               (double)kps / std::max<int64_t>(1, frames), (double)matches / std::max<int64_t>(1, frames), wall_s, gathers, (long long)gframes, A.hub, hubBatch, (unsigned long long)cs);
     } else {
         // as the reference's examples end (mono_tum.cc:113-122)
         printf("-------\n\nmedian tracking time: %f ms\nmean tracking time: %f ms\n", median(all), mean);

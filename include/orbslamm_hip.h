@@ -70,6 +70,12 @@ typedef struct orbx_handle orbx_t;
 /* Allocates every device buffer once (no allocation on the per-frame path).
  * max_w/max_h: largest frame; max_batch: frames in flight per call. */
 int orbx_create(const OrbxParams* params, int max_w, int max_h, int max_batch, int device, orbx_t** out);
+/* The same for the LIVE frames of up to max_cameras (1..8) cameras: every call of 1..max_cameras frames runs as ONE
+ * latency-mode chain (one queue, frames up through a copy kernel, results behind a flag the caller polls) -- the handle
+ * a hub creates that puts the frames of several robots' tracking threads through the GPU together
+ * (include/orbslamm_hub.hpp; MultipleRobotsScenario/Examples/Monocular/mono_kitti.cc:83-101 with more robots than the
+ * GPU runs queues).  orbx_create keeps the latency mode to calls of one or two frames. */
+int orbx_create_live(const OrbxParams* params, int max_w, int max_h, int max_cameras, int device, orbx_t** out);
 void orbx_destroy(orbx_t* h);
 
 /* GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors /

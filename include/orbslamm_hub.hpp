@@ -1,0 +1,223 @@
+// orbslamm_hub.hpp -- the live frames of several robots through ONE latency-mode chain (header only, over the C ABI).
+//
+// Reference shape: MultipleRobotsScenario/Examples/Monocular/mono_kitti.cc:83-101 -- one tracking thread per robot, each
+// handing ITS camera's next frame to Tracking::GrabImageMonocular (SingleRobotScenario/src/Tracking.cc:240-267: Frame::Frame
+// -> ExtractORB, UndistortKeyPoints, AssignFeaturesToGrid; TrackWithMotionModel -> SearchByProjection(Cur, Last), :925-936).
+// With one extractor handle per robot every robot owns a chain of ten small kernels in a queue of its own; an MI355X
+// executes about four such queues at a time (docs/experiments.md, round 4), so beyond four robots per GPU the chains
+// queue up behind each other: 8 robots x 1 camera read 19.6 k frames/s, the same as 4.  The kernels of a chain are a
+// few workgroups each -- eight frames in ONE chain take twice as long as one, not eight times.  CameraHub does that
+// without changing the robots' shape: every robot thread still calls `track(camera, frame, ...)` and gets ITS
+// keypoints, descriptors and match table back when the call returns; the frames of the robots that are waiting at that
+// moment go through the chain together (orbx_submit_batch with B = cameras present, one frame-set build, one
+// orbm_track_frames over the pairs present).  Results are the same bytes a handle per robot produces (the kernels
+// treat the frames of a batch independently; tests/test_gpu_example.py replays a hub camera through the CPU oracle).
+//
+// Batching rule: the first thread to find no batch being assembled becomes its leader, waits until every camera that is
+// a member of the hub has a frame waiting or `wait_us` microseconds have passed (cameras that free-run fall into
+// lockstep after one batch; a 30 Hz camera pays at most wait_us once per frame), takes what is there, runs the chain and
+// hands each waiting thread a view of its part; each thread copies its own results out, the next leader returns the ticket.
+// One batch is in flight per hub; for more than eight cameras per GPU use two to four hubs (a queue each).
+//
+// Frames of one batch must be of one kind: all pinned in the device layout (orbx_host_alloc_frames / orbx_host_register,
+// `stride` = the handle's) or all pageable.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+
+#include "orbslamm_hip.h"
+
+namespace orbslamm {
+
+class CameraHub {
+public:
+    static constexpr int kMaxCameras = 8;   // orbx_create_live's ceiling
+
+    struct Config {
+        OrbxParams prm{2000, 1.2f, 8, 20, 7};
+        int w = 0, h = 0, cameras = 1, device = 0;
+        bool track = true;                       // false: extraction only
+        float K[4] = {0, 0, 0, 0}, D[5] = {0, 0, 0, 0, 0};   // fx, fy, cx, cy; k1, k2, p1, p2, k3 (Frame.cc:120-150)
+        float th = 15.0f;                        // SearchByProjection(Cur, Last, th, mono): Tracking.cc:931
+        OrbmProjParams pp{4, 0.9f, 1, 100};      // mode 4, nnratio 0.9, rotation check, TH_HIGH
+        int wait_us = 40;                        // how long a leader waits for the other members' frames
+    };
+    struct Result {
+        int n = 0;            // keypoints of this frame
+        int nmatches = -1;    // SearchByProjection's return value; -1: no previous frame of this camera in the set (no search)
+        int batch = 0;        // how many cameras shared the chain with this frame
+    };
+
+    CameraHub() = default;
+    CameraHub(const CameraHub&) = delete;
+    CameraHub& operator=(const CameraHub&) = delete;
+    ~CameraHub() { close(); }
+
+    int open(const Config& c)
+    {
+        close();
+        cfg_ = c;
+        if (c.cameras < 1 || c.cameras > kMaxCameras || c.w < 1 || c.h < 1) return ORBX_E_INVALID;
+        int rc = orbx_create_live(&c.prm, c.w, c.h, c.cameras, c.device, &ex_);
+        if (rc) return rc;
+        cap_ = orbx_max_keypoints(ex_);
+        if (c.track) {
+            if ((rc = orbm_create(c.device, &m_))) { close(); return rc; }
+            float sf[ORBX_MAX_LEVELS];
+            if ((rc = orbx_scale_tables(ex_, sf, nullptr, nullptr, nullptr))) { close(); return rc; }
+            const float bounds[4] = {0.f, (float)c.w, 0.f, (float)c.h};   // undistorted image bounds of an undistorted camera (Frame.cc:430-462)
+            OrbmGrid g{0.f, 0.f, 64.f / (float)c.w, 48.f / (float)c.h, 64, 48};
+            nslots_ = 4 * c.cameras;
+            if ((rc = orbm_frameset_create(m_, nslots_, cap_, c.K, c.D, &g, bounds, sf, orbx_levels(ex_), &fs_))) { close(); return rc; }
+            if ((rc = orbm_frameset_attach(fs_, ex_))) { close(); return rc; }
+        }
+        for (int s = 0; s < 4 * kMaxCameras; s++) slotCam_[s] = -1;
+        for (int j = 0; j < kMaxCameras; j++) { lastSlot_[j] = -1; seq_[j] = 0; req_[j].state.store(0); }
+        return ORBX_OK;
+    }
+
+    void close()
+    {
+        if (ex_) release_pending();
+        if (fs_) { orbm_frameset_destroy(fs_); fs_ = nullptr; }
+        if (m_) { orbm_destroy(m_); m_ = nullptr; }
+        if (ex_) { orbx_destroy(ex_); ex_ = nullptr; }
+        members_.store(0); waiting_.store(0); leader_.store(false);
+    }
+
+    int cap() const { return cap_; }             // rows a caller's arrays need
+    orbx_t* extractor() const { return ex_; }    // e.g. for orbx_host_alloc_frames
+    // a camera that stops sending frames leaves, so that the others' batches do not wait for it
+    void leave(int cam) { if (cam >= 0 && cam < cfg_.cameras) members_.fetch_and(~(1u << cam)); }
+
+    // Called by camera `cam`'s own thread (one call at a time per camera).  Blocks until this frame's results are in the
+    // caller's arrays: kps[cap()], desc[cap() * 32], assign[cap()] (assign[t] = index of the PREVIOUS frame's feature whose
+    // MapPoint current feature t took, -1 = none; may be NULL).  Returns an ORBX_* code.
+    int track(int cam, const uint8_t* frame, int stride, OrbxKeyPoint* kps, uint8_t* desc, int32_t* assign, Result* res)
+    {
+        if (!ex_ || cam < 0 || cam >= cfg_.cameras || !frame || !kps || !desc || !res) return ORBX_E_INVALID;
+        Request& r = req_[cam];
+        r.frame = frame; r.stride = stride;
+        r.state.store(1, std::memory_order_relaxed);
+        members_.fetch_or(1u << cam, std::memory_order_relaxed);
+        waiting_.fetch_or(1u << cam, std::memory_order_release);
+        for (;;) {
+            const int st = r.state.load(std::memory_order_acquire);
+            if (st >= 2) break;
+            if (!leader_.exchange(true, std::memory_order_acquire)) {
+                // (a batch that was being served while this thread won the flag may have completed this request meanwhile)
+                if (r.state.load(std::memory_order_acquire) < 2) lead();
+                leader_.store(false, std::memory_order_release);
+                continue;
+            }
+            std::this_thread::yield();
+        }
+        // state 2: this thread's part of the batch is published; copy it out (the next leader returns the ticket once all have)
+        const int rc = r.rc;
+        if (rc == ORBX_OK) {
+            res->n = r.n; res->nmatches = r.nmatches; res->batch = r.batch;
+            std::memcpy(kps, r.kps, (size_t)r.n * sizeof(OrbxKeyPoint));
+            std::memcpy(desc, r.desc, (size_t)r.n * 32);
+            if (assign) {
+                if (r.assign) std::memcpy(assign, r.assign, (size_t)r.n * 4);
+                else for (int t = 0; t < r.n; t++) assign[t] = -1;
+            }
+        }
+        r.state.store(0, std::memory_order_relaxed);
+        readers_.fetch_sub(1, std::memory_order_release);
+        return rc;
+    }
+
+private:
+    struct Request {
+        std::atomic<int> state{0};   // 0 idle, 1 waiting for a batch, 2 served (view published)
+        const uint8_t* frame = nullptr; int stride = 0;
+        const OrbxKeyPoint* kps = nullptr; const uint8_t* desc = nullptr; const int32_t* assign = nullptr;
+        int n = 0, nmatches = -1, batch = 0, rc = 0;
+    };
+
+    void lead()
+    {
+        using clk = std::chrono::steady_clock;
+        const auto t0 = clk::now();
+        // every member has a frame waiting, or wait_us are over
+        for (;;) {
+            const uint32_t w = waiting_.load(std::memory_order_acquire), mset = members_.load(std::memory_order_relaxed);
+            if ((w & mset) == mset) break;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count() >= cfg_.wait_us) break;
+            std::this_thread::yield();
+        }
+        release_pending();   // the previous batch's readers had the wait above to copy their parts
+        const uint32_t take = waiting_.exchange(0, std::memory_order_acquire);
+        int cams[kMaxCameras], B = 0;
+        for (int j = 0; j < cfg_.cameras; j++) if (take >> j & 1) cams[B++] = j;
+        if (B == 0) return;
+        const uint8_t* imgs[kMaxCameras];
+        for (int p = 0; p < B; p++) imgs[p] = req_[cams[p]].frame;
+        int rc = ORBX_OK, ticket = -1, np = 0;
+        int32_t cur[kMaxCameras], last[kMaxCameras], pairOf[kMaxCameras];
+        bool strideOk = true;
+        for (int p = 1; p < B; p++) strideOk &= req_[cams[p]].stride == req_[cams[0]].stride;
+        if (!strideOk) rc = ORBX_E_INVALID;
+        if (!rc) rc = orbx_submit_batch(ex_, imgs, B, cfg_.w, cfg_.h, req_[cams[0]].stride, nullptr, &ticket);
+        if (!rc && fs_) {
+            // a ring of slots: this batch's frames take B consecutive ones; a camera's previous frame is searched against as
+            // long as its slot has not been handed to another frame since (4 x cameras slots: at least three batches)
+            if (cursor_ + B > nslots_) cursor_ = 0;
+            const int slot0 = cursor_;
+            cursor_ += B;
+            rc = orbm_frameset_build_from_extractor(fs_, slot0, ex_);
+            for (int p = 0; p < B && !rc; p++) {
+                const int j = cams[p], ls = lastSlot_[j];
+                pairOf[p] = -1;
+                const bool havePrev = ls >= 0 && slotCam_[ls] == j && slotSeq_[ls] == seq_[j] - 1 && (ls < slot0 || ls >= slot0 + B);
+                if (havePrev) { cur[np] = slot0 + p; last[np] = ls; pairOf[p] = np++; }
+            }
+            for (int p = 0; p < B; p++) { const int j = cams[p]; slotCam_[slot0 + p] = j; slotSeq_[slot0 + p] = seq_[j]; lastSlot_[j] = slot0 + p; seq_[j]++; }
+            if (!rc && np > 0) rc = orbm_track_frames(fs_, &cfg_.pp, cfg_.th, cur, last, np);
+        }
+        OrbxBatchView v{};
+        if (!rc) rc = orbx_collect_view(ex_, ticket, &v);
+        const int32_t *assign = nullptr, *nmp = nullptr;
+        int npOut = 0, c2 = 0;
+        if (!rc && np > 0) rc = orbm_track_results(fs_, 0, &assign, &nmp, &npOut, &c2);
+        readers_.store(B, std::memory_order_relaxed);
+        for (int p = 0; p < B; p++) {
+            Request& r = req_[cams[p]];
+            r.rc = rc; r.batch = B;
+            if (!rc) {
+                r.n = v.n[p]; r.kps = v.kps + (size_t)p * v.cap; r.desc = v.desc + (size_t)p * v.cap * 32;
+                const int q = fs_ ? pairOf[p] : -1;
+                r.assign = q >= 0 ? assign + (size_t)q * c2 : nullptr;
+                r.nmatches = q >= 0 ? nmp[q] : -1;
+            }
+        }
+        for (int p = 0; p < B; p++) req_[cams[p]].state.store(2, std::memory_order_release);
+        // The views live in the ticket's pinned block, and the leader itself copies its part only after this returns: the
+        // ticket goes back at the start of the NEXT batch (or in close()), once readers_ has fallen to zero.
+        pendingTicket_ = ticket;
+    }
+
+    void release_pending()
+    {
+        while (readers_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        if (pendingTicket_ >= 0) (void)orbx_release(ex_, pendingTicket_);
+        pendingTicket_ = -1;
+    }
+
+    Config cfg_{};
+    orbx_t* ex_ = nullptr; orbm_t* m_ = nullptr; orbm_frameset_t* fs_ = nullptr;
+    int cap_ = 0, nslots_ = 0, cursor_ = 0;
+    int slotCam_[4 * kMaxCameras]; int64_t slotSeq_[4 * kMaxCameras];
+    int lastSlot_[kMaxCameras]; int64_t seq_[kMaxCameras];
+    Request req_[kMaxCameras];
+    std::atomic<uint32_t> members_{0}, waiting_{0};
+    std::atomic<bool> leader_{false};
+    std::atomic<int> readers_{0};
+    int pendingTicket_ = -1;
+};
+
+}  // namespace orbslamm

@@ -62,7 +62,7 @@ class OrbmProjParams(C.Structure):
 
 # every symbol include/orbslamm_hip.h declares (tests check that all of them resolve)
 EXPORTS = [
-    "orbx_last_error", "orbx_device_count", "orbx_device_pci_bus_id", "orbx_create", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
+    "orbx_last_error", "orbx_device_count", "orbx_device_pci_bus_id", "orbx_create", "orbx_create_live", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
     "orbx_scale_tables", "orbx_features_per_level", "orbx_umax", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch", "orbx_submit_batch", "orbx_submit_batch_into", "orbx_collect", "orbx_host_alloc", "orbx_collect_view", "orbx_release", "orbx_collect_batch", "orbx_extract_match_batch",
     "orbx_host_alloc_frames", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_device_results", "orbx_download",

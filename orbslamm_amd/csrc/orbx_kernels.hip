@@ -1926,6 +1926,16 @@ __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ src, u
     if (i < n16) ((u32x4*)dst)[i] = __builtin_nontemporal_load((const u32x4*)src + i);
 }
 
+// the same for frames that do NOT lie back to back (the cameras of several robots in one call: a ring buffer each):
+// blockIdx.y = frame, one source pointer per frame
+struct UploadSrcs { const uint4* src[8]; };
+__global__ __launch_bounds__(256) void k_upload_frames(UploadSrcs s, uint4* __restrict__ dst, int n16)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i < n16) ((u32x4*)dst)[(size_t)f * n16 + i] = __builtin_nontemporal_load((const u32x4*)s.src[f] + i);
+}
+
 // raised behind a copy kernel that wrote a caller's results into pinned host memory: the host polls it instead of waiting
 // for the stream
 __global__ void k_raise_flag(int32_t* flag, int32_t value)

@@ -101,3 +101,47 @@ def test_what_the_native_loop_got_back_is_what_the_oracle_computes(gpu, oracle, 
             checked += 1
         prev = ref
     assert checked == 7
+
+
+def test_robots_behind_a_hub_get_what_a_handle_each_gives_them(gpu):
+    """--hub P: still one thread per robot and one blocking call per frame, but the frames of the robots waiting together go
+    through ONE chain (include/orbslamm_hub.hpp, orbx_create_live).  Every robot's stream of results -- keypoint counts,
+    descriptor words, match-table entries: the per-robot checksum -- is the one it gets from a handle of its own, whatever the
+    size of the groups and however long a leader waits for the others."""
+    alone = _run("--mode", "track", "--robots", 6, "--w", 640, "--h", 480, "--nfeat", 1000)
+    for hub, wait in ((2, 2000), (4, 2000), (8, 2000), (3, 0), (8, 40)):
+        r = _run("--mode", "track", "--robots", 6, "--hub", hub, "--hub-wait", wait, "--w", 640, "--h", 480, "--nfeat", 1000)
+        assert r["gathered_frames"] == 240 and r["hub"] == hub
+        assert r["checksum"] == alone["checksum"], (hub, wait)
+        assert r["matches_mean"] == alone["matches_mean"] and r["keypoints_mean"] == alone["keypoints_mean"]
+        if wait >= 2000:
+            groups = [min(hub, 6 - g0) for g0 in range(0, 6, hub)]   # six robots dealt to hubs of `hub`
+            assert r["hub_batch_mean"] > 0.9 * sum(g * g for g in groups) / 6   # lockstep: the groups stay together
+
+
+def test_a_hub_camera_replayed_through_the_oracle(gpu, oracle, tmp_path):
+    """camera 0 of a hub of four: eight consecutive frames with what track() handed back for them, byte for byte against the
+    CPU oracle (extraction, then SearchByProjection(Cur, Last) against the previous frame of the SAME camera)"""
+    import numpy as np
+    path = str(tmp_path / "dump.bin")
+    _run("--mode", "track", "--robots", 4, "--hub", 4, "--hub-wait", 2000, "--w", 640, "--h", 480, "--nfeat", 1000, "--dump", path)
+    recs = _read_dump(path, "track")
+    assert len(recs) == 8
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    sf = np.array(oex.scale_factors(), np.float32)
+    gp = oracle.make_grid_params(0.0, 0.0, 640.0, 480.0)
+    prev, checked = None, 0
+    for r in recs:
+        ref = oex(np.ascontiguousarray(r["frame"]))
+        assert ref["kps"].tobytes() == r["kps"].tobytes() and ref["desc"].tobytes() == r["desc"].tobytes()
+        if prev is not None:
+            kl, kc = prev["kps"], ref["kps"]
+            uvr = np.stack([kl["x"], kl["y"], (np.float32(15.0) * sf[kl["octave"]]).astype(np.float32)], axis=1).astype(np.float32)
+            lvl = np.stack([kl["octave"] - 1, kl["octave"] + 1], axis=1).astype(np.int8)
+            start, idx = oracle.grid_build(gp, kc)
+            wa, _, wn = oracle.search_by_projection(4, 0.9, True, 100, uvr, lvl, prev["desc"], kl["angle"], None, None, gp, kc, start, idx, ref["desc"],
+                                                    np.zeros(len(kc), np.uint8), np.full(len(kc), -1, np.int32))
+            assert r["count"] == wn and np.array_equal(r["table"], wa)
+            checked += 1
+        prev = ref
+    assert checked == 7
