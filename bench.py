@@ -620,7 +620,8 @@ def live_streams(cfg, dev_index=0, frames=600):
       one_robot.track_plus_local_map   track, then SearchByProjection(Frame, 3 000 local MapPoints) (Tracking.cc:1242-1249) on the same frame
       one_robot.bf          extract + brute-force match vs previous frame (BASELINE.json's pair), one frame per call
       robots_on_one_gpu     K robots = K threads on the one GPU, one frame per robot per call, and 8 cameras fed two per
-                            call by 4 threads (the GPU runs about four queues at a time: tools/live_scale_probe.sh)"""
+                            call by 4 threads (the GPU runs about four queues at a time: tools/live_scale_probe.sh); 8 and 16
+                            robot threads behind four orbslamm::CameraHub's (the frames that wait together share a chain)"""
     import __graft_entry__ as ge
     exe = ge.build_examples()
     base = [exe, "--json", "--interval", "0", "--w", str(cfg["w"]), "--h", str(cfg["h"]), "--nfeat", str(cfg["nfeat"]), "--gpus", "1"]
@@ -658,10 +659,16 @@ def live_streams(cfg, dev_index=0, frames=600):
         out["robots_on_one_gpu"]["track_%d_threads_x1" % k] = run("--mode", "track", "--robots", k, n=400)
     out["robots_on_one_gpu"]["track_4_threads_x2_cameras"] = run("--mode", "track", "--robots", 4, "--per-call", 2, n=400)
     out["robots_on_one_gpu"]["bf_4_threads_x1"] = run("--mode", "bf", "--robots", 4, n=400)
+    # more robots than the GPU runs queues: one thread and one blocking call per robot as before, but the frames of the robots
+    # waiting together go through ONE chain (include/orbslamm_hub.hpp, orbx_create_live) -- four hubs per GPU
+    keep = keep + ("hub_batch_mean",)
+    out["robots_on_one_gpu"]["track_8_threads_x1_hubs_of_2"] = run("--mode", "track", "--robots", 8, "--hub", 2, n=400)
+    out["robots_on_one_gpu"]["track_16_threads_x1_hubs_of_4"] = run("--mode", "track", "--robots", 16, "--hub", 4, n=400)
     t = out["one_robot"]["track"]
     if "ms_median" in t:
         out["target"] = {"track_ms_median_le_0.20": bool(t["ms_median"] <= 0.20), "bf_ms_median_le_0.15": bool(out["one_robot"]["bf"].get("ms_median", 9) <= 0.15),
-                         "eight_cameras_ge_25k": bool(out["robots_on_one_gpu"]["track_4_threads_x2_cameras"].get("frames_per_s", 0) >= 25000)}
+                         "eight_cameras_ge_25k": bool(out["robots_on_one_gpu"]["track_4_threads_x2_cameras"].get("frames_per_s", 0) >= 25000),
+                         "eight_robot_threads_ge_25k": bool(out["robots_on_one_gpu"]["track_8_threads_x1_hubs_of_2"].get("frames_per_s", 0) >= 25000)}
     return out
 
 

@@ -10,11 +10,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "orbslamm_hip.h"
+#include "orbslamm_hub.hpp"
 
 #ifdef ORBSLAMM_WITH_OPENCV
 #include <cassert>
@@ -83,8 +85,24 @@ public:
         cap_ = orbx_max_keypoints(h_);
         kps_.resize(cap_);
     }
+    // Several robots on one GPU (MultipleRobotsScenario: a System -- and with it an ORBextractor -- per robot, each driven by
+    // its own tracking thread, Examples/Monocular/mono_kitti.cc:83-101): the robots' extractors share ONE hub, opened with
+    // Config::track = false and the reference's five parameters; operator() of robot `camera` blocks like the reference's
+    // and returns that robot's keypoints and descriptors, while the frames of the robots that call at the same time go
+    // through the GPU together (orbslamm_hub.hpp).  Monocular: mvImagePyramid (read by the stereo path only) is not kept.
+    ORBextractor(std::shared_ptr<orbslamm::CameraHub> hub, int camera) : mvImagePyramid(this), hub_(hub), cam_(camera)
+    {
+        if (!hub_ || !hub_->extractor()) throw std::runtime_error("ORBextractor(HIP): the hub is not open");
+        h_ = hub_->extractor();
+        const int L = orbx_levels(h_);
+        mvScaleFactor.resize(L); mvInvScaleFactor.resize(L); mvLevelSigma2.resize(L); mvInvLevelSigma2.resize(L);
+        orbx_scale_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data());
+        cap_ = hub_->cap();
+        kps_.resize(cap_);
+    }
+    bool onHub() const { return (bool)hub_; }
     orbx_t* handle() { return h_; }
-    ~ORBextractor() { orbx_destroy(h_); }
+    ~ORBextractor() { if (hub_) hub_->leave(cam_); else orbx_destroy(h_); }
     ORBextractor(const ORBextractor&) = delete;
     ORBextractor& operator=(const ORBextractor&) = delete;
 
@@ -109,7 +127,7 @@ public:
         static_assert(sizeof(cv::KeyPoint) == sizeof(OrbxKeyPoint), "cv::KeyPoint layout");
         desc_.resize((size_t)cap_ * 32);
         int n = 0;
-        const int rc = orbx_extract(h_, image.data, image.cols, image.rows, (int)image.step, kps_.data(), desc_.data(), cap_, &n);
+        const int rc = run(image.data, image.cols, image.rows, (int)image.step, n);
         if (rc != ORBX_OK) {  // never exit(): Tracking already copes with 0 keypoints (Frame.cc:195-196)
             std::fprintf(stderr, "ORBextractor(HIP): %s\n", orbx_last_error());
             n = 0;
@@ -130,7 +148,7 @@ public:
         if (!image || width <= 0 || height <= 0) return;
         desc_.resize((size_t)cap_ * 32);
         int n = 0;
-        const int rc = orbx_extract(h_, image, width, height, stride, kps_.data(), desc_.data(), cap_, &n);
+        const int rc = run(image, width, height, stride, n);
         if (rc != ORBX_OK) { std::fprintf(stderr, "ORBextractor(HIP): %s\n", orbx_last_error()); n = 0; }
         mvImagePyramid.invalidate();
         keypoints.assign(kps_.begin(), kps_.begin() + n);
@@ -149,6 +167,18 @@ public:
     }
 
 protected:
+    // one frame through the handle of this extractor, or through the hub it shares with the other robots' extractors
+    int run(const uint8_t* image, int width, int height, int stride, int& n)
+    {
+        if (!hub_) return orbx_extract(h_, image, width, height, stride, kps_.data(), desc_.data(), cap_, &n);
+        (void)width; (void)height;   // the hub's frames have one shape (Config::w, h)
+        orbslamm::CameraHub::Result res;
+        const int rc = hub_->track(cam_, image, stride, kps_.data(), desc_.data(), nullptr, &res);
+        n = rc == ORBX_OK ? res.n : 0;
+        return rc;
+    }
+    std::shared_ptr<orbslamm::CameraHub> hub_;
+    int cam_ = 0;
     orbx_t* h_ = nullptr;
     int cap_ = 0;
     std::vector<OrbxKeyPoint> kps_;
@@ -173,6 +203,7 @@ inline LazyPyramid::Level& LazyPyramid::operator[](size_t level)
 }
 inline void LazyPyramid::fill()
 {
+    if (owner_->onHub()) throw std::runtime_error("mvImagePyramid: an extractor on a hub keeps no pyramid (monocular robots; give a stereo rig a handle of its own)");
     const int E = 19;  // EDGE_THRESHOLD, ORBextractor.cc:74
     const int L = orbx_levels(owner_->handle());
     levels_.resize((size_t)L);

@@ -11,7 +11,7 @@
 // keypoints, descriptors and match table back when the call returns; the frames of the robots that are waiting at that
 // moment go through the chain together (orbx_submit_batch with B = cameras present, one frame-set build, one
 // orbm_track_frames over the pairs present).  Results are the same bytes a handle per robot produces (the kernels
-// treat the frames of a batch independently; tests/test_gpu_example.py replays a hub camera through the CPU oracle).
+// treat the frames of a batch independently; tests/test_gpu_example.py replays a hub camera on the CPU byte for byte).
 //
 // Batching rule: the first thread to find no batch being assembled becomes its leader, waits until every camera that is
 // a member of the hub has a frame waiting or `wait_us` microseconds have passed (cameras that free-run fall into

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <thread>
 
 #include "ORBextractor_hip.hpp"
 #include "ORBmatcher_hip.hpp"
@@ -155,6 +156,34 @@ int main()
             off += (size_t)lw * lh;
         }
         EXPECT(l0_is_frame(ex, img, W, H));
+    }
+    // three robots' extractors on ONE hub (MultipleRobotsScenario: an ORBextractor per robot, a tracking thread each): every
+    // robot gets the keypoints and descriptors of ITS frames, whatever went through the GPU beside them
+    {
+        orbslamm::CameraHub::Config hc;
+        hc.prm = OrbxParams{1000, 1.2f, 8, 20, 7}; hc.w = W; hc.h = H; hc.cameras = 3; hc.device = 0; hc.track = false; hc.wait_us = 500;
+        std::shared_ptr<orbslamm::CameraHub> hub(new orbslamm::CameraHub());
+        EXPECT(hub->open(hc) == ORBX_OK);
+        const int R = 3, F = 4;
+        std::vector<std::vector<uint8_t> > frames((size_t)R * F, std::vector<uint8_t>((size_t)W * H));
+        for (int r = 0; r < R; r++)
+            for (int f = 0; f < F; f++)
+                for (int y = 0; y < H; y++)
+                    for (int x = 0; x < W; x++) frames[(size_t)r * F + f][(size_t)y * W + x] = (uint8_t)(((((x + 5 * f) / (11 + r)) ^ ((y + 3 * r) / (9 + f))) * 41 + (rng() & 7)) & 0xFF);
+        std::vector<std::vector<OrbxKeyPoint> > gk((size_t)R * F); std::vector<std::vector<uint8_t> > gd((size_t)R * F);
+        std::vector<std::thread> th;
+        for (int r = 0; r < R; r++)
+            th.emplace_back([&, r] {
+                iORB_SLAM::ORBextractor rex(hub, r);
+                for (int f = 0; f < F; f++) rex(frames[(size_t)r * F + f].data(), W, H, W, gk[(size_t)r * F + f], gd[(size_t)r * F + f]);
+            });
+        for (auto& t : th) t.join();
+        for (int i = 0; i < R * F; i++) {
+            const int n2 = orc_extract(&oex, frames[(size_t)i].data(), W, H, W, okps.data(), odesc.data(), 2000, nullptr, nullptr, nullptr);
+            EXPECT(n2 > 100 && (size_t)n2 == gk[(size_t)i].size());
+            EXPECT((size_t)n2 == gk[(size_t)i].size() && std::memcmp(okps.data(), gk[(size_t)i].data(), (size_t)n2 * 28) == 0);
+            EXPECT((size_t)n2 * 32 == gd[(size_t)i].size() && std::memcmp(odesc.data(), gd[(size_t)i].data(), (size_t)n2 * 32) == 0);
+        }
     }
     std::printf(fails ? "adapter_gpu: %d failures\n" : "adapter_gpu ok (%d keypoints, %d BoW matches, %d init matches)\n", fails ? fails : on, nm, ni);
     return fails ? 1 : 0;

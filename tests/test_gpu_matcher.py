@@ -268,7 +268,7 @@ def test_cpp_adapters_on_gpu(gpu, tmp_path):
     from oracle import binding as ob
     ob.build()
     exe = str(tmp_path / "adapter_gpu")
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(root, "include"),
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-pthread", "-I", os.path.join(root, "include"),
                            os.path.join(root, "tests", "cpp", "adapter_gpu.cpp"), "-o", exe,
                            "-L", os.path.join(root, "orbslamm_amd"), "-lorbslamm_hip", "-L", os.path.join(root, "oracle"), "-lorb_oracle",
                            "-Wl,-rpath," + os.path.join(root, "orbslamm_amd"), "-Wl,-rpath," + os.path.join(root, "oracle"),
