@@ -112,7 +112,7 @@ __device__ __forceinline__ void undistort_point(const UndistArgs& a, float& px, 
 // LDS: 2 * ncell ints (counts -> starts, fill cursors) + cap uint16 (the cell lists, sorted in place before they go out)
 // + cap x {x, y, octave} (12 bytes): every later phase reads the keys from LDS, not back from memory -- the kernel is a
 // chain of short phases and a memory round trip per phase was most of its 31 us.
-__global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
+__device__ __forceinline__ void frame_build_body(const FrameBuildArgs& a, const int src)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t gl[];
     __shared__ int wsum[kWaves];
@@ -127,7 +127,6 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
     int32_t* ko = (int32_t*)(ky + capE);
     uint16_t* lst = (uint16_t*)(ko + capE);
     const int tid = threadIdx.x;
-    const int src = blockIdx.x;
     const int slot = (a.slot0 + src) % a.slotMod;
     const int n = min(a.srcCount ? a.srcCount[src] : a.srcN, a.fs.cap);
     const KeyDev* __restrict__ sk = a.srcKeys + (int64_t)src * a.srcCap;
@@ -245,6 +244,23 @@ __global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
         rec[j] = make_uint4(__float_as_uint(kx[i]), __float_as_uint(ky[i]), (uint32_t)i | ((uint32_t)ko[i] << 24), 0u);
     }
     ORBT_BMARK(8);
+}
+
+__global__ __launch_bounds__(kThreads) void k_frame_build(FrameBuildArgs a)
+{
+    frame_build_body(a, blockIdx.x);
+}
+
+// The live chain (a frame set attached to the extractor): the frames' results go to the host from the SAME launch that
+// builds their Frame tail -- workgroups [0, nframes) build, the kPackParts per frame behind them write keypoints and
+// descriptors into the ticket's pinned block and raise its flag (orbx::pack_host_part).  Both only read the extractor's
+// result set; as two launches the copy (6 us per frame over the link, a few waves) ran in front of the build (10 us).
+constexpr int kPackParts = 4;   // x 1024 threads = the sixteen 256-thread workgroups of k_pack_host
+__global__ __launch_bounds__(kThreads) void k_frame_build_pack(FrameBuildArgs a, orbx::PackArgs pa, int nframes)
+{
+    if ((int)blockIdx.x < nframes) { frame_build_body(a, blockIdx.x); return; }
+    const int q = blockIdx.x - nframes;
+    orbx::pack_host_part(pa, q / kPackParts, q % kPackParts, kPackParts, nframes * kPackParts);
 }
 
 // ------------------------------------------------------------------ SearchByProjection, batched: candidates + resolve

@@ -1971,12 +1971,12 @@ struct PackArgs {
     int maxKp;       // pitch (records per frame) of the device arrays
     int hostPitch;   // and of the host arrays: the slot's own block (= maxKp) or the caller's (orbx_submit_batch_into)
 };
-__global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
+// frame f's part `part` of `nparts` (each a workgroup of blockDim.x threads); `total` workgroups take part in all
+__device__ __forceinline__ void pack_host_part(const PackArgs& a, int f, int part, int nparts, int total)
 {
-    const int f = blockIdx.y;
     const int nAll = a.count[f];
     const int n = min(nAll, a.hostPitch);   // never past the caller's row; hN carries the true count
-    const int t = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+    const int t = part * blockDim.x + threadIdx.x, step = nparts * blockDim.x;
     const int64_t o = (int64_t)f * a.maxKp, oh = (int64_t)f * a.hostPitch;
     // 16 bytes per lane where the frame's slot is 16-byte aligned (maxKp a multiple of 4): a wave instruction then writes
     // a contiguous KiB towards the host
@@ -1995,7 +1995,7 @@ __global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
     if (t == 0) {
         a.hN[f] = nAll;
         if (a.nmatch) a.hNmatch[f] = a.nmatch[f];
-        if (f == 0 && blockIdx.x == 0) *a.hErr = atomicExch(a.err, 0);  // the batch's own word: handed over and cleared
+        if (f == 0 && part == 0) *a.hErr = atomicExch(a.err, 0);  // the batch's own word: handed over and cleared
     }
     // Without a flag the consumer waits for the kernel's completion event, and the end of the kernel publishes: no
     // system-scope fence, no arrival count.
@@ -2004,13 +2004,16 @@ __global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int total = gridDim.x * gridDim.y;
         if (atomicAdd(a.blocksDone, 1) == total - 1) {
             *a.blocksDone = 0;
             __threadfence_system();
             __hip_atomic_store(a.hFlag, a.flagValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+__global__ __launch_bounds__(256) void k_pack_host(PackArgs a)
+{
+    pack_host_part(a, blockIdx.y, blockIdx.x, gridDim.x, gridDim.x * gridDim.y);
 }
 
 // ------------------------------------------------------------------ Frame::ComputeStereoMatches (Frame.cc:466-638)
