@@ -13,14 +13,15 @@ class ORBextractor:
     HARRIS_SCORE, FAST_SCORE = 0, 1  # ORBextractor.h:49 (unused enum in the reference too)
 
     def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
-                 max_width=1280, max_height=720, max_batch=1, device=0):
+                 max_width=1280, max_height=720, max_batch=1, device=0, live=False):
         """ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
-        -- src/ORBextractor.cc:410.  device=-1 gives a host-only handle (tables only)."""
+        -- src/ORBextractor.cc:410.  device=-1 gives a host-only handle (tables only).  live=True: orbx_create_live -- every
+        call of 1..max_batch (<= 8) frames runs as one latency-mode chain (the handle a camera hub creates)."""
         self._L = lib()
         self._h = C.c_void_p()
         prm = OrbxParams(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST))
-        check(self._L.orbx_create(C.byref(prm), int(max_width), int(max_height), int(max_batch), int(device),
-                                  C.byref(self._h)))
+        create = self._L.orbx_create_live if live else self._L.orbx_create
+        check(create(C.byref(prm), int(max_width), int(max_height), int(max_batch), int(device), C.byref(self._h)))
         self.nfeatures, self.nlevels, self.max_batch, self.device = nfeatures, nlevels, max_batch, device
         self._cap = self._L.orbx_max_keypoints(self._h)
         self._last_shape = None
@@ -159,7 +160,7 @@ class ORBextractor:
     def collect_host(self, ticket, view=True):
         """view=True: orbx_collect_view + copies of the per-frame counts only + orbx_release -- what a consumer that reads
         the pinned results in place costs; view=False: orbx_collect_batch into fresh arrays."""
-        self._inflight.pop(ticket, None)
+        getattr(self, "_inflight", {}).pop(ticket, None)
         if view:
             v = _lib.OrbxBatchView()
             check(self._L.orbx_collect_view(self._h, int(ticket), C.byref(v)))

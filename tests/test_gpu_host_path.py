@@ -220,3 +220,47 @@ def test_results_straight_into_caller_arrays(gpu, oracle):
     with pytest.raises(OrbError):
         ex2.collect_into(t)
     ex2.collect_host(t)
+
+
+@pytest.mark.parametrize("kind", ["pageable", "pinned_rings"])
+def test_live_handle_chains_of_up_to_eight_frames(gpu, oracle, kind):
+    """orbx_create_live: calls of 1..8 frames all run as ONE latency-mode chain (what orbslamm::CameraHub submits for the
+    robots that wait together).  Batches of 5, 8, 1, 3, 8 frames of one stream with the brute-force match against the
+    previous frame (a batch's frames are consecutive frames of the stream), pageable frames and pinned frames that do NOT
+    lie back to back (a ring buffer per camera: k_upload_frames) -- every frame and match table equals the oracle's."""
+    from orbslamm_amd import ORBextractor
+    w, h, nf = 640, 480, 1000
+    sizes = [5, 8, 1, 3, 8]
+    fr = frames_for(w, h, sum(sizes), stream=9)
+    ref = _oracle_stream(oracle, fr, nf)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=8, device=0, live=True)
+    with pytest.raises(Exception):
+        ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=9, device=0, live=True)
+    L = ex._L
+    pins = []
+    if kind == "pinned_rings":
+        # every frame in a pinned block of its own, in the device layout (stride = width rounded up to 64)
+        stride = (w + 63) // 64 * 64
+        for f in fr:
+            p = C.c_void_p()
+            assert L.orbx_host_alloc(ex._h, C.c_size_t(stride * h), C.byref(p)) == 0
+            buf = np.frombuffer((C.c_uint8 * (stride * h)).from_address(p.value), dtype=np.uint8).reshape(h, stride)
+            buf[:, :w] = f
+            pins.append(p)
+    t0 = 0
+    for B in sizes:
+        tk = C.c_int(-1)
+        opts = ex._opts(True, 0.7, 50, True)
+        if kind == "pinned_rings":
+            arr = (C.c_void_p * B)(*[pins[t0 + i].value for i in range(B)])
+            stride = (w + 63) // 64 * 64
+        else:
+            arr = (C.c_void_p * B)(*[fr[t0 + i].ctypes.data for i in range(B)])
+            stride = w
+        assert L.orbx_submit_batch(ex._h, arr, B, w, h, stride, C.byref(opts), C.byref(tk)) == 0, L.orbx_last_error()
+        kps, desc, n, m, nm = ex.collect_host(tk.value, view=False)
+        for i in range(B):
+            _check(ref[t0 + i], kps[i], desc[i], int(n[i]), m[i], int(nm[i]))
+        t0 += B
+    for p in pins:
+        L.orbx_host_free(ex._h, p)
