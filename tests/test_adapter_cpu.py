@@ -75,3 +75,16 @@ def test_check_vs_opencv_compiles(tmp_path):
     assert len(names) == 19 and all(n.endswith(".pgm") for n in names)
     head = open(tmp_path / "frames" / "synth_1241x376_0.pgm", "rb").read(16)
     assert head.startswith(b"P5\n1241 376\n255\n")
+
+
+def test_camera_hub_host_logic_under_thread_sanitizer(tmp_path):
+    """include/orbslamm_hub.hpp (the robots' threads sharing one chain) against a mock of the C ABI entries it calls, built with
+    -fsanitize=thread: one thread at a time inside the library, every ticket released once and only after its readers copied,
+    orbm_track_frames pairs = (frame s, frame s - 1) of the same camera in the slot ring, every thread gets ITS rows --
+    lockstep (long wait), no wait, one slow camera, extraction only (tests/cpp/hub_mock_cpu.cpp)"""
+    exe = str(tmp_path / "hub_mock")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "hub_mock_cpu.cpp"), "-o", exe])
+    out = subprocess.run([exe, "400"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "hub_mock ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-4000:]
