@@ -131,9 +131,19 @@ struct Robot {
         }
         std::vector<OrbxKeyPoint> kps((size_t)cap);
         std::vector<uint8_t> desc((size_t)cap * 32);
-        std::vector<int32_t> assign((size_t)cap);
+        std::vector<int32_t> assign((size_t)cap), assign3((size_t)cap);
         const int total = A.warmup + A.frames;
         lat_ms.reserve(A.frames);
+        // --mode full: the local map of ring position r = the keypoints of the two frames before it as projected MapPoints
+        // (the same construction as in run() below), built once per ring position during the warm-up
+        const bool full = A.mode == "full";
+        struct LocalMap { std::vector<float> uvr; std::vector<int8_t> lvl; std::vector<uint8_t> desc; int n = 0; };
+        std::vector<LocalMap> lmap(full ? nring : 0);
+        std::vector<std::vector<OrbxKeyPoint>> rkps(full ? nring : 0);
+        std::vector<std::vector<uint8_t>> rdesc(full ? nring : 0);
+        float sfl[ORBX_MAX_LEVELS] = {0};
+        if (full) OX(orbx_scale_tables(hub->extractor(), sfl, nullptr, nullptr, nullptr));
+        OrbmProjParams pp3{3, 0.8f, 0, 100};
         ready.fetch_add(1);
         while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
         using clk = std::chrono::steady_clock;
@@ -145,11 +155,38 @@ struct Robot {
             const auto t0 = clk::now();
             orbslamm::CameraHub::Result res;
             OX(hub->track(cam, fr0, stride, kps.data(), desc.data(), assign.data(), &res));
-            const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
             const int n = res.n;
+            int nm3 = 0;
+            if (full) {
+                const int r = i % nring;
+                if (rkps[r].empty() && n > 0) {   // (warm-up, first pass over the ring)
+                    rkps[r].assign(kps.begin(), kps.begin() + n);
+                    rdesc[r].assign(desc.begin(), desc.begin() + (size_t)n * 32);
+                    for (int rr = 0; rr < nring; rr++) {
+                        const int p1 = (rr + nring - 1) % nring, p2 = (rr + nring - 2) % nring;
+                        if (lmap[rr].n || rkps[p1].empty() || rkps[p2].empty()) continue;
+                        LocalMap& lm = lmap[rr];
+                        for (int src = 0; src < 2 && lm.n < 3000; src++) {
+                            const auto& K = rkps[src ? p2 : p1]; const auto& D = rdesc[src ? p2 : p1];
+                            for (size_t k = 0; k < K.size() && lm.n < 3000; k++, lm.n++) {
+                                const int lv = K[k].octave;
+                                lm.uvr.push_back(K[k].x); lm.uvr.push_back(K[k].y); lm.uvr.push_back(4.0f * sfl[lv]);
+                                lm.lvl.push_back((int8_t)(lv - 1)); lm.lvl.push_back((int8_t)lv);
+                                lm.desc.insert(lm.desc.end(), D.begin() + k * 32, D.begin() + (k + 1) * 32);
+                            }
+                        }
+                    }
+                }
+                LocalMap& lm = lmap[r];
+                if (lm.n > 0) {   // Tracking::SearchLocalPoints (Tracking.cc:1242-1249) against the frame just sent, resident in the hub's set
+                    OX(hub->search_local_points(cam, &pp3, lm.uvr.data(), lm.lvl.data(), lm.desc.data(), nullptr, nullptr, lm.n, nullptr, assign3.data(), &nm3));
+                }
+            }
+            const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
             uint64_t cs = (uint64_t)n * 1315423911ull;   // the same per-frame word the loop below forms for one camera per call
             if (n > 0) { uint32_t d0; memcpy(&d0, desc.data() + (size_t)(n - 1) * 32, 4); cs ^= d0; }
             if (res.nmatches >= 0 && n > 0) cs ^= (uint64_t)(uint32_t)assign[n - 1] << 32;
+            if (full && lmap[i % nring].n > 0) cs ^= (uint64_t)(uint32_t)nm3 * 2654435761ull;
             if (robot == 0 && !A.dump.empty() && i >= A.warmup && i < A.warmup + 8) {
                 FILE* df = fopen(A.dump.c_str(), i == A.warmup ? "wb" : "ab");
                 if (df) {
@@ -164,7 +201,7 @@ struct Robot {
             }
             if (i >= A.warmup) {
                 lat_ms.push_back(ms);
-                const int nm = std::max(0, res.nmatches);
+                const int nm = std::max(0, res.nmatches) + nm3;
                 st.frames += 1; st.keypoints += n; st.matches += nm; st.checksum = st.checksum * 1099511628211ull ^ cs;
                 batchSum += res.batch;
                 live_frames.fetch_add(1, std::memory_order_relaxed); live_kps.fetch_add(n, std::memory_order_relaxed); live_matches.fetch_add(nm, std::memory_order_relaxed);
@@ -387,7 +424,7 @@ int main(int argc, char** argv)
             hipMalloc(&d_send[d], sizeof(Stats)) != hipSuccess || hipMalloc(&d_recv[d], sizeof(Stats) * A.gpus) != hipSuccess) { fprintf(stderr, "hip setup failed\n"); return 4; }
     }
 
-    if (A.hub < 0 || A.hub > orbslamm::CameraHub::kMaxCameras || (A.hub > 0 && (A.mode != "track" || A.per_call != 1 || A.depth != 1))) { fprintf(stderr, "--hub 1..8: mode track, one camera per robot, one ticket deep\n"); return 2; }
+    if (A.hub < 0 || A.hub > orbslamm::CameraHub::kMaxCameras || (A.hub > 0 && ((A.mode != "track" && A.mode != "full") || A.per_call != 1 || A.depth != 1))) { fprintf(stderr, "--hub 1..8: mode track or full, one camera per robot, one ticket deep\n"); return 2; }
     // --hub P: on every GPU the robots are dealt to hubs of P cameras in the order they come
     std::vector<std::unique_ptr<orbslamm::CameraHub>> hubs;
     std::vector<Robot> robots(A.robots);

@@ -75,7 +75,7 @@ public:
             if ((rc = orbm_frameset_attach(fs_, ex_))) { close(); return rc; }
         }
         for (int s = 0; s < 4 * kMaxCameras; s++) slotCam_[s] = -1;
-        for (int j = 0; j < kMaxCameras; j++) { lastSlot_[j] = -1; seq_[j] = 0; req_[j].state.store(0); }
+        for (int j = 0; j < kMaxCameras; j++) { lastSlot_[j] = -1; seq_[j] = 0; lastN_[j] = 0; req_[j].state.store(0); }
         return ORBX_OK;
     }
 
@@ -131,6 +131,33 @@ public:
         return rc;
     }
 
+    // Tracking::SearchLocalPoints' search (Tracking.cc:1242-1249 -> ORBmatcher::SearchByProjection(Frame, local MapPoints, th),
+    // ORBmatcher.cc:45-129) against the frame camera `cam` sent LAST, still resident in the hub's frame set -- the arguments
+    // of orbm_track_local_points; assign[cap()] receives, per feature of that frame, the index of the MapPoint it took or -1.
+    // The searches of a hub run one after the other between two batches; ORBX_E_INVALID if the frame has left the set.
+    int search_local_points(int cam, const OrbmProjParams* pp, const float* q_uvr, const int8_t* q_lvl, const uint8_t* qdesc,
+                            const uint8_t* qvalid, const uint8_t* q_obs_pos, int nq, const uint8_t* t_occ, int32_t* assign, int* nmatches)
+    {
+        if (!fs_ || cam < 0 || cam >= cfg_.cameras || !pp || !assign) return ORBX_E_INVALID;
+        LocalRequest& q = lreq_[cam];
+        q.pp = pp; q.uvr = q_uvr; q.lvl = q_lvl; q.desc = qdesc; q.valid = qvalid; q.obs = q_obs_pos; q.nq = nq; q.occ = t_occ; q.assign = assign;
+        q.state.store(1, std::memory_order_relaxed);
+        lwaiting_.fetch_or(1u << cam, std::memory_order_release);
+        // whoever holds the leader's flag serves it -- a leader waiting for the other cameras' frames does (this camera's next
+        // frame will not come before its search has returned), else this thread takes the flag for the search alone
+        while (q.state.load(std::memory_order_acquire) < 2) {
+            if (!leader_.exchange(true, std::memory_order_acquire)) {
+                serve_local_searches();
+                leader_.store(false, std::memory_order_release);
+                continue;
+            }
+            std::this_thread::yield();
+        }
+        q.state.store(0, std::memory_order_relaxed);
+        if (nmatches) *nmatches = q.nmatches;
+        return q.rc;
+    }
+
 private:
     struct Request {
         std::atomic<int> state{0};   // 0 idle, 1 waiting for a batch, 2 served (view published)
@@ -138,6 +165,36 @@ private:
         const OrbxKeyPoint* kps = nullptr; const uint8_t* desc = nullptr; const int32_t* assign = nullptr;
         int n = 0, nmatches = -1, batch = 0, rc = 0;
     };
+
+    struct LocalRequest {
+        std::atomic<int> state{0};   // 0 idle, 1 waiting, 2 served
+        const OrbmProjParams* pp = nullptr; const float* uvr = nullptr; const int8_t* lvl = nullptr; const uint8_t* desc = nullptr;
+        const uint8_t *valid = nullptr, *obs = nullptr, *occ = nullptr; int nq = 0; int32_t* assign = nullptr;
+        int nmatches = 0, rc = 0;
+    };
+
+    // (leader only) the local-map searches that wait, one after the other on the chain; the tables go straight into the
+    // waiting callers' arrays
+    void serve_local_searches()
+    {
+        const uint32_t take = lwaiting_.exchange(0, std::memory_order_acquire);
+        if (!take) return;
+        // the previous batch's threads copy their match tables out of a result set that four searches from now is recycled
+        while (readers_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        for (int cam = 0; cam < cfg_.cameras; cam++) {
+            if (!(take >> cam & 1)) continue;
+            LocalRequest& q = lreq_[cam];
+            const int slot = lastSlot_[cam];
+            int rc = slot >= 0 && slotCam_[slot] == cam && slotSeq_[slot] == seq_[cam] - 1 ? ORBX_OK : ORBX_E_INVALID;
+            const int32_t *a = nullptr, *nm = nullptr;
+            int np = 0, c2 = 0;
+            if (!rc) rc = orbm_track_local_points(fs_, slot, q.pp, q.uvr, q.lvl, q.desc, q.valid, q.obs, q.nq, q.occ);
+            if (!rc) rc = orbm_track_results(fs_, 0, &a, &nm, &np, &c2);
+            if (!rc) { std::memcpy(q.assign, a, (size_t)lastN_[cam] * 4); q.nmatches = nm[0]; }
+            q.rc = rc;
+            q.state.store(2, std::memory_order_release);
+        }
+    }
 
     void lead()
     {
@@ -148,8 +205,10 @@ private:
             const uint32_t w = waiting_.load(std::memory_order_acquire), mset = members_.load(std::memory_order_relaxed);
             if ((w & mset) == mset) break;
             if (std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count() >= cfg_.wait_us) break;
+            serve_local_searches();
             std::this_thread::yield();
         }
+        serve_local_searches();
         release_pending();   // the previous batch's readers had the wait above to copy their parts
         const uint32_t take = waiting_.exchange(0, std::memory_order_acquire);
         int cams[kMaxCameras], B = 0;
@@ -189,7 +248,7 @@ private:
             Request& r = req_[cams[p]];
             r.rc = rc; r.batch = B;
             if (!rc) {
-                r.n = v.n[p]; r.kps = v.kps + (size_t)p * v.cap; r.desc = v.desc + (size_t)p * v.cap * 32;
+                r.n = v.n[p]; lastN_[cams[p]] = v.n[p]; r.kps = v.kps + (size_t)p * v.cap; r.desc = v.desc + (size_t)p * v.cap * 32;
                 const int q = fs_ ? pairOf[p] : -1;
                 r.assign = q >= 0 ? assign + (size_t)q * c2 : nullptr;
                 r.nmatches = q >= 0 ? nmp[q] : -1;
@@ -212,9 +271,10 @@ private:
     orbx_t* ex_ = nullptr; orbm_t* m_ = nullptr; orbm_frameset_t* fs_ = nullptr;
     int cap_ = 0, nslots_ = 0, cursor_ = 0;
     int slotCam_[4 * kMaxCameras]; int64_t slotSeq_[4 * kMaxCameras];
-    int lastSlot_[kMaxCameras]; int64_t seq_[kMaxCameras];
+    int lastSlot_[kMaxCameras]; int64_t seq_[kMaxCameras]; int lastN_[kMaxCameras];
     Request req_[kMaxCameras];
-    std::atomic<uint32_t> members_{0}, waiting_{0};
+    LocalRequest lreq_[kMaxCameras];
+    std::atomic<uint32_t> members_{0}, waiting_{0}, lwaiting_{0};
     std::atomic<bool> leader_{false};
     std::atomic<int> readers_{0};
     int pendingTicket_ = -1;

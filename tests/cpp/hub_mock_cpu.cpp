@@ -114,6 +114,16 @@ int orbm_track_frames(orbm_frameset_t*, const OrbmProjParams*, float, const int3
     }
     return ORBX_OK;
 }
+int orbm_track_local_points(orbm_frameset_t*, int slot, const OrbmProjParams* pp, const float* q_uvr, const int8_t*, const uint8_t*, const uint8_t*, const uint8_t*, int nq, const uint8_t*)
+{
+    Guard g;
+    MOCK_CHECK(slot >= 0 && slot < M.nslots && pp->mode == 3 && nq == 5);
+    const int cam = (int)q_uvr[0], seq = (int)q_uvr[1];   // the caller says whose frame it expects in the slot
+    MOCK_CHECK(M.slotCam[slot] == cam && M.slotSeq[slot] == seq);
+    M.np = 1; M.assign.assign(kCap, -1); M.nm.assign(1, cam * 3 + seq);
+    for (int t = 0; t < kCap; t++) M.assign[t] = 7000000 + cam * 100000 + seq * 10 + t % 10;
+    return ORBX_OK;
+}
 int orbx_collect_view(orbx_t*, int ticket, OrbxBatchView* v)
 {
     Guard g;
@@ -177,6 +187,19 @@ static Outcome run(int cameras, int nframes, int wait_us, int slowCam, int track
                 } else {
                     for (int t = 0; t < r.n; t++) MOCK_CHECK(assign[t] == -1);
                     if (s > 0 && track) out[cam].lost++;
+                }
+                if (track && s % 3 == 0) {   // SearchLocalPoints' search against the frame just sent
+                    OrbmProjParams p3{3, 0.8f, 0, 100};
+                    const float uvr[15] = {(float)cam, (float)s};
+                    const int8_t lvl[10] = {0}; const uint8_t qd[5 * 32] = {0};
+                    int nm3 = -1;
+                    const int rc3 = hub.search_local_points(cam, &p3, uvr, lvl, qd, nullptr, nullptr, 5, nullptr, assign.data(), &nm3);
+                    if (rc3 == ORBX_OK) {
+                        MOCK_CHECK(nm3 == cam * 3 + s);
+                        bool tab = true;
+                        for (int t = 0; t < r.n; t++) tab = tab && assign[t] == 7000000 + cam * 100000 + s * 10 + t % 10;
+                        MOCK_CHECK(tab);
+                    } else MOCK_CHECK(rc3 == ORBX_E_INVALID);   // (the ring went round: the frame has left the set)
                 }
                 out[cam].frames++; out[cam].batchSum += r.batch;
             }

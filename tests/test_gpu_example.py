@@ -119,6 +119,17 @@ def test_robots_behind_a_hub_get_what_a_handle_each_gives_them(gpu):
             assert r["hub_batch_mean"] > 0.9 * sum(g * g for g in groups) / 6   # lockstep: the groups stay together
 
 
+def test_local_map_search_behind_a_hub(gpu):
+    """--mode full --hub: after track() every robot runs Tracking::SearchLocalPoints' search (3 000 projected MapPoints) against
+    ITS frame, still resident in the hub's frame set (CameraHub::search_local_points, served by whoever leads): the same
+    tables as with a handle and a frame set per robot"""
+    alone = _run("--mode", "full", "--robots", 3, "--w", 640, "--h", 480, "--nfeat", 1000)
+    assert alone["matches_mean"] > 600
+    for hub, wait in ((3, 2000), (2, 40)):
+        r = _run("--mode", "full", "--robots", 3, "--hub", hub, "--hub-wait", wait, "--w", 640, "--h", 480, "--nfeat", 1000)
+        assert r["checksum"] == alone["checksum"] and r["matches_mean"] == alone["matches_mean"], (hub, wait)
+
+
 def test_a_hub_camera_replayed_through_the_oracle(gpu, oracle, tmp_path):
     """camera 0 of a hub of four: eight consecutive frames with what track() handed back for them, byte for byte against the
     CPU oracle (extraction, then SearchByProjection(Cur, Last) against the previous frame of the SAME camera)"""
