@@ -19,7 +19,7 @@
 //
 // build:  hipcc -O2 -std=c++17 examples/multi_robot.cpp -Iinclude -Lorbslamm_amd -lorbslamm_hip -lrccl -Wl,-rpath,'$ORIGIN/../orbslamm_amd' -o examples/multi_robot
 // usage:  multi_robot [--gpus N] [--robots R] [--frames F] [--warmup W] [--mode track|bf|extract|full] [--depth 1|2]
-//                     [--hub P (robots in groups of P share one orbslamm::CameraHub: still one thread per robot, the frames that wait together go through one chain) --hub-wait US]
+//                     [--hub P | -1 = four hubs per GPU (robots in groups of P share one orbslamm::CameraHub: still one thread per robot, the frames that wait together go through one chain) --hub-wait US]
 //                     [--per-call 1..8 (cameras whose frames one thread puts through the chain together)] [--attach 0|1] [--pinned 0|1] [--w 1241 --h 376 --nfeat 2000] [--interval 200] [--json] [--dump FILE]
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -424,6 +424,7 @@ int main(int argc, char** argv)
             hipMalloc(&d_send[d], sizeof(Stats)) != hipSuccess || hipMalloc(&d_recv[d], sizeof(Stats) * A.gpus) != hipSuccess) { fprintf(stderr, "hip setup failed\n"); return 4; }
     }
 
+    if (A.hub == -1) A.hub = std::max(1, ((A.robots + A.gpus - 1) / A.gpus + 3) / 4);   // --hub -1: four hubs per GPU (a queue each)
     if (A.hub < 0 || A.hub > orbslamm::CameraHub::kMaxCameras || (A.hub > 0 && ((A.mode != "track" && A.mode != "full") || A.per_call != 1 || A.depth != 1))) { fprintf(stderr, "--hub 1..8: mode track or full, one camera per robot, one ticket deep\n"); return 2; }
     // --hub P: on every GPU the robots are dealt to hubs of P cameras in the order they come
     std::vector<std::unique_ptr<orbslamm::CameraHub>> hubs;

@@ -44,6 +44,8 @@ public:
         float th = 15.0f;                        // SearchByProjection(Cur, Last, th, mono): Tracking.cc:931
         OrbmProjParams pp{4, 0.9f, 1, 100};      // mode 4, nnratio 0.9, rotation check, TH_HIGH
         int wait_us = 40;                        // how long a leader waits for the other members' frames
+        int sleep_us = 0;                        // > 0: a thread waiting for its results sleeps this long between two looks instead of
+                                                 // spinning (frees its core for the robot's other threads; costs up to that much latency)
     };
     struct Result {
         int n = 0;            // keypoints of this frame
@@ -113,7 +115,7 @@ public:
                 leader_.store(false, std::memory_order_release);
                 continue;
             }
-            std::this_thread::yield();
+            idle();
         }
         // state 2: this thread's part of the batch is published; copy it out (the next leader returns the ticket once all have)
         const int rc = r.rc;
@@ -151,7 +153,7 @@ public:
                 leader_.store(false, std::memory_order_release);
                 continue;
             }
-            std::this_thread::yield();
+            idle();
         }
         q.state.store(0, std::memory_order_relaxed);
         if (nmatches) *nmatches = q.nmatches;
@@ -159,6 +161,11 @@ public:
     }
 
 private:
+    void idle() const
+    {
+        if (cfg_.sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(cfg_.sleep_us));
+        else std::this_thread::yield();
+    }
     struct Request {
         std::atomic<int> state{0};   // 0 idle, 1 waiting for a batch, 2 served (view published)
         const uint8_t* frame = nullptr; int stride = 0;
