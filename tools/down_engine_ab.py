@@ -16,6 +16,7 @@ from orbslamm_amd import ORBextractor, synth  # noqa: E402
 
 W, H, B = 1241, 376, 64
 SECONDS = float(os.environ.get("AB_SECONDS", "1.5"))
+DEPTH = int(os.environ.get("AB_DEPTH", "3"))  # tickets in flight (the library holds three slots unless built with -DORBX_HOST_SLOTS=n)
 frames = synth.make_frames(W, H, B)
 ex = ORBextractor(2000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
 pin = [ex.alloc_pinned_frames(B, W, H) for _ in range(3)]
@@ -44,21 +45,27 @@ for name, src in (("pinned", lambda i: pin[i % 3]), ("pageable", lambda i: frame
     n_checked, ref, bad = [0], [None], [0]
     for _ in range(6):  # warm
         tick.append(ex.submit_host(src(n))); n += 1
-        if len(tick) == 3:
+        if len(tick) == DEPTH:
             take(tick.pop(0))
     while tick:
         take(tick.pop(0))
     n = 0
+    t_sub = t_col = 0.0
     t = time.perf_counter()
     while time.perf_counter() - t < SECONDS:
+        a = time.perf_counter()
         tick.append(ex.submit_host(src(n)))
-        if len(tick) == 3:
+        b = time.perf_counter()
+        if len(tick) == DEPTH:
             take(tick.pop(0))
+        t_sub += b - a
+        t_col += time.perf_counter() - b
         n += 1
     while tick:
         take(tick.pop(0))
     dt = time.perf_counter() - t
-    out[name] = (n * B / dt, crc, bad[0])
+    out[name] = (n * B / dt, crc, bad[0], t_sub / n * 1e3, t_col / n * 1e3)
 print("ORBX_DOWN_ENGINE=%s  pinned %.0f frames/s  pageable %.0f frames/s  crc of the first six tickets %08x %08x  tickets with other counts %d"
       % (os.environ.get("ORBX_DOWN_ENGINE", "(default)"), out["pinned"][0], out["pageable"][0], out["pinned"][1], out["pageable"][1],
          out["pinned"][2] + out["pageable"][2]))
+print("   host side per ticket: pinned submit %.3f ms + collect %.3f ms; pageable submit %.3f + collect %.3f" % (out["pinned"][3], out["pinned"][4], out["pageable"][3], out["pageable"][4]))
