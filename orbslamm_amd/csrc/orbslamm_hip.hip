@@ -25,6 +25,9 @@
 #include <thread>
 #include <type_traits>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>  // streaming stores of the pageable-frame staging (orbx_host.inc)
+#endif
 
 #include "../../include/orbslamm_hip.h"
 #include "orbx_common.hpp"
