@@ -324,7 +324,7 @@ def host_path(ex, cfg, frames, seconds=1.5):
                 h2d, d2h, bu, bd = ex.link_rate(up_b, down_b, 40)
                 peak_fps = bu * 1e9 / (stride * H)
                 out.update(pcie_peak_gbs={"h2d_alone": h2d, "d2h_alone": d2h, "h2d_beside_d2h": bu, "d2h_beside_h2d": bd,
-                                          "what": "pinned hipMemcpyAsync of %d B up / %d B down per repetition (one batch), GB/s" % (up_b, down_b)},
+                                          "what": "pinned hipMemcpyAsync of %d B up / %d B down per repetition (one batch), GB/s; the two 'beside' figures are each direction's bytes over the time of the loop that issues one copy down per copy up -- the rates the pipeline asks for together, not each direction's limit (tools/ubench/link_duplex.hip has those: 54.6 up beside 42.9 down)" % (up_b, down_b)},
                            pcie_frames_per_s_ceiling=peak_fps,
                            pcie_frac_pinned=out.get("pipelined_pinned_fps", 0.0) / peak_fps,
                            pcie_frac_pageable=out.get("pipelined_fps", 0.0) / peak_fps)
