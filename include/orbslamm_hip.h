@@ -248,6 +248,12 @@ int orbx_debug_pair_overlap(orbx_t* h, int nb, float target_ms, int* n_kernels, 
 int orbx_debug_link_rate(orbx_t* h, size_t up_bytes, size_t down_bytes, int reps, float* h2d_gbs, float* d2h_gbs,
                          float* both_up_gbs, float* both_down_gbs);
 
+/* Diagnostics: the row copy the host-buffer entries stage pageable frames with (streaming stores where the destination
+ * rows are 32-byte aligned, memcpy otherwise) -- `rows` rows of `w` bytes from src (pitch spitch) to dst (pitch dpitch).
+ * Needs no device: the CPU suite holds it to a plain copy for odd widths, unaligned sources and row tails.
+ * Returns 1 if the streaming form ran, 0 for memcpy, < 0 on a bad argument. */
+int orbx_debug_stage_rows(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t w, int rows);
+
 /* ---------------------------------------------------------------- matcher
  * replaces class ORBmatcher (include/ORBmatcher.h:37-102).  The object-graph
  * walking (MapPoint flags, mutex-guarded getters, camera projection) stays in the

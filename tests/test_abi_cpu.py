@@ -100,3 +100,32 @@ def test_multi_robot_example_builds_against_the_abi():
     from orbslamm_amd import _lib
     if _lib.lib().orbx_device_count() == 0:
         assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+def test_staging_row_copy_equals_memcpy():
+    """orbx_debug_stage_rows: the streaming-store row copy of the pageable-frame staging (orbx_host.inc stage_rows) against a
+    plain copy -- widths with every tail length, unaligned sources, aligned and unaligned destinations (the latter take memcpy),
+    bytes outside the rows untouched"""
+    from orbslamm_amd import _lib
+    L = _lib.lib()
+    L.orbx_debug_stage_rows.restype = C.c_int
+    L.orbx_debug_stage_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+    rng = np.random.default_rng(7)
+    ran_streaming = 0
+    for w in list(range(120, 200)) + [1241, 640, 1920, 1279]:
+        for src_off, dst_off in ((0, 0), (1, 0), (13, 0), (5, 32), (0, 8)):
+            rows, spitch, dpitch = 7, w + 19, (w + 63) // 64 * 64 + 64
+            src = rng.integers(0, 256, rows * spitch + 64, dtype=np.uint8)
+            raw = np.full(rows * dpitch + 128, 0xA5, dtype=np.uint8)
+            base = (-raw.ctypes.data) % 64 + dst_off      # 64-byte aligned start, then the offset under test
+            rc = L.orbx_debug_stage_rows(raw.ctypes.data + base, dpitch, src.ctypes.data + src_off, spitch, w, rows)
+            assert rc >= 0
+            ran_streaming += rc
+            want = np.full_like(raw, 0xA5)
+            for y in range(rows):
+                want[base + y * dpitch: base + y * dpitch + w] = src[src_off + y * spitch: src_off + y * spitch + w]
+            assert np.array_equal(raw, want), (w, src_off, dst_off)
+    assert L.orbx_debug_stage_rows(None, 0, None, 0, 0, 0) < 0
+    import platform
+    if platform.machine() == "x86_64" and os.environ.get("ORBX_STAGE_NT") != "0":
+        assert ran_streaming > 0   # the aligned cases took the streaming path on this host
