@@ -65,6 +65,29 @@ for name, src in (("pinned", lambda i: pin[i % 3]), ("pageable", lambda i: frame
         take(tick.pop(0))
     dt = time.perf_counter() - t
     out[name] = (n * B / dt, crc, bad[0], t_sub / n * 1e3, t_col / n * 1e3)
+# results into caller-owned pinned arrays (orbx_submit_batch_into / orbx_collect), pageable frames, like bench.py's pipelined_into
+outs = [ex.alloc_pinned_results(B) for _ in range(3)]
+tick, n = [], 0
+for _ in range(6):
+    tick.append(ex.submit_host_into(frames, outs[n % 3])); n += 1
+    if len(tick) == DEPTH:
+        ex.collect_into(tick.pop(0))
+while tick:
+    ex.collect_into(tick.pop(0))
+n = 0
+t = time.perf_counter()
+while time.perf_counter() - t < SECONDS:
+    tick.append(ex.submit_host_into(frames, outs[n % 3])); n += 1
+    if len(tick) == DEPTH:
+        ex.collect_into(tick.pop(0))
+while tick:
+    ex.collect_into(tick.pop(0))
+into_fps = n * B / (time.perf_counter() - t)
+crc_into = 0
+for f in (0, B // 2, B - 1):
+    k = int(outs[0][2][f])
+    crc_into = zlib.crc32(outs[0][0][f, :k].tobytes() + outs[0][1][f, :k].tobytes() + outs[0][3][f, :k].tobytes(), crc_into)
+print("   into caller arrays (pageable frames): %.0f frames/s  crc %08x" % (into_fps, crc_into))
 print("ORBX_DOWN_ENGINE=%s  pinned %.0f frames/s  pageable %.0f frames/s  crc of the first six tickets %08x %08x  tickets with other counts %d"
       % (os.environ.get("ORBX_DOWN_ENGINE", "(default)"), out["pinned"][0], out["pageable"][0], out["pinned"][1], out["pageable"][1],
          out["pinned"][2] + out["pageable"][2]))

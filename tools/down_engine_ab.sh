@@ -7,5 +7,5 @@ N=${1:-3}
 VARS=${2:-"ORBX_DOWN_ENGINE=0|ORBX_DOWN_ENGINE=1"}
 IFS='|' read -ra V <<< "$VARS"
 for i in $(seq $N); do
-  for v in "${V[@]}"; do echo -n "[$v] "; env $v python $R/tools/down_engine_ab.py 2>&1 | tail -2; done
+  for v in "${V[@]}"; do echo -n "[$v] "; env $v python $R/tools/down_engine_ab.py 2>&1 | tail -3; done
 done
