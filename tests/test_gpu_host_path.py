@@ -97,6 +97,52 @@ def test_pipelined_batches(gpu, oracle, kind):
         p.free()
 
 
+def test_pipelined_batches_without_matching_read_in_place(gpu, oracle):
+    """extraction-only tickets (no match tables) three deep, batch sizes 4, 4, 3, 4, 4 on a handle of four: a batch submitted
+    behind others gathers its results in HBM and goes down as ONE copy of the block laid out for its own B -- read in place
+    through orbx_collect_view (keypoints, descriptors, counts; match / nmatch are null)"""
+    from orbslamm_amd import ORBextractor, _lib
+    w, h, nf = 640, 480, 1000
+    sizes = [4, 4, 3, 4, 4]
+    fr = frames_for(w, h, sum(sizes), stream=11)
+    ref = _oracle_stream(oracle, fr, nf)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=4, device=0)
+    batches, o = [], 0
+    for b in sizes:
+        batches.append(np.ascontiguousarray(fr[o:o + b]))
+        o += b
+    got = []
+
+    def take(t):
+        ex._inflight.pop(t, None)
+        v = _lib.OrbxBatchView()
+        assert ex._L.orbx_collect_view(ex._h, t, C.byref(v)) == 0
+        assert not v.match and not v.nmatch
+        n = np.ctypeslib.as_array(C.cast(v.n, C.POINTER(C.c_int32)), (v.B,)).copy()
+        frames = []
+        for f in range(v.B):
+            k = int(n[f])
+            kps = np.frombuffer((C.c_uint8 * (k * 28)).from_address(v.kps + f * v.cap * 28), dtype=_lib.KP_DTYPE).copy()
+            desc = np.frombuffer((C.c_uint8 * (k * 32)).from_address(v.desc + f * v.cap * 32), dtype=np.uint8).reshape(k, 32).copy()
+            frames.append((kps, desc))
+        assert ex._L.orbx_release(ex._h, t) == 0
+        got.append(frames)
+
+    tickets = []
+    for b in batches:
+        tickets.append(ex.submit_host(b, match=False))
+        if len(tickets) == 3:
+            take(tickets.pop(0))
+    while tickets:
+        take(tickets.pop(0))
+    o = 0
+    for i, b in enumerate(sizes):
+        assert len(got[i]) == b
+        for f in range(b):
+            assert got[i][f][0].tobytes() == ref[o + f][0].tobytes() and np.array_equal(got[i][f][1], ref[o + f][1])
+        o += b
+
+
 def test_view_collect_and_ticket_errors(gpu, oracle):
     from orbslamm_amd import ORBextractor, OrbError, _lib
     w, h, nf = 320, 240, 500
