@@ -586,7 +586,11 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
 // two live lists (2 * ldsCand halves) | per query: state byte (qCap bytes) | two lists of undecided queries (2 * qCap halves).
 // L = false: the per-query tables and the lists stay in memory (more queries or candidates than the LDS plan holds).
 constexpr uint8_t kQDecided = 1, kQBlocking = 2;
-constexpr int kTailLive = 512, kTailQueries = 128;   // at most this much left: the first wave runs the remaining rounds alone
+#ifndef ORBT_TAIL_LIVE
+#define ORBT_TAIL_LIVE 512
+#define ORBT_TAIL_QUERIES 128
+#endif
+constexpr int kTailLive = ORBT_TAIL_LIVE, kTailQueries = ORBT_TAIL_QUERIES;   // at most this much left: the first wave runs the remaining rounds alone
 
 template <bool L>
 __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const ProjCommon& c, int nq, int nt, int total,
