@@ -31,7 +31,10 @@ using orbm::GridDev;
 using orbm::KeyDev;
 using orbm::UndistArgs;
 
-constexpr int kThreads = 1024;
+#ifndef ORBT_THREADS
+#define ORBT_THREADS 1024
+#endif
+constexpr int kThreads = ORBT_THREADS;
 constexpr int kWaves = kThreads / 64;
 constexpr int kFree = 0x7FFFFFFF;
 constexpr int kMaxQueryIters = 32;  // decided-bit per (thread, iteration): nq <= 32 * 1024
