@@ -671,6 +671,11 @@ def live_streams(cfg, dev_index=0, frames=600):
     keep = keep + ("hub_batch_mean",)
     out["robots_on_one_gpu"]["track_8_threads_x1_hubs_of_2"] = run("--mode", "track", "--robots", 8, "--hub", 2, n=400)
     out["robots_on_one_gpu"]["track_16_threads_x1_hubs_of_4"] = run("--mode", "track", "--robots", 16, "--hub", 4, n=400)
+    # the same program's offline-sequence mode (--mode batch: this file's own step through the device-resident entries, one
+    # thread + one handle per GPU): the native cross-check of `value`, measured in a process of its own
+    r = run("--mode", "batch", "--steps", 200, "--warmup", 5)
+    out["native_offline_batch"] = {k: r[k] for k in ("frames_per_s", "keypoints_mean", "matches_mean") if k in r} if "error" not in r else r
+    out["native_offline_batch"]["what"] = "examples/multi_robot --mode batch: 64 frames per step, 8 batches resident in HBM, 200 steps -- bench.py's `value` from the C++ caller"
     t = out["one_robot"]["track"]
     if "ms_median" in t:
         out["target"] = {"track_ms_median_le_0.20": bool(t["ms_median"] <= 0.20), "bf_ms_median_le_0.15": bool(out["one_robot"]["bf"].get("ms_median", 9) <= 0.15),

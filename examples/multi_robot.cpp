@@ -20,6 +20,7 @@
 // build:  hipcc -O2 -std=c++17 examples/multi_robot.cpp -Iinclude -Lorbslamm_amd -lorbslamm_hip -lrccl -Wl,-rpath,'$ORIGIN/../orbslamm_amd' -o examples/multi_robot
 // usage:  multi_robot [--gpus N] [--robots R] [--frames F] [--warmup W] [--mode track|bf|extract|full] [--depth 1|2]
 //                     [--hub P | -1 = four hubs per GPU (robots in groups of P share one orbslamm::CameraHub: still one thread per robot, the frames that wait together go through one chain) --hub-wait US]
+//                     [--mode batch --batch 64 --pool 8 --steps 200 (the offline-sequence mode: bench.py's step through the device-resident entries, one thread + one handle per GPU)]
 //                     [--per-call 1..8 (cameras whose frames one thread puts through the chain together)] [--attach 0|1] [--pinned 0|1] [--w 1241 --h 376 --nfeat 2000] [--interval 200] [--json] [--dump FILE]
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -45,6 +46,7 @@ namespace {
 
 struct Args {
     int gpus = 1, robots = 1, per_call = 1, hub = 0, hub_wait = 40, frames = 600, warmup = 30, depth = 1, attach = 1, pinned = 1, w = 1241, h = 376, nfeat = 2000, interval = 200;
+    int batch = 64, pool = 8, steps = 200;   // --mode batch: frames per step, batches resident in HBM, timed steps
     std::string mode = "track", dump;
     bool json = false;
 };
@@ -212,6 +214,75 @@ struct Robot {
         batch_mean = (double)batchSum / std::max<size_t>(1, lat_ms.size());
         st.ns_busy = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tTimed).count();
         if (A.pinned) orbx_host_free(hub->extractor(), ring);
+    }
+
+    // --mode batch: an offline sequence of this robot's camera through the batched device-resident entries -- what bench.py
+    // times as `value` (BASELINE.json configs[3]: 64 frames in flight): --pool batches of --batch frames resident in HBM, per
+    // step orbx_extract_batch_device + orbx_match_prev_batch_device, nothing crosses the link inside the timed region.
+    // One thread + one handle per GPU; lat_ms holds the per-step times.
+    void run_batch(std::atomic<int>& ready, std::atomic<bool>& go)
+    {
+        const Args& A = *a;
+        OrbxParams prm{A.nfeat, 1.2f, 8, 20, 7};
+        orbx_t* ex = nullptr;
+        const int B = A.batch;
+        OX(orbx_create(&prm, A.w, A.h, B, device, &ex));
+        const int cap = orbx_max_keypoints(ex);
+        const int stride = (A.w + 63) / 64 * 64;
+        const size_t pitch = (size_t)stride * A.h;
+        std::vector<void*> d_pool((size_t)A.pool, nullptr);
+        {
+            int cw, ch;
+            const std::vector<uint8_t> scene = make_scene(A.w, A.h, robot, cw, ch);
+            std::vector<uint8_t> host(pitch * B);
+            for (int p = 0; p < A.pool; p++) {
+                for (int f = 0; f < B; f++) make_frame(scene, cw, A.w, A.h, robot, p * B + f, host.data() + (size_t)f * pitch, stride);
+                OX(orbx_device_alloc(ex, pitch * B, &d_pool[p]));
+                OX(orbx_upload(ex, d_pool[p], host.data(), pitch * B));
+            }
+        }
+        auto step = [&](int i) -> int {
+            int rc = orbx_extract_batch_device(ex, (const uint8_t*)d_pool[i % A.pool], B, A.w, A.h, stride, pitch);
+            return rc ? rc : orbx_match_prev_batch_device(ex, 0.7f, 50, 1);
+        };
+        // every resident batch once (device error flag read, both result sets in use), then the warm-up, then the timed steps
+        for (int i = 0; i < A.pool; i++) OX(step(i));
+        OX(orbx_sync(ex));
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        for (int i = 0; i < A.warmup; i++) OX(step(i));
+        OX(orbx_sync(ex));
+        const auto t0 = std::chrono::steady_clock::now();
+        auto tp = t0;
+        for (int i = 0; i < A.steps; i++) {
+            OX(step(A.warmup + i));
+            live_frames.fetch_add(B);
+            const auto tn = std::chrono::steady_clock::now();   // (enqueue pace: the device runs behind; the sum is exact after the sync)
+            lat_ms.push_back(std::chrono::duration<double, std::milli>(tn - tp).count());
+            tp = tn;
+        }
+        OX(orbx_sync(ex));
+        st.ns_busy = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        st.frames = (int64_t)B * A.steps;
+        // the last batch's results: counts of every frame, checksum over its last frame's bytes
+        std::vector<OrbxKeyPoint> kps((size_t)cap);
+        std::vector<uint8_t> desc((size_t)cap * 32);
+        std::vector<int32_t> match((size_t)cap);
+        uint64_t cs = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { cs ^= b[i]; cs *= 1099511628211ull; } };
+        int64_t kp_sum = 0, m_sum = 0;
+        for (int f = 0; f < B; f++) {
+            int n = 0, nm = 0;
+            OX(orbx_download(ex, f, kps.data(), desc.data(), cap, &n));
+            OX(orbx_download_matches(ex, f, match.data(), cap, &nm));
+            kp_sum += n; m_sum += nm;
+            if (f == B - 1) { mix(kps.data(), (size_t)n * sizeof(OrbxKeyPoint)); mix(desc.data(), (size_t)n * 32); mix(match.data(), (size_t)n * 4); }
+        }
+        st.keypoints = kp_sum * A.steps; st.matches = m_sum * A.steps;   // (per-frame means of the last batch, scaled to the run)
+        live_kps.store(st.keypoints); live_matches.store(st.matches);
+        st.checksum = cs;
+        for (void* d : d_pool) if (d) orbx_device_free(ex, d);
+        orbx_destroy(ex);
     }
 
     void run(std::atomic<int>& ready, std::atomic<bool>& go)
@@ -398,6 +469,7 @@ int main(int argc, char** argv)
         else if (k == "--attach") A.attach = atoi(val()); else if (k == "--pinned") A.pinned = atoi(val()); else if (k == "--w") A.w = atoi(val());
         else if (k == "--h") A.h = atoi(val()); else if (k == "--nfeat") A.nfeat = atoi(val()); else if (k == "--interval") A.interval = atoi(val());
         else if (k == "--dump") A.dump = val();
+        else if (k == "--batch") A.batch = atoi(val()); else if (k == "--pool") A.pool = atoi(val()); else if (k == "--steps") A.steps = atoi(val());
         else if (k == "--hub") A.hub = atoi(val()); else if (k == "--hub-wait") A.hub_wait = atoi(val());
         else if (k == "--json") A.json = true;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
@@ -406,7 +478,10 @@ int main(int argc, char** argv)
     if (ndev < 1) { fprintf(stderr, "no HIP device: the ORB front-end has no CPU fallback\n"); return 3; }
     if (A.gpus < 1 || A.gpus > ndev) { fprintf(stderr, "--gpus %d but %d device(s) visible\n", A.gpus, ndev); return 2; }
     if (A.robots < A.gpus) A.robots = A.gpus;
-    if (A.mode != "track" && A.mode != "bf" && A.mode != "extract" && A.mode != "full") { fprintf(stderr, "--mode track|bf|extract|full\n"); return 2; }
+    if (A.mode != "track" && A.mode != "bf" && A.mode != "extract" && A.mode != "full" && A.mode != "batch") { fprintf(stderr, "--mode track|bf|extract|full|batch\n"); return 2; }
+    const bool batchMode = A.mode == "batch";
+    if (batchMode && (A.batch < 1 || A.batch > 256 || A.pool < 1 || A.steps < 1 || A.per_call != 1 || A.depth != 1 || A.hub != 0)) { fprintf(stderr, "--mode batch: --batch 1..256 --pool >= 1 --steps >= 1, no --per-call / --depth / --hub\n"); return 2; }
+    if (batchMode && A.warmup == 30) A.warmup = 5;
     if (A.mode == "full" && (A.per_call != 1 || A.depth != 1)) { fprintf(stderr, "--mode full: one camera per call, one ticket deep\n"); return 2; }
     if (A.mode == "full" && A.warmup < 12) A.warmup = 12;   // the ring's local maps are built during the warm-up
     if (A.depth != 1 && A.depth != 2) { fprintf(stderr, "--depth 1|2\n"); return 2; }
@@ -451,7 +526,7 @@ int main(int argc, char** argv)
     std::atomic<bool> go{false};
     std::vector<std::thread> th;
     for (int r = 0; r < A.robots; r++) { robots[r].robot = r; robots[r].device = r % A.gpus; robots[r].a = &A; }
-    for (int r = 0; r < A.robots; r++) th.emplace_back([&, r] { if (robots[r].hub) robots[r].run_hub(ready, go); else robots[r].run(ready, go); if (robots[r].failed) ready.fetch_add(1 << 16); });
+    for (int r = 0; r < A.robots; r++) th.emplace_back([&, r] { if (batchMode) robots[r].run_batch(ready, go); else if (robots[r].hub) robots[r].run_hub(ready, go); else robots[r].run(ready, go); if (robots[r].failed) ready.fetch_add(1 << 16); });
     while ((ready.load() & 0xFFFF) + (ready.load() >> 16) < A.robots) std::this_thread::yield();
     const auto t0 = std::chrono::steady_clock::now();
     go.store(true, std::memory_order_release);
@@ -479,7 +554,7 @@ int main(int argc, char** argv)
     bool anyFailed = false;
     for (;;) {
         bool done = true;
-        for (auto& r : robots) done &= r.failed || r.live_frames.load() >= (int64_t)A.frames * A.per_call;
+        for (auto& r : robots) done &= r.failed || r.live_frames.load() >= (batchMode ? (int64_t)A.batch * A.steps : (int64_t)A.frames * A.per_call);
         if (done) break;
         if (A.interval > 0 && robots[0].live_frames.load() >= nextReport) {
             if (!gather()) { fprintf(stderr, "stats gather failed\n"); anyFailed = true; break; }
@@ -508,10 +583,10 @@ int main(int argc, char** argv)
     std::sort(all.begin(), all.end());
     const double p95 = all.empty() ? 0 : all[all.size() * 95 / 100], p99 = all.empty() ? 0 : all[all.size() * 99 / 100], pmax = all.empty() ? 0 : all.back();
     if (A.json) {
-        printf("{\"mode\": \"%s\", \"gpus\": %d, \"robots\": %d, \"cameras_per_call\": %d, \"depth\": %d, \"attach\": %d, \"pinned\": %d, \"w\": %d, \"h\": %d, \"nfeat\": %d, \"frames_per_robot\": %d, "
+        printf("{\"mode\": \"%s\", \"batch\": %d, \"steps\": %d, \"gpus\": %d, \"robots\": %d, \"cameras_per_call\": %d, \"depth\": %d, \"attach\": %d, \"pinned\": %d, \"w\": %d, \"h\": %d, \"nfeat\": %d, \"frames_per_robot\": %d, "
                "\"frames_per_s\": %.1f, \"ms_median\": %.4f, \"ms_mean\": %.4f, \"ms_p95\": %.4f, \"ms_p99\": %.4f, \"ms_max\": %.4f, \"host_us_submit\": %.1f, \"host_us_enqueue\": %.1f, \"keypoints_mean\": %.1f, \"matches_mean\": %.1f, \"wall_s\": %.3f, "
                "\"rccl_allgathers\": %d, \"gathered_frames\": %lld, \"hub\": %d, \"hub_batch_mean\": %.2f, \"checksum\": \"%016llx\"}\n",
-               A.mode.c_str(), A.gpus, A.robots, A.per_call, A.depth, A.attach, A.pinned, A.w, A.h, A.nfeat, A.frames, fps, median(all), mean, p95, p99, pmax, usSub, usEnq,
+               A.mode.c_str(), batchMode ? A.batch : 0, batchMode ? A.steps : 0, A.gpus, A.robots, A.per_call, A.depth, A.attach, A.pinned, A.w, A.h, A.nfeat, A.frames, fps, median(all), mean, p95, p99, pmax, usSub, usEnq,
                (double)kps / std::max<int64_t>(1, frames), (double)matches / std::max<int64_t>(1, frames), wall_s, gathers, (long long)gframes, A.hub, hubBatch, (unsigned long long)cs);
     } else {
         // as the reference's examples end (mono_tum.cc:113-122)
