@@ -914,6 +914,7 @@ def run_rank(args):
                        "frames_per_step_per_gpu": B, "streams": world, "parallelism": "1 independent stream per GPU",
                        "resident_pool_frames_per_gpu": pool * B, "resident_pool_mb_per_gpu": pool * B * STRIDE * H / 1e6,
                        "pool_validation_steps_before_warmup": pool},
+            "stats_gather": streams.stats_transport() if distributed else "none (single process)",
             "keypoints_last_frame": [int(g[1]) for g in gathered],
             "matches_last_frame": [int(g[2]) for g in gathered],
         }

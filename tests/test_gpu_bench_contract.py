@@ -47,6 +47,7 @@ def test_stdout_is_one_json_record(gpu, mode):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     if mode == "rccl_world1":
         assert "RCCL version" not in out.stdout  # the banner belongs on stderr
+        assert rec["stats_gather"].startswith("rccl all_gather")   # the record went over an RCCL communicator (made after the timed region)
 
 
 def _plain_env():
