@@ -36,6 +36,9 @@ def init(backend, device=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one node, ranks meet on the loopback: gloo need not resolve the container's hostname to pick an interface
+        if os.environ.get("MASTER_ADDR") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         kw = {}
         eager = os.environ.get("ORBX_DIST_EAGER_NCCL") == "1"
         if backend == "nccl" and not eager:
