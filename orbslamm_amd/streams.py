@@ -92,7 +92,10 @@ def barrier(world):
 
 
 def timed_region(step, steps, sync, world):
-    """barrier + device sync on both sides, EXACTLY `steps` steps in between"""
+    """barrier + device sync on both sides, EXACTLY `steps` steps in between.  A rank's time ends when ITS device has
+    drained (the closing barrier follows, outside the interval): the job's time is the MAX over ranks, taken in
+    gather_stats -- with the barrier inside, every rank would read the slowest one's time plus the barrier's own
+    latency (a CPU barrier over sockets is tenths of a millisecond, a few percent of a 20-step region)."""
     import time
     sync()
     barrier(world)
@@ -100,8 +103,9 @@ def timed_region(step, steps, sync, world):
     for _ in range(steps):
         step()
     sync()
+    dt = time.perf_counter() - t0
     barrier(world)
-    return time.perf_counter() - t0
+    return dt
 
 
 def gather_stats(stats, world, device="cpu"):
