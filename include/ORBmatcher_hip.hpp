@@ -1,7 +1,12 @@
 // ORBmatcher_hip.hpp -- the reference's ORBmatcher (/root/reference/SingleRobotScenario/include/ORBmatcher.h:37-102)
 // over the C ABI of liborbslamm_hip.so.  Header-only, C++11.
 //
-//   FlatMatcher     the C ABI with RAII and std::vector outputs, on flat arrays
+//   FlatMatcher     the C ABI with std::vector outputs, on flat arrays.  Holds (mfNNratio, mbCheckOrientation, device)
+//                   and NOTHING on the device: the reference builds its matchers as stack temporaries at every call
+//                   site (Tracking.cc:639, 809, 914, 1242, 1415, 1454; LocalMapping.cc:215, 483; LoopClosing.cc:245, 603;
+//                   MultiMapper.cc:180, 687), so constructing / destroying one touches no HIP API.  Every member call
+//                   runs on the calling thread's handle (orbm_thread_handle: queue, scratch and staging block made at
+//                   the thread's first search, kept for the thread's life).
 //   ORBmatcherT<Frame, KeyFrame, MapPoint>
 //                   the drop-in: the reference's eleven member signatures (ORBmatcher.h:48-83).  Every member does
 //                   what the reference's loop does around its distance search -- walks the object graph (MapPoint
@@ -20,6 +25,7 @@
 // device, bit-exact against the CPU checker.
 #pragma once
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -40,17 +46,20 @@ struct FlatFeatVec {
     std::vector<uint32_t> node_id;
     std::vector<int32_t> start, idx;
     FlatFeatVec() : start(1, 0) {}
+    // (re)fill from a DBoW2::FeatureVector; the vectors keep their capacity from call to call
     template <class MapT>
-    static FlatFeatVec from(const MapT& fv)
+    void assign(const MapT& fv)
     {
-        FlatFeatVec f;
+        node_id.clear(); idx.clear(); start.clear();
+        start.push_back(0);
         for (typename MapT::const_iterator it = fv.begin(); it != fv.end(); ++it) {
-            f.node_id.push_back((uint32_t)it->first);
-            for (size_t k = 0; k < it->second.size(); k++) f.idx.push_back((int32_t)it->second[k]);
-            f.start.push_back((int32_t)f.idx.size());
+            node_id.push_back((uint32_t)it->first);
+            for (size_t k = 0; k < it->second.size(); k++) idx.push_back((int32_t)it->second[k]);
+            start.push_back((int32_t)idx.size());
         }
-        return f;
     }
+    template <class MapT>
+    static FlatFeatVec from(const MapT& fv) { FlatFeatVec f; f.assign(fv); return f; }
     OrbmFeatVec view() const
     {
         OrbmFeatVec v;
@@ -140,24 +149,34 @@ private:
 
 class FlatMatcher {
 public:
-    orbm_t* handle() { return h_; }
+    // the calling thread's device handle (never owned by the matcher object; do not orbm_destroy it)
+    orbm_t* handle() const
+    {
+        orbm_t* h = nullptr;
+        if (orbm_thread_handle(device_, &h) != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher(HIP): ") + orbx_last_error());
+        return h;
+    }
     static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;  // ORBmatcher.cc:37-39
 
+    // ORBmatcher.cc:41: stores the two parameters, like the reference's constructor; no device call
     FlatMatcher(float nnratio = 0.6f, bool checkOri = true, int device = 0)
-        : mfNNratio(nnratio), mbCheckOrientation(checkOri)
-    {
-        if (orbm_create(device, &h_) != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher(HIP): ") + orbx_last_error());
-    }
-    ~FlatMatcher() { orbm_destroy(h_); }
-    FlatMatcher(const FlatMatcher&) = delete;
-    FlatMatcher& operator=(const FlatMatcher&) = delete;
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
+    int device() const { return device_; }
+    // Microseconds the calling thread's last member call spent inside the C ABI (upload, kernels, download, wait).  What a
+    // drop-in member costs beyond this is the object-graph walk around it -- the reference's own loop head and write-back.
+    static double& lastDeviceUs() { static thread_local double us = 0; return us; }
+    struct DeviceClock {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~DeviceClock() { lastDeviceUs() = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+    };
 
     // static int DescriptorDistance(const cv::Mat&, const cv::Mat&)  ORBmatcher.cc:1649.
     // One pair per launch: residual callers only; hot callers use the batched members below.
     int DescriptorDistance(const uint8_t a[32], const uint8_t b[32])
     {
         int32_t d = -1;
-        check(orbm_distance_matrix(h_, a, 1, b, 1, &d));
+        DeviceClock clk_;
+        check(orbm_distance_matrix(handle(), a, 1, b, 1, &d));
         return d;
     }
 
@@ -169,7 +188,8 @@ public:
         match.assign(outByTrain ? nt : nq, -1);
         int n = 0;
         OrbmFeatVec a = qfv.view(), b = tfv.view();
-        check(orbm_search_by_bow(h_, qdesc, qangle, qvalid, nq, &a, tdesc, tangle, tvalid, nt, &b, mfNNratio, mbCheckOrientation,
+        DeviceClock clk_;
+        check(orbm_search_by_bow(handle(), qdesc, qangle, qvalid, nq, &a, tdesc, tangle, tvalid, nt, &b, mfNNratio, mbCheckOrientation,
                                  outByTrain, match.data(), &n));
         return n;
     }
@@ -184,7 +204,8 @@ public:
     {
         OrbmProjParams pp = {mode, mfNNratio, mbCheckOrientation, thDist};
         int n = 0;
-        check(orbm_search_by_projection_stereo(h_, &pp, q_uvr, q_ur, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, &grid, t_keys_un, tdesc,
+        DeviceClock clk_;
+        check(orbm_search_by_projection_stereo(handle(), &pp, q_uvr, q_ur, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, &grid, t_keys_un, tdesc,
                                                t_uright, nt, t_occ.data(), assign.data(), &n));
         return n;
     }
@@ -196,7 +217,8 @@ public:
     {
         vnMatches12.assign(n1, -1);
         int n = 0;
-        check(orbm_search_for_initialization(h_, vbPrevMatched_xy, (float)windowSize, keys1, desc1, n1, &grid, keys2, desc2, n2,
+        DeviceClock clk_;
+        check(orbm_search_for_initialization(handle(), vbPrevMatched_xy, (float)windowSize, keys1, desc1, n1, &grid, keys2, desc2, n2,
                                              mfNNratio, mbCheckOrientation, vnMatches12.data(), &n));
         return n;
     }
@@ -212,7 +234,8 @@ public:
         std::vector<int32_t> m12(n1, -1);
         int n = 0;
         OrbmFeatVec a = fv1.view(), b = fv2.view();
-        check(orbm_search_for_triangulation(h_, k1, d1, skip1, uright1, n1, &a, k2, d2, skip2, uright2, n2, &b, F12, ex, ey,
+        DeviceClock clk_;
+        check(orbm_search_for_triangulation(handle(), k1, d1, skip1, uright1, n1, &a, k2, d2, skip2, uright2, n2, &b, F12, ex, ey,
                                             mvScaleFactors2.data(), mvLevelSigma2_2.data(), (int)mvScaleFactors2.size(),
                                             bOnlyStereo, mbCheckOrientation, m12.data(), &n));
         vMatchedPairs.clear();
@@ -227,7 +250,8 @@ public:
                     const std::vector<float>& mvInvLevelSigma2, bool chi2, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist)
     {
         bestIdx.assign(nq, -1); bestDist.assign(nq, 256);
-        check(orbm_window_best(h_, q_uvr, q_ur, q_pred, qdesc, qvalid, nq, &grid, t_keys_un, tdesc, t_uright, nt,
+        DeviceClock clk_;
+        check(orbm_window_best(handle(), q_uvr, q_ur, q_pred, qdesc, qvalid, nq, &grid, t_keys_un, tdesc, t_uright, nt,
                                mvInvLevelSigma2.data(), (int)mvInvLevelSigma2.size(), chi2, bestIdx.data(), bestDist.data()));
     }
 
@@ -237,7 +261,8 @@ public:
                                            const float K[4], const float D[5], const OrbmGrid& grid)
     {
         orbm_frame_t* f = nullptr;
-        check(orbm_frame_create(h_, d_keypoints, d_descriptors, n, K, D, &grid, &f));
+        DeviceClock clk_;
+        check(orbm_frame_create(handle(), d_keypoints, d_descriptors, n, K, D, &grid, &f));
         return std::unique_ptr<DeviceFrame>(new DeviceFrame(f));
     }
     // SearchForInitialization(F1, F2, ...) :407 between two device frames
@@ -245,7 +270,8 @@ public:
     {
         vnMatches12.assign((size_t)F1.size(), -1);
         int n = 0;
-        check(orbm_search_for_initialization_frames(h_, vbPrevMatched_xy, (float)windowSize, F1.get(), F2.get(), mfNNratio, mbCheckOrientation,
+        DeviceClock clk_;
+        check(orbm_search_for_initialization_frames(handle(), vbPrevMatched_xy, (float)windowSize, F1.get(), F2.get(), mfNNratio, mbCheckOrientation,
                                                     vnMatches12.data(), &n));
         return n;
     }
@@ -256,7 +282,8 @@ public:
     {
         OrbmProjParams pp = {mode, mfNNratio, mbCheckOrientation ? 1 : 0, thDist};
         int n = 0;
-        check(orbm_search_by_projection_frame(h_, &pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, train.get(), tOcc.data(), assign.data(), &n));
+        DeviceClock clk_;
+        check(orbm_search_by_projection_frame(handle(), &pp, q_uvr, q_lvl, qdesc, qangle, qvalid, q_obs_pos, nq, train.get(), tOcc.data(), assign.data(), &n));
         return n;
     }
 
@@ -265,7 +292,7 @@ public:
 
 protected:
     static void check(int rc) { if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBmatcher(HIP): ") + orbx_last_error()); }
-    orbm_t* h_ = nullptr;
+    int device_ = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -372,10 +399,14 @@ public:
     static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;  // ORBmatcher.cc:37-39
     static const int FRAME_GRID_COLS = 64, FRAME_GRID_ROWS = 48;      // Frame.h:36-37
 
-    ORBmatcherT(float nnratio = 0.6f, bool checkOri = true, int device = 0) : flat_(nnratio, checkOri, device) {}
+    // ORBmatcher.cc:41-43: two parameters, nothing else -- the object is a stack temporary in the reference
+    ORBmatcherT(float nnratio = 0.6f, bool checkOri = true, int device = 0)
+        : last(threadScratch(0)), last2(threadScratch(1)), flat_(nnratio, checkOri, device) {}
 
-    // What the last member call handed to the device and got back (flattened arrays + the query -> object index map).
-    // The vectors are reused from call to call; tests feed them to the CPU checker.
+    // What the last member call OF THIS THREAD handed to the device and got back (flattened arrays + the query -> object
+    // index map).  The storage is per thread, not per matcher (the matcher is a temporary; its flattening scratch must
+    // outlive it to be reused): the vectors keep their capacity from call to call, whichever matcher object makes the
+    // call.  Tests feed them to the CPU checker right after a call.
     struct FlatCall {
         std::string fn;
         int mode = 0, thDist = 0, nq = 0, nt = 0, chi2 = 0;
@@ -390,12 +421,13 @@ public:
         const OrbxKeyPoint* tkeys = nullptr; const OrbxKeyPoint* qkeys = nullptr;
         std::vector<uint8_t> tdesc_store, qdesc_store;  // only when the caller's descriptor matrix is not continuous
         const uint8_t* tdesc = nullptr; const float* turight = nullptr;
+        const uint8_t* qdescBlock = nullptr;             // query side given as a whole descriptor matrix (BoW, initialisation, triangulation)
         std::vector<float> tangle, F12; float ex = 0, ey = 0;
         int nmatches = 0;
     };
-    FlatCall last;
+    FlatCall& last;
     // second pass of SearchBySim3 (KF2's points into KF1)
-    FlatCall last2;
+    FlatCall& last2;
 
     // static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)   ORBmatcher.h:45, ORBmatcher.cc:1649-1665
     // ONE pair: eight xor + popcount on the host.  The reference calls this per pair from loops the device entries
@@ -559,8 +591,8 @@ public:
         }
         c.tangle.resize(c.nt);
         for (int t = 0; t < c.nt; t++) c.tangle[t] = F.mvKeys[t].angle;  // :238: the Frame side reads mvKeys, not mvKeysUn
-        c.qfv = FlatFeatVec::from(pKF->mFeatVec); c.tfv = FlatFeatVec::from(F.mFeatVec);
-        const uint8_t* qd = descPtr(pKF->mDescriptors, c.nq, c.qdesc_store);
+        c.qfv.assign(pKF->mFeatVec); c.tfv.assign(F.mFeatVec);
+        const uint8_t* qd = c.qdescBlock = descPtr(pKF->mDescriptors, c.nq, c.qdesc_store);
         c.tdesc = descPtr(F.mDescriptors, c.nt, c.tdesc_store);
         c.nmatches = flat_.SearchByBoW(qd, c.qangle.data(), c.qvalid.data(), c.nq, c.qfv, c.tdesc, c.tangle.data(), nullptr, c.nt, c.tfv,
                                        /*outByTrain=*/true, c.match);
@@ -579,8 +611,8 @@ public:
         c.qvalid.assign(c.nq, 0); c.tvalid.assign(c.nt, 0); c.qangle.resize(c.nq); c.tangle.resize(c.nt);
         for (int i = 0; i < c.nq; i++) { MapPoint* p = vpMapPoints1[i]; c.qvalid[i] = p && !p->isBad(); c.qangle[i] = pKF1->mvKeysUn[i].angle; }
         for (int i = 0; i < c.nt; i++) { MapPoint* p = vpMapPoints2[i]; c.tvalid[i] = p && !p->isBad(); c.tangle[i] = pKF2->mvKeysUn[i].angle; }
-        c.qfv = FlatFeatVec::from(pKF1->mFeatVec); c.tfv = FlatFeatVec::from(pKF2->mFeatVec);
-        const uint8_t* qd = descPtr(pKF1->mDescriptors, c.nq, c.qdesc_store);
+        c.qfv.assign(pKF1->mFeatVec); c.tfv.assign(pKF2->mFeatVec);
+        const uint8_t* qd = c.qdescBlock = descPtr(pKF1->mDescriptors, c.nq, c.qdesc_store);
         c.tdesc = descPtr(pKF2->mDescriptors, c.nt, c.tdesc_store);
         c.nmatches = flat_.SearchByBoW(qd, c.qangle.data(), c.qvalid.data(), c.nq, c.qfv, c.tdesc, c.tangle.data(), c.tvalid.data(), c.nt, c.tfv,
                                        /*outByTrain=*/false, c.match);
@@ -625,7 +657,7 @@ public:
         for (int i = 0; i < c.nt; i++) c.skip2[i] = pKF2->GetMapPoint(i) != NULL;
         c.F12.resize(9);
         for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c.F12[3 * r + k] = at(F12, r, k);
-        c.qfv = FlatFeatVec::from(pKF1->mFeatVec); c.tfv = FlatFeatVec::from(pKF2->mFeatVec);
+        c.qfv.assign(pKF1->mFeatVec); c.tfv.assign(pKF2->mFeatVec);
         c.qkeys = keys(pKF1->mvKeysUn); c.tkeys = keys(pKF2->mvKeysUn);
         const uint8_t* qd = descPtr(pKF1->mDescriptors, c.nq, c.qdesc_store);
         c.tdesc = descPtr(pKF2->mDescriptors, c.nt, c.tdesc_store);
@@ -797,6 +829,7 @@ public:
 
 protected:
     static float RadiusByViewingCos(const float& viewCos) { return viewCos > 0.998 ? 2.5f : 4.0f; }  // :131-137
+    static FlatCall& threadScratch(int which) { static thread_local FlatCall c[2]; return c[which]; }
 
     FlatMatcher flat_;
 

@@ -261,6 +261,16 @@ int orbx_debug_stage_rows(uint8_t* dst, size_t dpitch, const uint8_t* src, size_
 typedef struct orbm_handle orbm_t;
 int orbm_create(int device, orbm_t** out);
 void orbm_destroy(orbm_t* h);
+/* The reference builds an ORBmatcher as a STACK TEMPORARY at every call site (src/Tracking.cc:639, 809, 914, 1242, 1415,
+ * 1454, src/LocalMapping.cc:215, 483, src/LoopClosing.cc:245, 603, MultiMapper.cc:180, 687) holding only (mfNNratio,
+ * mbCheckOrientation) -- include/ORBmatcher.h:96-97.  The device state a search needs (queue, grow-only scratch, pinned
+ * staging block, the pool of frame blocks) therefore belongs to the calling THREAD: this returns the thread's handle for
+ * `device`, made at the thread's first call and released when the thread ends (frames made through it keep it alive).  Its
+ * queue is one of the device's four shared chain streams, not one more queue per thread.  Never pass it to orbm_destroy. */
+int orbm_thread_handle(int device, orbm_t** out);
+/* Allocation counters: device allocations (scratch growth + frame blocks) and pinned allocations of handle h (0 for a
+ * null h), and the number of matcher handles the process has made.  A steady-state loop leaves all three unchanged. */
+int orbm_alloc_stats(orbm_t* h, int64_t* device_allocs, int64_t* host_allocs, int64_t* handles_made);
 
 /* static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)
  * src/ORBmatcher.cc:1649-1665.  dist[nq*nt], row-major. */
@@ -376,7 +386,10 @@ int orbm_search_for_triangulation(orbm_t* h,
  * The tail of Frame::Frame (src/Frame.cc:196-210: UndistortKeyPoints + AssignFeaturesToGrid) run on DEVICE-resident
  * extractor output -- e.g. d_keys = kps + f*cap, d_desc = desc + f*cap*32 from orbx_device_results -- so that the
  * projection searches consume it without a round trip through the host.  The frame copies what it needs (the
- * extractor's result sets are reused two batches later) and belongs to the matcher handle that created it. */
+ * extractor's result sets are reused two batches later) into ONE block taken from the creating handle's pool and given
+ * back by orbm_frame_destroy (from any thread): a Frame per image allocates nothing in steady state, and neither call
+ * waits for the device.  Any matcher handle of the same device may search a frame; the creating handle lives until its
+ * last frame is destroyed. */
 typedef struct orbm_frame orbm_frame_t;
 int orbm_frame_create(orbm_t* h, const OrbxKeyPoint* d_keys, const uint8_t* d_desc, int n,
                       const float K[4], const float D[5], const OrbmGrid* grid, orbm_frame_t** out);

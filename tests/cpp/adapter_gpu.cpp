@@ -97,6 +97,79 @@ int main()
         EXPECT(std::memcmp(f12.data(), of12.data(), (size_t)n * 4) == 0);
         std::printf("device frames: %d / %d features, %d init matches\n", n, n2, nf);
     }
+    // Ownership: matchers are stack temporaries; the device state is the calling thread's.
+    //  * constructing / destroying a matcher makes no handle and no allocation once the thread has searched;
+    //  * four threads building temporaries side by side get the oracle's answer each (their handles share the chain streams);
+    //  * a device frame made in one thread is searched through another thread's handle and destroyed there, after its
+    //    creator's thread -- and with it the creator's thread-local handle -- has ended;
+    //  * frame blocks are recycled: a frame per image allocates nothing in steady state.
+    {
+        orbm_t* mine = nullptr;
+        EXPECT(orbm_thread_handle(0, &mine) == ORBX_OK && mine == m.handle());
+        int64_t a0 = 0, b0 = 0, c0 = 0, a1 = 0, b1 = 0, c1 = 0;
+        std::vector<int32_t> mt;
+        { iORB_SLAM::FlatMatcher w(0.75f, true, 0); w.SearchByBoW(desc.data(), ang.data(), nullptr, n, fq, d2.data(), ang.data(), nullptr, n, ft, true, mt); }
+        orbm_alloc_stats(mine, &a0, &b0, &c0);
+        for (int rep = 0; rep < 20; rep++) {
+            iORB_SLAM::FlatMatcher tmp(0.75f, true, 0);   // the reference's `ORBmatcher matcher(0.75, true);` on the stack
+            const int k = tmp.SearchByBoW(desc.data(), ang.data(), nullptr, n, fq, d2.data(), ang.data(), nullptr, n, ft, true, mt);
+            EXPECT(k == onm && std::memcmp(mt.data(), omatch.data(), (size_t)n * 4) == 0);
+        }
+        orbm_alloc_stats(mine, &a1, &b1, &c1);
+        EXPECT(a0 == a1 && b0 == b1 && c0 == c1);
+        // frames: the first few take blocks, later ones recycle them
+        const OrbxKeyPoint* dk = nullptr; const uint8_t* dd = nullptr;
+        ex(img.data(), W, H, W, kps, desc);
+        ex.lastOnDevice(dk, dd);
+        const float K[4] = {517.3f, 516.5f, 318.6f, 255.3f}, D0[5] = {0, 0, 0, 0, 0};
+        { auto Fa = m.makeFrame(dk, dd, n, K, D0, g); auto Fb = m.makeFrame(dk, dd, n, K, D0, g); }
+        orbm_alloc_stats(mine, &a0, &b0, &c0);
+        for (int rep = 0; rep < 50; rep++) {
+            auto Fa = m.makeFrame(dk, dd, n, K, D0, g);
+            auto Fb = m.makeFrame(dk, dd, n - (rep % 7), K, D0, g);
+            if (rep % 10 == 0) {
+                std::vector<int> f12;
+                const int nf = m.SearchForInitialization(xy.data(), 100, *Fa, *Fa, f12);
+                EXPECT(nf > 50);
+            }
+        }
+        orbm_alloc_stats(mine, &a1, &b1, &c1);
+        EXPECT(a0 == a1 && b0 == b1 && c0 == c1);
+        // threads: each its own handle, the same answers; a frame handed from a thread that ends to one that goes on
+        std::unique_ptr<iORB_SLAM::DeviceFrame> handed;
+        int64_t madeBefore = 0, madeAfter = 0;
+        orbm_alloc_stats(nullptr, nullptr, nullptr, &madeBefore);
+        std::vector<int> tfails(4, 0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < 4; t++)
+            th.emplace_back([&, t] {
+                std::vector<int32_t> mm;
+                for (int rep = 0; rep < 10; rep++) {
+                    iORB_SLAM::FlatMatcher tmp(0.75f, true, 0);
+                    const int k = tmp.SearchByBoW(desc.data(), ang.data(), nullptr, n, fq, d2.data(), ang.data(), nullptr, n, ft, true, mm);
+                    if (k != onm || std::memcmp(mm.data(), omatch.data(), (size_t)n * 4)) tfails[(size_t)t]++;
+                }
+                if (t == 0) { iORB_SLAM::FlatMatcher mk(0.75f, true, 0); handed = mk.makeFrame(dk, dd, n, K, D0, g); }
+            });
+        for (auto& t : th) t.join();
+        orbm_alloc_stats(nullptr, nullptr, nullptr, &madeAfter);
+        EXPECT(madeAfter - madeBefore == 4);   // one handle per thread, not one per matcher object
+        for (int t = 0; t < 4; t++) EXPECT(tfails[(size_t)t] == 0);
+        EXPECT(handed && handed->size() == n);
+        {
+            std::vector<int> f12;
+            auto Fm = m.makeFrame(dk, dd, n, K, D0, g);
+            const int nf = m.SearchForInitialization(xy.data(), 100, *handed, *Fm, f12);   // thread 0's frame through this thread's handle
+            std::vector<int> g12;
+            const int ng = m.SearchForInitialization(xy.data(), 100, *Fm, *Fm, g12);
+            EXPECT(nf == ng && f12 == g12);
+            std::vector<OrbxKeyPoint> un;
+            handed->keysUn(un);
+            EXPECT((int)un.size() == n && std::memcmp(un.data(), kps.data(), (size_t)n * 28) == 0);
+        }
+        handed.reset();   // the last reference to thread 0's handle goes here
+        std::printf("ownership: 20 + 40 matcher temporaries, 100 recycled frames, no handle or allocation made in steady state\n");
+    }
     // FrameSet: two consecutive extractions into two slots, SearchByProjection(Cur, Last) with the identity pose on the
     // device, against the oracle's sequential loop on the downloaded arrays
     {

@@ -25,9 +25,9 @@ class Mat {
 public:
     int rows = 0, cols = 0;
     Mat() {}
-    static Mat f32(int r, int c) { Mat m; m.rows = r; m.cols = c; m.esz = 4; m.buf.reset(new std::vector<uint8_t>((size_t)r * c * 4, 0)); return m; }
-    static Mat u8(int r, int c) { Mat m; m.rows = r; m.cols = c; m.esz = 1; m.buf.reset(new std::vector<uint8_t>((size_t)r * c, 0)); return m; }
-    Mat clone() const { Mat m = *this; if (buf) m.buf.reset(new std::vector<uint8_t>(*buf)); return m; }
+    static Mat f32(int r, int c) { Mat m; m.rows = r; m.cols = c; m.esz = 4; m.buf = std::make_shared<std::vector<uint8_t> >((size_t)r * c * 4, (uint8_t)0); return m; }
+    static Mat u8(int r, int c) { Mat m; m.rows = r; m.cols = c; m.esz = 1; m.buf = std::make_shared<std::vector<uint8_t> >((size_t)r * c, (uint8_t)0); return m; }
+    Mat clone() const { Mat m = *this; if (buf) m.buf = std::make_shared<std::vector<uint8_t> >(*buf); return m; }  // two allocations, like cv::Mat::clone in OpenCV 3 (UMatData + data)
     bool isContinuous() const { return true; }
     template <class T> T& at(int r, int c = 0) { return *reinterpret_cast<T*>(&(*buf)[((size_t)r * cols + c) * esz]); }
     template <class T> const T& at(int r, int c = 0) const { return *reinterpret_cast<const T*>(&(*buf)[((size_t)r * cols + c) * esz]); }

@@ -175,3 +175,23 @@ def test_batch_mode_is_bench_py_s_step(gpu):
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     best = max(a["frames_per_s"], b["frames_per_s"])
     assert abs(best - rec["value"]) / rec["value"] < 0.08, (a["frames_per_s"], b["frames_per_s"], rec["value"])
+
+
+def test_dropin_classes_in_trackings_shape_make_no_device_state_per_matcher(gpu):
+    """examples/tracking_loop: ORBextractor::operator() and ORBmatcher STACK TEMPORARIES per frame, the way Tracking builds them
+    (Tracking.cc:809, 914, 1242).  The program checks every member against the raw C ABI on the same flattened arrays and exits
+    non-zero if the steady-state loop made a matcher handle, a device allocation or a pinned allocation (SURVEY.md 8b
+    "Ownership"); here additionally: a matcher temporary must cost at least 10x less than the round-4 pattern (a device handle
+    per matcher object), and what the adapter adds to the C ABI beyond the reference's own per-MapPoint getters stays small."""
+    import __graft_entry__ as ge
+    exe = ge.build_tracking_loop()
+    out = subprocess.run([exe, "--json", "--frames", "80", "--warmup", "15"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "tracking_loop ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["steady_state"] == {"device_allocs": 0, "pinned_allocs": 0, "matcher_handles": 0, "none_made": True}
+    assert r["features"] == 2000 and r["w"] == 1241
+    for name, m in r["members"].items():
+        assert m["matches_per_frame"] > 100, name
+        assert m["total_us"] * 10 < m["handle_per_object_us"], (name, m)
+        assert m["adapter_us"] - m["reference_getters_us"] < 60.0, (name, m)   # flatten + write-back beyond the reference's own getters
+    assert r["median_motion_model_frame_ms"] < 1.5
