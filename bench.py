@@ -59,6 +59,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of two frames of the last timed step")
     ap.add_argument("--no-tracking-path", action="store_true", help="skip the (untimed) Tracking-shaped matcher measurements")
     ap.add_argument("--no-live-streams", action="store_true", help="skip the (untimed) one-frame-per-robot-per-call measurements (examples/multi_robot)")
+    ap.add_argument("--live-full", action="store_true", help="every live-stream configuration (default: the five the record's targets and DESIGN.md quote)")
+    ap.add_argument("--no-dropin-classes", action="store_true", help="skip the (untimed) Tracking-shaped loop over the drop-in C++ classes (examples/tracking_loop)")
+    ap.add_argument("--side-budget", type=float, default=150.0, help="seconds of wall-clock ALL untimed side blocks together may take (live_streams, dropin_classes, "
+                    "tracking_path, host_path); a block that would start beyond it is skipped and the record says so -- the headline never waits for them longer than this")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--no-replay", action="store_true", help="skip the untimed serialized replay (roofline.isolated); used under rocprofv3 so that its per-kernel averages are those of the timed launches")
     return ap.parse_args(argv)
@@ -192,10 +196,14 @@ def cpu_baseline(cfg, frames, seconds_budget=12.0, max_frames=320, streams_n=8):
     run_stream(seconds_budget, res, 0)
     n1, dt1 = res[0]
     info = host_info()
+    if streams_n <= 0:
+        return {"value": n1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d synthetic %dx%d frames (%.1f s), extract + brute-force match vs previous frame, 1 thread, gcc -O3 -march=native -ffp-contract=off" % (n1, W, H, dt1),
+                "nproc": info["nproc"], "cpu_model": info["cpu_model"]}
     nthr = max(1, min(streams_n, info["nproc"] or 1))
     resn = {}
     t0 = time.perf_counter()
-    th = [threading.Thread(target=run_stream, args=(seconds_budget * 0.75, resn, i)) for i in range(nthr)]  # ctypes releases the GIL
+    th = [threading.Thread(target=run_stream, args=(seconds_budget * 0.4, resn, i)) for i in range(nthr)]  # ctypes releases the GIL
     for t in th:
         t.start()
     for t in th:
@@ -605,7 +613,57 @@ def tracking_path(ex, cfg, frames, dargs, seconds=1.0):
     return out
 
 
-def live_streams(cfg, dev_index=0, frames=600):
+class SideBudget:
+    """One wall-clock allowance for every untimed side block of a run (the side blocks could outlast the
+    driver's limit before a single timed step ran).  A block asks for time before it starts; what it is refused it skips,
+    and the record carries what ran, what was skipped and how long each took."""
+
+    def __init__(self, seconds):
+        self.total = float(seconds)
+        self.t0 = time.time()
+        self.spent = {}
+        self.skipped = []
+
+    def left(self):
+        return self.total - (time.time() - self.t0)
+
+    def allows(self, name, need=5.0):
+        if self.left() >= need:
+            return True
+        self.skipped.append(name)
+        return False
+
+    def charge(self, name, t_start):
+        self.spent[name] = round(self.spent.get(name, 0.0) + time.time() - t_start, 1)
+
+    def record(self):
+        return {"budget_s": self.total, "spent_s": self.spent, "skipped": self.skipped,
+                "what": "wall-clock of the untimed side blocks; none of it is inside the timed region"}
+
+
+def dropin_classes(cfg, budget):
+    """The drop-in CLASSES on the clock (never `value`): examples/tracking_loop -- per frame ORBextractor::operator() and
+    ORBmatcher STACK TEMPORARIES exactly where Tracking builds them (Tracking.cc:809, 914, 1242), on mock Frame / KeyFrame /
+    MapPoint objects at this configuration's size, per-frame median / mean as mono_tum.cc:113-122 prints them.  Per member:
+    total = device (inside the C ABI) + adapter (object-graph walk), the same arrays through the raw C ABI, and the round-4
+    ownership pattern (a device handle per matcher object) beside it; the program fails if its steady-state loop made a
+    matcher handle or a device / pinned allocation."""
+    import __graft_entry__ as ge
+    try:
+        exe = ge.build_tracking_loop()
+        r = subprocess.run([exe, "--json", "--frames", "200", "--warmup", "30", "--w", str(cfg["w"]), "--h", str(cfg["h"]), "--features", str(cfg["nfeat"])],
+                           capture_output=True, text=True, timeout=max(10.0, min(120.0, budget.left())))
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-300:], "rc": r.returncode}
+        d = json.loads(line[-1])
+        d["what"] = "examples/tracking_loop: ORBextractor::operator() + ORBmatcher temporaries per frame in Tracking's shape, mock SLAM objects; never `value`"
+        return d
+    except Exception as e:  # never lose the record over a secondary block
+        return {"error": repr(e)}
+
+
+def live_streams(cfg, dev_index=0, frames=400, budget=None, full=False):
     """The mode the reference actually runs (never `value`): ONE live frame per robot per iteration
     (MultipleRobotsScenario/Examples/Monocular/mono_kitti.cc:80-101 -> Tracking::GrabImageMonocular, Tracking.cc:240-267;
     the search of frame t needs only the pose predicted from frame t-1, Tracking.cc:905-936).  Measured by the native
@@ -628,10 +686,18 @@ def live_streams(cfg, dev_index=0, frames=600):
     env = dict(os.environ)   # (single-GPU runs only: the program takes device 0 of what this process sees)
     keep = ("frames_per_s", "ms_median", "ms_mean", "ms_p99", "keypoints_mean", "matches_mean", "host_us_submit", "host_us_enqueue")
 
-    def run(*extra, n=frames, more_env=None, timeout=240):
+    budget = budget or SideBudget(600.0)
+
+    def run(*extra, n=frames, more_env=None, timeout=120, only_full=False):
+        if only_full and not full:
+            return {"skipped": "--live-full"}
+        if budget.left() < 4.0:
+            budget.skipped.append("live_streams:" + " ".join(str(a) for a in extra))
+            return {"skipped": "side budget spent"}
         try:
             e = dict(env, **more_env) if more_env else env
-            r = subprocess.run(base + ["--frames", str(n), "--warmup", "40"] + [str(a) for a in extra], capture_output=True, text=True, timeout=timeout, env=e)
+            r = subprocess.run(base + ["--frames", str(n), "--warmup", "40"] + [str(a) for a in extra], capture_output=True, text=True,
+                               timeout=max(4.0, min(timeout, budget.left())), env=e)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 return {"error": (r.stderr or r.stdout)[-300:]}
@@ -644,37 +710,37 @@ def live_streams(cfg, dev_index=0, frames=600):
     # box the image pages it in on first use -- minutes, now and then (one refresh run lost its first configuration to the
     # 180 s limit that way).  One short untimed run takes that, with a limit to match.
     t_first = time.time()
-    first = run("--mode", "extract", n=5, timeout=900)
+    first = run("--mode", "extract", n=5, timeout=budget.left())
     t_first = time.time() - t_first
     out = {"what": "examples/multi_robot (C ABI, one thread per robot, B = 1 per call, pinned camera ring unless stated); never `value`",
            "first_run_s": round(t_first, 1), "first_run_ok": "error" not in first,
            "one_robot": {
                "track": run("--mode", "track"),
-               "track_pageable_frames": run("--mode", "track", "--pinned", 0),
-               "track_d2": run("--mode", "track", "--depth", 2),
+               "track_pageable_frames": run("--mode", "track", "--pinned", 0, only_full=True),
+               "track_d2": run("--mode", "track", "--depth", 2, only_full=True),
                # (ORBX_LAT_PRIO=0: the extractor's queue at the matcher's priority -- a high- and a normal-priority queue busy
                # at the same time are time-sliced in ~50 us quanta, tools/live_d2_trace.sh: 2.7 k frames/s instead of 8.2 k)
-               "track_d2_two_queues": run("--mode", "track", "--depth", 2, "--attach", 0, more_env={"ORBX_LAT_PRIO": "0"}),
+               "track_d2_two_queues": run("--mode", "track", "--depth", 2, "--attach", 0, more_env={"ORBX_LAT_PRIO": "0"}, only_full=True),
                # the whole front-end of one Tracking iteration: the chain above + Tracking::SearchLocalPoints' search of 3 000 local
                # MapPoints against the same resident frame, collected one after the other as Tracking needs them
                "track_plus_local_map": run("--mode", "full"),
                "bf": run("--mode", "bf"),
-               "bf_pageable_frames": run("--mode", "bf", "--pinned", 0),
-               "extract": run("--mode", "extract")},
+               "bf_pageable_frames": run("--mode", "bf", "--pinned", 0, only_full=True),
+               "extract": run("--mode", "extract", only_full=True)},
            "robots_on_one_gpu": {}}
     for k in (2, 4, 8):
-        out["robots_on_one_gpu"]["track_%d_threads_x1" % k] = run("--mode", "track", "--robots", k, n=400)
-    out["robots_on_one_gpu"]["track_4_threads_x2_cameras"] = run("--mode", "track", "--robots", 4, "--per-call", 2, n=400)
-    out["robots_on_one_gpu"]["bf_4_threads_x1"] = run("--mode", "bf", "--robots", 4, n=400)
+        out["robots_on_one_gpu"]["track_%d_threads_x1" % k] = run("--mode", "track", "--robots", k, n=300, only_full=(k != 4))
+    out["robots_on_one_gpu"]["track_4_threads_x2_cameras"] = run("--mode", "track", "--robots", 4, "--per-call", 2, n=300)
+    out["robots_on_one_gpu"]["bf_4_threads_x1"] = run("--mode", "bf", "--robots", 4, n=300, only_full=True)
     # more robots than the GPU runs queues: one thread and one blocking call per robot as before, but the frames of the robots
     # waiting together go through ONE chain (include/orbslamm_hub.hpp, orbx_create_live) -- four hubs per GPU
     keep = keep + ("hub_batch_mean",)
-    out["robots_on_one_gpu"]["track_8_threads_x1_hubs_of_2"] = run("--mode", "track", "--robots", 8, "--hub", 2, n=400)
-    out["robots_on_one_gpu"]["track_16_threads_x1_hubs_of_4"] = run("--mode", "track", "--robots", 16, "--hub", 4, n=400)
+    out["robots_on_one_gpu"]["track_8_threads_x1_hubs_of_2"] = run("--mode", "track", "--robots", 8, "--hub", 2, n=300)
+    out["robots_on_one_gpu"]["track_16_threads_x1_hubs_of_4"] = run("--mode", "track", "--robots", 16, "--hub", 4, n=300, only_full=True)
     # the same program's offline-sequence mode (--mode batch: this file's own step through the device-resident entries, one
     # thread + one handle per GPU): the native cross-check of `value`, measured in a process of its own
-    r = run("--mode", "batch", "--steps", 200, "--warmup", 5)
-    out["native_offline_batch"] = {k: r[k] for k in ("frames_per_s", "keypoints_mean", "matches_mean") if k in r} if "error" not in r else r
+    r = run("--mode", "batch", "--steps", 200, "--warmup", 5, only_full=True)
+    out["native_offline_batch"] = {k: r[k] for k in ("frames_per_s", "keypoints_mean", "matches_mean") if k in r} if ("error" not in r and "skipped" not in r) else dict(r)
     out["native_offline_batch"]["what"] = "examples/multi_robot --mode batch: 64 frames per step, 8 batches resident in HBM, 200 steps -- bench.py's `value` from the C++ caller"
     t = out["one_robot"]["track"]
     if "ms_median" in t:
@@ -750,8 +816,17 @@ def run_rank(args):
     # time and every queue a process holds takes part in the rotation, idle or not -- docs/experiments.md, round 4.)
     # It is no part of the timed region either way.
     ls = None
-    if world == 1 and not distributed and not os.environ.get("ORBX_BENCH_EXTRACTOR") and not args.no_live_streams and not args.no_tracking_path:
-        ls = live_streams(cfg, 0)
+    dic = None
+    budget = SideBudget(args.side_budget)
+    alone = world == 1 and not distributed and not os.environ.get("ORBX_BENCH_EXTRACTOR")
+    if alone and not args.no_live_streams and not args.no_tracking_path and budget.allows("live_streams", 20.0):
+        t_blk = time.time()
+        ls = live_streams(cfg, 0, budget=budget, full=args.live_full)
+        budget.charge("live_streams", t_blk)
+    if alone and not args.no_dropin_classes and not args.no_tracking_path and budget.allows("dropin_classes", 10.0):
+        t_blk = time.time()
+        dic = dropin_classes(cfg, budget)   # (a process of its own, like the robots above: the classes as a maintainer's binary runs them)
+        budget.charge("dropin_classes", t_blk)
     ndev = device_count()
     if backend == "nccl" and distributed and local_rank >= max(ndev, 1):
         sys.stderr.write("bench.py: rank %d has no GPU of its own (%d visible); one process per GPU\n" % (rank, ndev))
@@ -870,11 +945,17 @@ def run_rank(args):
     # hardware queues of their own), and with more than ~4 queues alive in the process the GPU rotates them -- the
     # batched extraction + search step then reads 113 k pairs/s instead of 150 k (idle queues count)
     trk = None
-    if real and world == 1 and not args.no_tracking_path and hasattr(ex, "extract_match_host"):
+    if real and world == 1 and not args.no_tracking_path and hasattr(ex, "extract_match_host") and budget.allows("tracking_path", 10.0):
+        t_blk = time.time()
         trk = tracking_path(ex, cfg, first_batch, dargs)
+        budget.charge("tracking_path", t_blk)
     hp = None
-    if real and not args.no_host_path and hasattr(ex, "extract_match_host") and (world == 1 or distributed):
+    # (N > 1: every rank measures its own link at the same time and the figures ride in the gathered record, so the block is
+    # not optional there)
+    if real and not args.no_host_path and hasattr(ex, "extract_match_host") and (distributed or budget.allows("host_path", 10.0)):
+        t_blk = time.time()
         hp = host_path(ex, cfg, first_batch)
+        budget.charge("host_path", t_blk)
     gathered, dt_max = streams.gather_stats((B * args.steps, len(kps_last), nmatch_last, dt,
                                              -1.0 if par is None else float(par["ok"]),
                                              0.0 if hp is None else hp.get("pipelined_fps", 0.0),
@@ -913,7 +994,19 @@ def run_rank(args):
             "config": {"workload": cfg["workload"], "name": args.config,
                        "frames_per_step_per_gpu": B, "streams": world, "parallelism": "1 independent stream per GPU",
                        "resident_pool_frames_per_gpu": pool * B, "resident_pool_mb_per_gpu": pool * B * STRIDE * H / 1e6,
-                       "pool_validation_steps_before_warmup": pool},
+                       "pool_validation_steps_before_warmup": pool,
+                       # SURVEY.md 8(d) asks for wall-clock including H2D of frames and D2H of results (the reference times the whole
+                       # TrackMonocular call, mono_tum.cc:80-97); `value` is the HBM-resident rate the task's contract defines, and the
+                       # PCIe-inclusive figures of the same workload ride here, as scalars, so that they survive every parser:
+                       "io_in_timed_region": False,
+                       "host_inclusive_fps_pinned": None if hp is None else hp.get("pipelined_pinned_fps"),
+                       "host_inclusive_fps_pageable": None if hp is None else hp.get("pipelined_fps"),
+                       "host_inclusive_one_frame_per_call_ms": None if hp is None else hp.get("b1_ms_median"),
+                       "dropin_classes_tracking_frame_ms_median": None if not dic or "error" in dic else dic.get("median_motion_model_frame_ms"),
+                       # what the timed interval is (orbslamm_amd/streams.py: timed_region): records of rounds <= 3 had the closing
+                       # barrier inside the interval and, at N > 1, RCCL up before it -- not comparable silently
+                       "timed_region_version": 2, "closing_barrier_inside_interval": False,
+                       "rccl_up_before_timed_region": bool(distributed and backend == "nccl" and os.environ.get("ORBX_DIST_EAGER_NCCL") == "1")},
             "stats_gather": streams.stats_transport() if distributed else "none (single process)",
             "keypoints_last_frame": [int(g[1]) for g in gathered],
             "matches_last_frame": [int(g[2]) for g in gathered],
@@ -1017,8 +1110,15 @@ def run_rank(args):
         out["replayed_pmc"] = replay
         if ls is not None:
             out["live_streams"] = ls
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, first_batch)
+        if dic is not None:
+            out["dropin_classes"] = dic
+        out["side_blocks"] = budget.record()
+        if not args.no_cpu_baseline:
+            # the CPU figure beside EVERY number.  N = 1: ~12 s on one thread + the one-thread-per-stream leg;
+            # N > 1 (rank 0, the other ranks wait in finalize's barrier): a 6 s one-thread sample, so that a scaling sweep
+            # does not spend its time on the host
+            cpu_s = float(os.environ.get("ORBX_BENCH_CPU_SECONDS", "12.0" if world == 1 else "6.0"))   # (the CPU suite asks for less)
+            out["cpu_baseline"] = cpu_baseline(cfg, first_batch, seconds_budget=cpu_s) if world == 1 else cpu_baseline(cfg, first_batch, seconds_budget=cpu_s, streams_n=0)
         line = json.dumps(out) + "\n"
         if json_fd is not None:
             os.write(json_fd, line.encode())

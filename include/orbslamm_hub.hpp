@@ -76,8 +76,9 @@ public:
             if ((rc = orbm_frameset_create(m_, nslots_, cap_, c.K, c.D, &g, bounds, sf, orbx_levels(ex_), &fs_))) { close(); return rc; }
             if ((rc = orbm_frameset_attach(fs_, ex_))) { close(); return rc; }
         }
-        for (int s = 0; s < 4 * kMaxCameras; s++) slotCam_[s] = -1;
+        for (int s = 0; s < 4 * kMaxCameras; s++) { slotCam_[s] = -1; slotSeq_[s] = 0; }
         for (int j = 0; j < kMaxCameras; j++) { lastSlot_[j] = -1; seq_[j] = 0; lastN_[j] = 0; req_[j].state.store(0); }
+        cursor_ = 0; pendingTicket_ = -1;   // (a hub reopened with another camera count starts its ring afresh)
         return ORBX_OK;
     }
 
@@ -236,14 +237,21 @@ private:
             const int slot0 = cursor_;
             cursor_ += B;
             rc = orbm_frameset_build_from_extractor(fs_, slot0, ex_);
+            for (int p = 0; p < B; p++) pairOf[p] = -1;
             for (int p = 0; p < B && !rc; p++) {
                 const int j = cams[p], ls = lastSlot_[j];
-                pairOf[p] = -1;
                 const bool havePrev = ls >= 0 && slotCam_[ls] == j && slotSeq_[ls] == seq_[j] - 1 && (ls < slot0 || ls >= slot0 + B);
                 if (havePrev) { cur[np] = slot0 + p; last[np] = ls; pairOf[p] = np++; }
             }
-            for (int p = 0; p < B; p++) { const int j = cams[p]; slotCam_[slot0 + p] = j; slotSeq_[slot0 + p] = seq_[j]; lastSlot_[j] = slot0 + p; seq_[j]++; }
             if (!rc && np > 0) rc = orbm_track_frames(fs_, &cfg_.pp, cfg_.th, cur, last, np);
+            // the ring remembers a frame only if its Frame tail was built and its search went out: after a failed batch the
+            // cameras' next frames have no previous frame (nmatches = -1) instead of one that was never built
+            for (int p = 0; p < B; p++) {
+                const int j = cams[p];
+                if (!rc) { slotCam_[slot0 + p] = j; slotSeq_[slot0 + p] = seq_[j]; lastSlot_[j] = slot0 + p; }
+                else { slotCam_[slot0 + p] = -1; lastSlot_[j] = -1; }
+                seq_[j]++;
+            }
         }
         OrbxBatchView v{};
         if (!rc) rc = orbx_collect_view(ex_, ticket, &v);

@@ -107,6 +107,21 @@ static inline void cpu_relax()
 #endif
 }
 
+// Waits for a flag a kernel raises in coherent pinned memory behind a call's results: a tight poll first (the common case:
+// microseconds), then a yielding poll for up to five seconds.  Only after that does the caller fall back to synchronising
+// the stream -- which, for the chain streams several handles share, would also wait for the OTHER handles' work queued
+// behind this call's: a late chain (a profiler, an oversubscribed host) must not turn into cross-robot coupling.
+static inline bool wait_flag(volatile int32_t* flag, int32_t want)
+{
+    for (int spin = 0; spin < 400000; spin++) { if (*flag == want) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; } cpu_relax(); }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) {
+        for (int spin = 0; spin < 256; spin++) { if (*flag == want) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; } cpu_relax(); }
+        std::this_thread::yield();
+    }
+    return false;
+}
+
 static inline int cv_round(double v) { return (int)lrint(v); }  // cvRound: half to even
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 

@@ -69,6 +69,49 @@ def test_a_failing_rank_fails_the_launch(tmp_path):
     assert "rank 1 failed" in out.stderr
 
 
+@pytest.mark.timeout(300)
+def test_two_rank_record_carries_the_cpu_baseline_and_the_interval_stamp(tmp_path):
+    """the CPU figure beside EVERY number -- the N > 1 record too (rank 0 times a bounded one-thread
+    sample of the oracle after the gather; round 4 emitted it at N = 1 only)."""
+    args = [a for a in ARGS if a != "--no-cpu-baseline"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True,
+                         env=_env(tmp_path, ORBX_BENCH_CPU_SECONDS="1.0"), cwd=ROOT, timeout=280)
+    rec = _check_record(out, tmp_path)
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "frames/s" and cb["value"] > 1 and "640x480" in cb["sample"]
+    assert "one_thread_per_stream" not in cb   # the threaded leg is the N = 1 record's
+    c = rec["config"]
+    assert c["io_in_timed_region"] is False and c["timed_region_version"] == 2 and c["closing_barrier_inside_interval"] is False
+    assert c["rccl_up_before_timed_region"] is False and rec["stats_gather"] == "gloo all_gather"
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_eight_disjoint_streams_one_record(tmp_path):
+    """BASELINE.json configs[4] without the hardware: `bench.py --gpus 8` the way the driver invokes it, eight ranks over
+    gloo on a free port, the stub standing in for the GPUs.  Eight different camera streams on eight different devices,
+    ONE record, with `roofline` and `cpu_baseline` in it (MultipleRobotsScenario/Examples/Monocular/mono_kitti.cc:80-101:
+    eight robots, nothing shared but the counters)."""
+    args = [a for a in ARGS if a != "--no-cpu-baseline"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + args, capture_output=True, text=True,
+                         env=_env(tmp_path, ORBX_BENCH_STUB_DEVICES="8", ORBX_BENCH_CPU_SECONDS="1.0", ORBX_BENCH_STUB_PROFILE="1"), cwd=ROOT, timeout=550)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[:500]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["streams"] == 8 and rec["scaling"] == "weak"
+    assert rec["keypoints_last_frame"] == [1500 + r for r in range(8)] and rec["matches_last_frame"] == [700 + r for r in range(8)]
+    dumps = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(8)]
+    assert [d["device"] for d in dumps] == list(range(8)) and all(d["world"] == 8 for d in dumps)
+    assert len({tuple(d["uploads"]) for d in dumps}) == 8            # eight disjoint streams
+    assert all(d["steps"] == 3 + 2 + 6 for d in dumps)
+    # whole-job frames over the slowest rank (rank 7 sleeps 16 ms per step)
+    assert rec["ms_per_step"] >= 16.0 * 0.9 and abs(rec["value"] - 8 * 4 * 6 / (rec["ms_per_step"] * 6 / 1e3)) < 1e-6 * rec["value"]
+    assert rec["cpu_baseline"]["value"] > 1 and rec["cpu_baseline"]["cores"] == 1
+    r = rec["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert rec["stats_gather"] == "gloo all_gather"   # (the GPU box: "rccl all_gather ..." -- tests/test_gpu_bench_contract.py)
+
+
 def test_world_size_must_match_gpus(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS, capture_output=True, text=True,
                          env=_env(tmp_path, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, timeout=120)

@@ -23,8 +23,10 @@ def run_bench(extra_env, extra_args=()):
     env = dict(os.environ)
     env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29537", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     env.update(extra_env)
+    # (the live-stream / drop-in / tracking side blocks are a dozen sub-processes: one dedicated test below keeps them, the
+    # contract tests do not pay for them four times over -- round 4's suite took 695 s at the driver that way)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-replay",
-           "--no-host-path", "--pool", "2"]
+           "--no-host-path", "--no-live-streams", "--no-tracking-path", "--pool", "2"]
     return subprocess.run(cmd + list(extra_args), capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
 
 
@@ -59,7 +61,7 @@ def test_self_launch_one_rank_per_visible_gpu(gpu):
     """`python3 bench.py --gpus N` the way the driver invokes it (no RANK/WORLD_SIZE), N = every visible GPU: bench.py
     launches its own ranks over RCCL.  On a 1-GPU box this is the plain single-process run."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpu), "--steps", "20", "--warmup", "2",
-           "--no-cpu-baseline", "--no-replay", "--no-host-path", "--pool", "2"]
+           "--no-cpu-baseline", "--no-replay", "--no-host-path", "--no-live-streams", "--no-tracking-path", "--pool", "2"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=_plain_env(), cwd=ROOT, timeout=850)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.splitlines()
@@ -97,3 +99,34 @@ def test_c2_config_has_a_bench_line(gpu):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout)
     assert "640x480" in rec["metric"] and rec["config"]["name"] == "c2" and rec["keypoints_last_frame"][0] > 500
+
+
+@pytest.mark.timeout(600)
+def test_default_record_carries_the_side_blocks_under_one_budget(gpu):
+    """the record the DRIVER gets (no --no-* flags but the CPU baseline's): the side blocks run under one wall-clock budget
+    and say what they took; SURVEY.md 8(d)'s PCIe-inclusive figures and the timed-region stamp ride in `config` as scalars;
+    the drop-in classes' Tracking-shaped loop is in the record and made no device state per matcher object."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--pool", "4", "--side-budget", "120"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=_plain_env(), cwd=ROOT, timeout=550)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout)
+    sb = rec["side_blocks"]
+    assert sb["budget_s"] == 120 and sum(sb["spent_s"].values()) <= 150 and set(sb["spent_s"]) >= {"live_streams", "dropin_classes", "tracking_path", "host_path"}
+    c = rec["config"]
+    assert c["io_in_timed_region"] is False and c["timed_region_version"] == 2 and c["closing_barrier_inside_interval"] is False
+    assert c["host_inclusive_fps_pinned"] > 20000 and c["host_inclusive_fps_pageable"] > 20000 and rec["value"] > c["host_inclusive_fps_pinned"]
+    d = rec["dropin_classes"]
+    assert d["steady_state"]["none_made"] is True and 0 < d["median_motion_model_frame_ms"] < 1.5 == (c["dropin_classes_tracking_frame_ms_median"] < 1.5) * 1.5
+    assert rec["live_streams"]["one_robot"]["track"]["ms_median"] < 0.5
+    assert rec["parity_check"]["ok"] is True
+
+
+@pytest.mark.timeout(300)
+def test_side_budget_of_zero_skips_every_side_block_and_keeps_the_headline(gpu):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-replay", "--pool", "2", "--side-budget", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=_plain_env(), cwd=ROOT, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout)
+    assert rec["value"] > 50000 and rec["parity_check"]["ok"] is True
+    assert set(rec["side_blocks"]["skipped"]) >= {"live_streams", "dropin_classes", "tracking_path", "host_path"}
+    assert "live_streams" not in rec and "host_path" not in rec and rec["config"]["host_inclusive_fps_pinned"] is None
