@@ -340,6 +340,70 @@ __device__ __forceinline__ int arc_min_of_max(const int (&d)[16])
     return min(min3i(a5[0], a5[1], a5[2]), min3i(a5[3], a5[4], m9[15]));
 }
 
+// Round 5: the same window minima two ring pixels per instruction.  gfx950's v_pk_minimum3_f16 / v_pk_maximum3_f16
+// (IEEE-754-2019 minimum / maximum on two f16 lanes) issue at the full VALU rate, and on bytes widened to 16 bits they ARE
+// the integer min3 / max3: positive f16 bit patterns order like the integers they spell, 0..255 are denormals, and the
+// kernel's mode keeps f16 denormals (tools/ubench/pk_min3_rate.hip: all 3 x 2^24 byte triples exact, 4.8 cycles per wave
+// instruction -- v_min3_i32's rate; v_min3_u16, the integer spelling, takes 8.5).  Ring pixel k rides with its antipode:
+// X[k] = p[k] | p[k+8] << 16, so "index + 8" is an exchange of the two halves, which VOP3P's op_sel does for free in the
+// operand fetch -- the 16 windows of three are 8 instructions, the 16 windows of nine 8 more, the fold over them 5.
+// 8 (pairing) + 21 instead of 40 per visit; the visit's other ~25 instructions (list entry, addresses, ballot, stores) stay.
+#ifndef ORBX_FAST_PK
+#define ORBX_FAST_PK 1
+#endif
+// operand j's halves are exchanged when bit j of SW is set (op_sel = low lane's source half, op_sel_hi = high lane's)
+template <int SW> __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    if (SW == 0) asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (SW == 4) asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (SW == 6) asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    static_assert(SW == 0 || SW == 2 || SW == 4 || SW == 6, "exchange masks in use");
+    return r;
+}
+template <int SW> __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    if (SW == 0) asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (SW == 4) asm("v_pk_maximum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (SW == 6) asm("v_pk_maximum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_maximum3_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    static_assert(SW == 0 || SW == 2 || SW == 4 || SW == 6, "exchange masks in use");
+    return r;
+}
+// max over the 16 arcs of 9 of the min over the arc (MINMAX = true) or min of max (false), of the ring in r[]
+template <bool MAXMIN> __device__ __forceinline__ int arc_fold_pk(const int (&r)[16])
+{
+    uint32_t X[8], M3[8], M9[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) X[k] = (uint32_t)r[k] | ((uint32_t)r[k + 8] << 16);
+#define ORBX_IN(SW, a, b, c) (MAXMIN ? pk_min3<SW>(a, b, c) : pk_max3<SW>(a, b, c))
+#define ORBX_OUT(SW, a, b, c) (MAXMIN ? pk_max3<SW>(a, b, c) : pk_min3<SW>(a, b, c))
+    // windows of three: M3[k] = (m3[k], m3[k+8]); X(j) for j >= 8 is X[j-8] with its halves exchanged
+#pragma unroll
+    for (int k = 0; k < 6; k++) M3[k] = ORBX_IN(0, X[k], X[k + 1], X[k + 2]);
+    M3[6] = ORBX_IN(4, X[6], X[7], X[0]);
+    M3[7] = ORBX_IN(6, X[7], X[0], X[1]);
+    // windows of nine: M9[k] = (m9[k], m9[k+8]) = three windows of three, 3 apart
+    M9[0] = ORBX_IN(0, M3[0], M3[3], M3[6]);
+    M9[1] = ORBX_IN(0, M3[1], M3[4], M3[7]);
+    M9[2] = ORBX_IN(4, M3[2], M3[5], M3[0]);
+    M9[3] = ORBX_IN(4, M3[3], M3[6], M3[1]);
+    M9[4] = ORBX_IN(4, M3[4], M3[7], M3[2]);
+    M9[5] = ORBX_IN(6, M3[5], M3[0], M3[3]);
+    M9[6] = ORBX_IN(6, M3[6], M3[1], M3[4]);
+    M9[7] = ORBX_IN(6, M3[7], M3[2], M3[5]);
+    const uint32_t A = ORBX_OUT(0, M9[0], M9[1], M9[2]);
+    const uint32_t B = ORBX_OUT(0, M9[3], M9[4], M9[5]);
+    const uint32_t C = ORBX_OUT(0, M9[6], M9[7], A);
+    const uint32_t D = ORBX_OUT(4, B, C, B);      // low lane: B.lo, C.lo, B.hi
+    const uint32_t E = ORBX_OUT(2, D, C, D);      // low lane: that and C.hi
+#undef ORBX_IN
+#undef ORBX_OUT
+    return (int)(E & 0xFFFFu);
+}
+
 // one side only, on the ring's raw bytes (no difference per ring pixel):
 //   dark arcs   S = max_arc min_k (v - p_k) = v - min_arc max_k p_k
 //   bright arcs S = max_arc min_k (p_k - v) = max_arc min_k p_k - v
@@ -347,13 +411,21 @@ template <int TSB> __device__ __forceinline__ int fast_S_dark(const uint8_t* __r
 {
     int r[16];
     ring_load<TSB>(p, r);
+#if ORBX_FAST_PK
+    return max((int)p[0] - arc_fold_pk<false>(r), 0);
+#else
     return max((int)p[0] - arc_min_of_max(r), 0);
+#endif
 }
 template <int TSB> __device__ __forceinline__ int fast_S_bright(const uint8_t* __restrict__ p)
 {
     int r[16];
     ring_load<TSB>(p, r);
+#if ORBX_FAST_PK
+    return max(arc_fold_pk<true>(r) - (int)p[0], 0);
+#else
     return max(arc_max_of_min(r) - (int)p[0], 0);
+#endif
 }
 
 // both sides (the cell whose one-sided lists would not fit)
