@@ -240,6 +240,9 @@ constexpr int kMfmaRowsPerBlock = 64 * kMfmaWaves;
 constexpr int kMfmaEmpty = 0x7FFFFFFF;                 // absolute keys (H << 16 | j)
 constexpr int kMfmaEmptyRel = 0x7F7FFFFF;              // running keys: FLT_MAX (stays FLT_MAX under "- 16")
 constexpr int kMfmaTileBytes = 32 * kMfmaDescBytes;    // 4 KiB: one global_load_lds_dwordx4 per thread
+#ifndef ORBM_XCD_RUN
+#define ORBM_XCD_RUN 1
+#endif
 #ifndef ORBM_MFMA_RING
 #define ORBM_MFMA_RING 16
 #endif
@@ -268,9 +271,17 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
     const int qslot0 = acc.qslot0, tslot0 = acc.tslot0;
     extern __shared__ uint4 tileB[];  // [kMfmaRing][256]
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, so the query blocks of one frame
-    // pair are given to one XCD and share that frame's train tiles in its L2
+    // pair are given to one XCD and share that frame's train tiles in its L2 -- and (round 5) an XCD takes a RUN of
+    // consecutive pairs, whose slots overlap: 41.9 -> 25.0 MB of HBM traffic per 64-pair step, 0.054 -> 0.050 ms alone
+    // (profiles/r05_match_xcd_ab.txt; 18.4 MB of +-1 descriptors + the keypoint angles and the tables is the floor)
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+#if ORBM_XCD_RUN
+    // an XCD takes a RUN of consecutive frame pairs: pair f reads slots f (train) and f + 1 (queries), pair f + 1 slots
+    // f + 1 and f + 2 -- with pairs dealt round-robin every slot is fetched into two L2s
+    const int f = xcd * ((nframes + 7) >> 3) + k / nqb;
+#else
     const int f = (k / nqb) * 8 + xcd;
+#endif
     if (f >= nframes) return;
     const int nq = count[qslot0 + f], nt = count[tslot0 + f];
     const int q0 = (k % nqb) * kMfmaRowsPerBlock;

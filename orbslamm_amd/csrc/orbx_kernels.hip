@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const int Sx = fast_S_dark<TSB>(tb + pos);
                 const bool corner = act && Sx > th;
                 const uint64_t bal = ballot64(Sx > th) & tail_mask(nD - i0);
-                if (corner) { smapD[(e >> 7) * smapPitch + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+                if (corner) { smapD[__mul24(e >> 7, smapPitch) + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
                 nC += __popcll(bal);
             }
             for (int i0 = 0; i0 < nBt; i0 += 64) {
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const int Sx = fast_S_bright<TSB>(tb + pos);
                 const bool corner = act && Sx > th;
                 const uint64_t bal = ballot64(Sx > th) & tail_mask(nBt - i0);
-                if (corner) { smapD[(e >> 7) * smapPitch + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+                if (corner) { smapD[__mul24(e >> 7, smapPitch) + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
                 nC += __popcll(bal);
             }
         } else {
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const int Sx = fast_S<TSB>(tb + pos);
                 const bool corner = act && Sx > th;
                 const uint64_t bal = ballot64(Sx > th) & tail_mask(npx - i0);
-                if (corner) { smapD[(e >> 7) * smapPitch + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
+                if (corner) { smapD[__mul24(e >> 7, smapPitch) + (e & 0x7F)] = (uint8_t)Sx; list[nC + lanes_below(bal)] = (uint16_t)e; }
                 nC += __popcll(bal);
             }
         }
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
         for (int i0 = 0; i0 < nC; i0 += 64) {
             const int i = i0 + lane;
             const int e = i < nC ? list[i] : 0;
-            const uint8_t* sp = smapD + (e >> 7) * smapPitch + (e & 0x7F);
+            const uint8_t* sp = smapD + __mul24(e >> 7, smapPitch) + (e & 0x7F);
             const uint8_t* up = sp - smapPitch;
             const uint8_t* dn = sp + smapPitch;
             const int sc = sp[0];
