@@ -351,6 +351,9 @@ __device__ __forceinline__ int arc_min_of_max(const int (&d)[16])
 #ifndef ORBX_FAST_PK
 #define ORBX_FAST_PK 1
 #endif
+#ifndef ORBX_BRIEF_PK
+#define ORBX_BRIEF_PK 1   // k_orient_desc: the steered BRIEF coordinates on packed fp32
+#endif
 // operand j's halves are exchanged when bit j of SW is set (op_sel = low lane's source half, op_sel_hi = high lane's)
 template <int SW> __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -1924,13 +1927,36 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     const uint32_t adj = (uint32_t)((wave * 4 + q) * (PROWS * PDW * 4) + PR * (PDW * 4) + PR) - 0x400000u * (uint32_t)(PDW * 4) - 0x4B400000u;
     static_assert(PDW * 4 == 40, "row pitch is an inline constant of the mad below");
     uint32_t myWord = 0;
+#if ORBX_BRIEF_PK
+    // Round 5: the rotation of a sample point as four packed-fp32 instructions instead of eight scalar ones.  v_pk_mul_f32 /
+    // v_pk_add_f32 issue at the full VALU rate on gfx950 (tools/ubench/pk_min3_rate.hip) and round each lane like their
+    // scalar forms; op_sel broadcasts x (or y) to both lanes and exchanges (cos, sin), neg_lo turns the low lane's factor
+    // into -sin -- x a - y b is x a + (-(y b)) bit for bit, signed zeros included.
+    //   U = (x a, x b), V = (-(y b), y a), W = U + V = (x a - y b, x b + y a), Z = W + 1.5 * 2^23 = (column, row) bits
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v AB = {a, b}, KR = {kRnd, kRnd};
+    auto rot = [&](const f2v p, int& rx, int& ry) {
+        f2v U, V, W, Z;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(U) : "v"(p), "v"(AB));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(V) : "v"(p), "v"(AB));
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(W) : "v"(U), "v"(V));
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(Z) : "v"(W), "v"(KR));
+        rx = __float_as_int(Z.x); ry = __float_as_int(Z.y);
+    };
+#endif
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         const float4 pt = spat[ql + 16 * t];
+#if ORBX_BRIEF_PK
+        int rx0, ry0, rx1, ry1;
+        rot(f2v{pt.x, pt.y}, rx0, ry0);
+        rot(f2v{pt.z, pt.w}, rx1, ry1);
+#else
         const int ry0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)), kRnd));
         const int rx0 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), kRnd));
         const int ry1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), kRnd));
         const int rx1 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)), kRnd));
+#endif
         uint32_t o0, o1;
         asm("v_mad_i32_i24 %0, %1, 40, %2" : "=v"(o0) : "v"(ry0), "v"(rx0));
         asm("v_mad_i32_i24 %0, %1, 40, %2" : "=v"(o1) : "v"(ry1), "v"(rx1));
