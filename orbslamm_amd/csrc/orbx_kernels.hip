@@ -1738,6 +1738,33 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 constexpr int kKpPerBlock = 16;
 struct KpBlocks { int32_t base[ORBX_MAXL + 1]; };  // block index -> level (kKpPerBlock keypoints per block)
 
+// The blurred patch a keypoint's 512 steered samples can reach is a DISC, not the 39 x 40 rectangle round 4 fetched: a
+// pattern point at radius r lands, rotated by any angle and rounded, within |Y| <= r + 0.5 and, in row Y, within
+// |X| <= sqrt(r^2 - (|Y| - 0.5)^2) + 0.5; the pattern's largest radius is 18.385 (13, 13), so rows +-19 are never read and
+// row Y needs |X| <= kDiscHalf[|Y|] (tests/test_oracle_invariants.py recomputes the table from the pattern).  On the
+// kernel's grid of dwords from byte cx - 18 that is 308 of 370 (row, dword) items: FIVE gather loads per keypoint
+// instead of seven (a load instruction costs the CU's memory pipe ~7.5 cycles and ~1.1 more per cache line it touches,
+// tools/orient_npi_exp.sh; the kernel is bound by exactly that).  The LDS patch keeps its rectangular 40-byte rows --
+// a test's address stays one v_mad -- the slots outside the disc are simply never written or read.
+constexpr int kDiscR = 18;
+constexpr int kDiscHalf[kDiscR + 1] = {18, 18, 18, 18, 18, 18, 18, 17, 17, 16, 16, 15, 14, 13, 12, 11, 10, 8, 6};
+constexpr int kDiscLoads = 5;
+struct DiscItems { uint16_t rc[kDiscLoads * 64]; int n; };   // row << 4 | dword of item t; the tail repeats the last item
+constexpr DiscItems make_disc_items()
+{
+    DiscItems d{};
+    int n = 0;
+    for (int r = 0; r <= 2 * kDiscR; r++) {
+        const int ay = r < kDiscR ? kDiscR - r : r - kDiscR, h = kDiscHalf[ay];
+        for (int c = (kDiscR - h) / 4; c <= (kDiscR + h) / 4; c++) d.rc[n++] = (uint16_t)(r << 4 | c);
+    }
+    d.n = n;
+    for (int t = n; t < kDiscLoads * 64; t++) d.rc[t] = d.rc[n - 1];
+    return d;
+}
+__device__ const DiscItems kDisc = make_disc_items();
+static_assert(make_disc_items().n <= kDiscLoads * 64 && make_disc_items().n > (kDiscLoads - 1) * 64, "five loads, not four");
+
 // Four keypoints per wave, one per quarter-wave (16 lanes): about half of a keypoint's instructions are
 // quarter-uniform (level and slot bookkeeping, fastAtan2, the binary64 sin/cos, the keypoint record) and cost a
 // full wave instruction however many lanes need them, so one wave now pays them for four keypoints.
@@ -1762,7 +1789,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     OSTAMP();
     __shared__ float4 spat[256];           // 256 tests x (x0, y0, x1, y1)
     __shared__ uint32_t swu[256], sw1[256];  // per item: byte weights u + 16 (0 outside the disc), disc flags
-    constexpr int PR = 19, PDW = 10, PROWS = 2 * PR + 1;  // blurred patch: rows cy-19 .. cy+19, bytes cx-19 .. cx+20
+    constexpr int PR = kDiscR, PDW = 10, PROWS = 2 * PR + 1;  // blurred patch: rows cy-18 .. cy+18, bytes cx-18 .. cx+21, of which the disc is fetched
     __shared__ uint32_t spatch[kKpPerBlock][PROWS * PDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, ql = lane & 15;
@@ -1790,7 +1817,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
         totalAll += c;
     }
     if (bx == 0 && tid == 0) outCount[f] = totalAll < g->maxKp ? totalAll : g->maxKp;
-    asm volatile("" : "+v"(pk), "+v"(um));  // landed here: no compiler-tracked load is in flight next to the untracked ones below
+    // the disc's (row, dword) items of this lane, 64 per load (the items past the disc's end repeat the last one: same
+    // address, same LDS slot, so neither the loads nor the stores need a predicate)
+    int ditem[kDiscLoads];
+#pragma unroll
+    for (int i = 0; i < kDiscLoads; i++) ditem[i] = kDisc.rc[64 * i + lane];
+    asm volatile("" : "+v"(pk), "+v"(um), "+v"(ditem[0]), "+v"(ditem[1]), "+v"(ditem[2]), "+v"(ditem[3]), "+v"(ditem[4]));  // landed here: no compiler-tracked load is in flight next to the untracked ones below
+    static_assert(kDiscLoads == 5, "operand list above");
     const int o = before + idx;
     const bool active = idx < mine && o < g->maxKp;   // uniform over the quarter
     const bool anyActive = __builtin_amdgcn_ballot_w64(active) != 0;
@@ -1808,8 +1841,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     // (row, dword) map is then the same for every load, the keypoint's origin is a scalar (v_readlane) and the loads
     // take the SGPR-base form -- no per-load vector address arithmetic (it was a quarter of this kernel's instructions).
     //  * IC_Angle patch: rows cy-15 .. cy+16 x 8 dwords from cx-16, 8 rows per load (row cy+16 carries zero weights)
-    //  * blurred patch:  rows cy-19 .. cy+19 x 10 dwords from cx-19, 6 rows per load on lanes 0..59; it does not depend
-    //    on the angle, so it is in flight during the moments and lands in LDS before the trigonometry.
+    //  * blurred patch:  the disc of rows cy-18 .. cy+18 the steered tests can reach (kDisc: 308 dwords, five loads); it
+    //    does not depend on the angle, so it is in flight during the moments and lands in LDS before the trigonometry.
     // (16 bytes per lane -- 12 loads instead of 44 -- is slower: the patch origins have byte alignment, and what bounds
     // the kernel is the ~90 cache lines a keypoint touches, not the number of load instructions.)
     uint32_t dw[4][4];
@@ -1822,21 +1855,24 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
             for (int j = 0; j < 4; j++) gload_sbase(dw[k][j], voff, pk + 8 * j * stride);
         }
     }
-    // lanes past the 6 x 10 items of a load (and past row 38 in the last one) repeat an item: same address, same LDS
-    // slot, so neither the loads nor the stores need a predicate; an idle quarter repeats keypoint 0 (always live)
-    constexpr int NPI = (PROWS + 5) / 6;  // 7 loads of 6 rows
-    constexpr int LASTROWS = PROWS - 6 * (NPI - 1);
+    // the blurred disc, five loads per keypoint; an idle quarter repeats keypoint 0 (always live)
+    constexpr int NPI = kDiscLoads;
     uint32_t pd[4][NPI];
-    const int pr = min(lane, 59) / PDW, pc = min(lane, 59) - pr * PDW;
-    const int sidx = pr * PDW + pc, sidxLast = min(pr, LASTROWS - 1) * PDW + pc;
+    int sidx[NPI];
     if (anyActive) {
-        const uint32_t voff = (uint32_t)(pr * bs + 4 * pc), voffLast = (uint32_t)(min(pr, LASTROWS - 1) * bs + 4 * pc);
+        uint32_t voff[NPI];
+#pragma unroll
+        for (int i = 0; i < NPI; i++) {
+            const int it = ditem[i], r = it >> 4, c = it & 15;
+            voff[i] = (uint32_t)(r * bs + 4 * c);
+            sidx[i] = r * PDW + c;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int so = __builtin_amdgcn_readlane((int)active, 16 * k) ? __builtin_amdgcn_readlane(bctrOff, 16 * k) : __builtin_amdgcn_readlane(bctrOff, 0);
             const uint8_t* pk = blur + (so - PR * bs - PR);
 #pragma unroll
-            for (int i = 0; i < NPI; i++) gload_sbase(pd[k][i], i + 1 < NPI ? voff : voffLast, pk + 6 * i * bs);
+            for (int i = 0; i < NPI; i++) gload_sbase(pd[k][i], voff[i], pk);
         }
     }
     // the block's tables are built while the patches are in flight
@@ -1859,10 +1895,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     // IC_Angle: m10 = sum u I, m01 = sum v I over the disc, as v_dot4_u32_u8 sums against byte weights u + 16, v + 16
     // and the disc flags (one set of weights per lane serves the four keypoints)
     int m10, m01;
-    asm volatile("s_waitcnt vmcnt(28)"  // the 16 IC_Angle dwords are in; the 28 patch dwords may still be in flight
+    asm volatile("s_waitcnt vmcnt(20)"  // the 16 IC_Angle dwords are in; the 20 patch dwords may still be in flight
                  : "+v"(dw[0][0]), "+v"(dw[0][1]), "+v"(dw[0][2]), "+v"(dw[0][3]), "+v"(dw[1][0]), "+v"(dw[1][1]), "+v"(dw[1][2]), "+v"(dw[1][3]),
                    "+v"(dw[2][0]), "+v"(dw[2][1]), "+v"(dw[2][2]), "+v"(dw[2][3]), "+v"(dw[3][0]), "+v"(dw[3][1]), "+v"(dw[3][2]), "+v"(dw[3][3]));
-    static_assert(4 * NPI == 28, "vmcnt above");
+    static_assert(4 * NPI == 20, "vmcnt above");
     {
         int A[4], B[4];
         uint32_t wu[4], w1[4], wv[4];
@@ -1901,15 +1937,16 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     }
     OSTAMP();
     asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(pd[0][0]), "+v"(pd[0][1]), "+v"(pd[0][2]), "+v"(pd[0][3]), "+v"(pd[0][4]), "+v"(pd[0][5]), "+v"(pd[0][6]),
-                   "+v"(pd[1][0]), "+v"(pd[1][1]), "+v"(pd[1][2]), "+v"(pd[1][3]), "+v"(pd[1][4]), "+v"(pd[1][5]), "+v"(pd[1][6]),
-                   "+v"(pd[2][0]), "+v"(pd[2][1]), "+v"(pd[2][2]), "+v"(pd[2][3]), "+v"(pd[2][4]), "+v"(pd[2][5]), "+v"(pd[2][6]),
-                   "+v"(pd[3][0]), "+v"(pd[3][1]), "+v"(pd[3][2]), "+v"(pd[3][3]), "+v"(pd[3][4]), "+v"(pd[3][5]), "+v"(pd[3][6]));
-    // park the blurred patches: item 60 i + lane of keypoint k is (row 6 i + lane / 10, dword lane % 10)
+                 : "+v"(pd[0][0]), "+v"(pd[0][1]), "+v"(pd[0][2]), "+v"(pd[0][3]), "+v"(pd[0][4]),
+                   "+v"(pd[1][0]), "+v"(pd[1][1]), "+v"(pd[1][2]), "+v"(pd[1][3]), "+v"(pd[1][4]),
+                   "+v"(pd[2][0]), "+v"(pd[2][1]), "+v"(pd[2][2]), "+v"(pd[2][3]), "+v"(pd[2][4]),
+                   "+v"(pd[3][0]), "+v"(pd[3][1]), "+v"(pd[3][2]), "+v"(pd[3][3]), "+v"(pd[3][4]));
+    static_assert(NPI == 5, "operand list above");
+    // park the blurred discs
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int i = 0; i < NPI; i++) spatch[wave * 4 + k][60 * i + (i + 1 < NPI ? sidx : sidxLast)] = pd[k][i];
+        for (int i = 0; i < NPI; i++) spatch[wave * 4 + k][sidx[i]] = pd[k][i];
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // steered BRIEF on the blurred level

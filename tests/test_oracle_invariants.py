@@ -453,3 +453,35 @@ def test_undistort_inverts_the_distortion_model(oracle):
     bx, by = distort((got["x"].astype(np.float64) - K[2]) / K[0], (got["y"].astype(np.float64) - K[3]) / K[1])
     back = np.hypot(bx * K[0] + K[2] - keys["x"], by * K[1] + K[3] - keys["y"])
     assert back[r < 250].max() < 2e-3
+
+
+def test_blurred_disc_table_covers_every_steered_sample():
+    """k_orient_desc fetches only the DISC of the blurred patch the 512 steered BRIEF samples can reach (kDiscHalf in
+    orbx_kernels.hip).  Recomputed here from the pattern, two ways: the geometric bound the kernel's comment states (a
+    point at radius r, rotated by any angle and rounded, stays within |X| <= sqrt(r^2 - (|Y| - 0.5)^2) + 0.5 in row Y),
+    and a dense sweep of the angle in binary32 arithmetic as the kernel and the reference compute the coordinates."""
+    import re
+    src = open(os.path.join(ROOT, "orbslamm_amd", "csrc", "orbx_kernels.hip")).read()
+    R = int(re.search(r"constexpr int kDiscR = (\d+);", src).group(1))
+    half = [int(x) for x in re.search(r"kDiscHalf\[kDiscR \+ 1\] = \{([^}]*)\}", src).group(1).split(",")]
+    assert len(half) == R + 1
+    txt = open(os.path.join(ROOT, "orbslamm_amd", "csrc", "brief_pattern.inc")).read()
+    vals = np.array([int(x) for x in re.findall(r"-?\d+", txt[txt.index("*/") + 2:])], np.float32).reshape(-1, 2)
+    assert len(vals) == 512
+    rad = np.hypot(vals[:, 0].astype(np.float64), vals[:, 1].astype(np.float64))
+    rmax = rad.max()
+    assert rmax + 1e-3 < R + 0.5, "rows beyond +-kDiscR would be reachable (cvRound needs |y| >= R + 0.5 for them)"
+    for ay in range(R + 1):   # the geometric bound, with a margin for the float32 products
+        yy = max(ay - 0.5, 0.0)
+        need = int(np.floor(np.sqrt(max(rmax * rmax - yy * yy, 0.0)) + 0.5 + 1e-3)) if yy <= rmax + 1e-3 else -1
+        assert half[ay] >= need, (ay, half[ay], need)
+    # the sweep: 2^16 angles over [0, 2 pi), coordinates as :118-120 forms them (float32 products, separate roundings)
+    ang = np.linspace(0, 2 * np.pi, 1 << 16, endpoint=False).astype(np.float32)
+    a, b = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    x, y = vals[:, 0][:, None], vals[:, 1][:, None]
+    X = np.rint((x * a[None, :]).astype(np.float32) - (y * b[None, :]).astype(np.float32)).astype(np.int32)
+    Y = np.rint((x * b[None, :]).astype(np.float32) + (y * a[None, :]).astype(np.float32)).astype(np.int32)
+    assert np.abs(Y).max() <= R
+    reach = np.zeros(R + 1, np.int32)
+    np.maximum.at(reach, np.abs(Y).ravel(), np.abs(X).ravel())
+    assert (reach <= np.array(half)).all(), (reach, half)
