@@ -351,6 +351,9 @@ __device__ __forceinline__ int arc_min_of_max(const int (&d)[16])
 #ifndef ORBX_FAST_PK
 #define ORBX_FAST_PK 1
 #endif
+#ifndef ORBX_FAST_PK1
+#define ORBX_FAST_PK1 1   // k_fast stage 1: the compass test two pixels per instruction
+#endif
 #ifndef ORBX_BRIEF_PK
 #define ORBX_BRIEF_PK 1   // k_orient_desc: the steered BRIEF coordinates on packed fp32
 #endif
@@ -567,8 +570,32 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const uint64_t mY = ballot64(y < dh);
                 const uint32_t* q = tile + (rowOk ? y : 0) * TSD + (x4 >> 2);
                 const uint32_t N = q[1], C0 = q[3 * TSD], C1 = q[3 * TSD + 1], C2 = q[3 * TSD + 2], S = q[6 * TSD + 1];
+#if ORBX_FAST_PK1
+                // two pixels per instruction: the five dwords widened to 16-bit pairs (ten v_perm), the compass min / max on
+                // v_pk_min_u16 / v_pk_max_u16 (twelve), the thresholds added in packed form (four): 26 + 8 compares for four
+                // pixels against 40
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                auto wid = [](uint32_t hiSrc, uint32_t loSrc, uint32_t sel) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(hiSrc, loSrc, sel)); };
+                const us2 n2[2] = {wid(0, N, 0x0C010C00u), wid(0, N, 0x0C030C02u)}, s2[2] = {wid(0, S, 0x0C010C00u), wid(0, S, 0x0C030C02u)};
+                const us2 v2[2] = {wid(0, C1, 0x0C010C00u), wid(0, C1, 0x0C030C02u)};
+                const us2 w2[2] = {wid(0, C0, 0x0C020C01u), wid(C1, C0, 0x0C040C03u)};   // x - 3: C0.b1 C0.b2 | C0.b3 C1.b0
+                const us2 e2[2] = {wid(C2, C1, 0x0C040C03u), wid(0, C2, 0x0C020C01u)};   // x + 3: C1.b3 C2.b0 | C2.b1 C2.b2
+                const us2 th2 = {(unsigned short)th, (unsigned short)th};
+                us2 hiP[2], loP[2], vtP[2];
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    hiP[m] = __builtin_elementwise_min(__builtin_elementwise_max(n2[m], s2[m]), __builtin_elementwise_max(w2[m], e2[m]));
+                    loP[m] = __builtin_elementwise_max(__builtin_elementwise_min(n2[m], s2[m]), __builtin_elementwise_min(w2[m], e2[m])) + th2;
+                    vtP[m] = v2[m] + th2;
+                }
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
+#if ORBX_FAST_PK1
+                    const unsigned short hk = k & 1 ? hiP[k >> 1].y : hiP[k >> 1].x, lk = k & 1 ? loP[k >> 1].y : loP[k >> 1].x;
+                    const unsigned short vtk = k & 1 ? vtP[k >> 1].y : vtP[k >> 1].x, vk = k & 1 ? v2[k >> 1].y : v2[k >> 1].x;
+                    const bool br = hk > vtk, dk = vk > lk;   // hi - v > th, v - lo > th
+#else
                     const int v = (C1 >> (8 * k)) & 0xFF;
                     const int pn = (N >> (8 * k)) & 0xFF, ps = (S >> (8 * k)) & 0xFF;
                     const int pw = k < 3 ? (C0 >> (8 * (k + 1))) & 0xFF : C1 & 0xFF;
@@ -576,6 +603,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                     const int hi = min(max(pn, ps), max(pw, pe));   // bright: hi - v > th
                     const int lo = max(min(pn, ps), min(pw, pe));   // dark:   v - lo > th
                     const bool br = hi - v > th, dk = v - lo > th;
+#endif
                     const uint64_t mIn = mX[k] & mY, mBr = ballot64(br) & mIn, mDk = ballot64(dk) & mIn;
                     const bool in = rowOk && x4 + k < dw;
                     const int e = (y << 7) | (x4 + k);
