@@ -104,6 +104,20 @@ def test_fast_atan2_close_to_libm(oracle):
         d = abs(a - ref)
         assert min(d, 360 - d) < 0.3
     assert L.orc_fast_atan2(0.0, 0.0) == 0.0
+    # a dense sweep: every hundredth of a degree at three radii (IC_Angle's moments are integers up to ~10^6), and the
+    # axes, where OpenCV's polynomial is exact
+    worst = 0.0
+    for r in (1.0, 37.5, 3.0e5):
+        for k in range(36000):
+            t = math.radians(k * 0.01)
+            y, x = r * math.sin(t), r * math.cos(t)
+            a = L.orc_fast_atan2(float(np.float32(y)), float(np.float32(x)))
+            ref = math.degrees(math.atan2(float(np.float32(y)), float(np.float32(x)))) % 360.0
+            d = abs(a - ref)
+            worst = max(worst, min(d, 360 - d))
+    assert worst < 0.3, worst
+    for (y, x), want in (((0.0, 5.0), 0.0), ((7.0, 0.0), 90.0), ((0.0, -3.0), 180.0), ((-2.0, 0.0), 270.0)):
+        assert abs(L.orc_fast_atan2(y, x) - want) < 1e-4, (y, x)
 
 
 def test_resize_constant_and_shape(oracle):
