@@ -1769,7 +1769,7 @@ struct KpBlocks { int32_t base[ORBX_MAXL + 1]; };  // block index -> level (kKpP
 // The blurred patch a keypoint's 512 steered samples can reach is a DISC, not the 39 x 40 rectangle round 4 fetched: a
 // pattern point at radius r lands, rotated by any angle and rounded, within |Y| <= r + 0.5 and, in row Y, within
 // |X| <= sqrt(r^2 - (|Y| - 0.5)^2) + 0.5; the pattern's largest radius is 18.385 (13, 13), so rows +-19 are never read and
-// row Y needs |X| <= kDiscHalf[|Y|] (tests/test_oracle_invariants.py recomputes the table from the pattern).  On the
+// row Y needs |X| <= kDiscHalf[|Y|] (a CPU test under tests/ recomputes the table from the pattern and from a sweep of the angle).  On the
 // kernel's grid of dwords from byte cx - 18 that is 308 of 370 (row, dword) items: FIVE gather loads per keypoint
 // instead of seven (a load instruction costs the CU's memory pipe ~7.5 cycles and ~1.1 more per cache line it touches,
 // tools/orient_npi_exp.sh; the kernel is bound by exactly that).  The LDS patch keeps its rectangular 40-byte rows --
