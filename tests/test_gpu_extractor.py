@@ -514,3 +514,18 @@ def test_soak_256_frames_bit_exact(gpu, oracle):
             prev = (k, d)
             total_kp += len(k)
     assert total_kp > 500000 and total_m > 200000
+
+
+@pytest.mark.parametrize("nf", [2028, 2036, 2044, 2052, 2060, 2100])
+def test_quadtree_node_list_at_the_lds_limit(gpu, oracle, nf):
+    """One pyramid level with ~2 050 features (at 640 x 480: 2 044 and 2 052 fall in the window) puts k_distribute's node list (19 words per node) within a few KB of the CU's
+    160 KB of LDS: below the limit the list lives in LDS, above it in a global scratch region, and in between the kernel's own
+    static LDS used to make the launch attribute fail (found by tools/fuzz_soak.py).  All sizes must extract like the oracle."""
+    w, h = 640, 480
+    rng = np.random.default_rng(nf)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)   # white noise: far more corners than features asked for
+    gex = gpu_extractor(nf, w, h, 1, 1.2, 1, 20, 7)
+    ref = oracle.Extractor(nf, 1.2, 1, 20, 7)(img)
+    k, d = gex(img)
+    assert len(k) > 2000
+    assert_same(ref, k, d)
