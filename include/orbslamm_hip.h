@@ -213,7 +213,8 @@ int orbx_upload(orbx_t* h, void* d_dst, const void* h_src, size_t bytes);
 int orbx_match_prev_batch_device(orbx_t* h, float nnratio, int th_low, int check_ori);
 int orbx_device_matches(orbx_t* h, int32_t** d_match, int32_t** d_nmatch);
 int orbx_download_matches(orbx_t* h, int frame, int32_t* match, int cap, int* nmatch);
-/* forget the previous frame (start of a new stream) */
+/* forget the previous frame (start of a new stream).  A call with a frame shape other than the handle's current one does
+ * the same: a new shape starts a new stream (the first frame of the new shape has no previous frame). */
 int orbx_reset_stream(orbx_t* h);
 
 /* per-kernel timing with HIP events on the handle's stream.  enable=1 starts
