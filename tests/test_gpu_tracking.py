@@ -398,3 +398,45 @@ def test_track_with_projections_from_the_host(gpu, oracle):
         total += wn
     assert total > 1500
     fs.close(); m.close(); gex.close()
+
+
+def test_frame_to_frame_search_regrows_its_candidate_arena(gpu, oracle):
+    """A small, dense frame (2 400 features on 401 x 263) searched against itself with a wide window (th = 60) lists far
+    more than the arena's 64 candidates per feature: orbm_track_results grows the arena and runs the search again (it used to
+    return ORBX_E_CAPACITY -- found by tools/fuzz_frontend.py); the table equals the sequential oracle's."""
+    from orbslamm_amd import ORBextractor, ORBmatcher, make_grid, synth
+    w, h, nf, B = 401, 263, 2400, 2
+    # a periodic texture: every corner looks like every other, so all the spatial neighbours of a query survive the Hamming
+    # threshold and are listed
+    yy, xx = np.mgrid[0:h + 2, 0:w + 3]
+    base = np.where(((yy // 7) + (xx // 7)) % 2 == 0, 40, 210) + np.random.default_rng(12).integers(-2, 3, yy.shape)
+    base = np.clip(base, 0, 255).astype(np.uint8)
+    fr = np.stack([np.ascontiguousarray(base[:h, :w]), np.ascontiguousarray(base[2:, 3:])])
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=0)
+    sf = np.array(gex.GetScaleFactors(), np.float32)
+    gex.extract_batch_device(*gex.upload_frames(fr))
+    K, D = [400.0, 400.0, 200.0, 131.0], [0, 0, 0, 0, 0]
+    host = []
+    for f in range(B):
+        keys, desc = gex.download(f)
+        host.append((oracle.undistort_keypoints(keys, K, D), desc))
+    bounds = [0.0, float(w), 0.0, float(h)]
+    g = make_grid(bounds[0], bounds[2], bounds[1], bounds[3])
+    gp = oracle.make_grid_params(bounds[0], bounds[2], bounds[1], bounds[3])
+    m = ORBmatcher(0.9, True, device=0)
+    fs = m.frame_set(B, gex.max_keypoints, K, D, g, bounds, sf)
+    fs.build_from_extractor(0, gex)
+    for rep in range(2):   # the second call runs in the grown arena without the retry
+        fs.track([0, 1], [0, 0], th=60.0, th_dist=100, nnratio=0.9, check_ori=True)
+        assign, nm = fs.results()
+        for p, (c, l) in enumerate(((0, 0), (1, 0))):
+            kc, dc = host[c]
+            kl, dl = host[l]
+            uvr, lvl, qv = _identity_queries(kl, sf, 60.0, bounds)
+            start, idx = oracle.grid_build(gp, kc)
+            wa, _, wn = oracle.search_by_projection(4, 0.9, True, 100, uvr, lvl, dl, kl["angle"], qv, None, gp, kc, start, idx, dc,
+                                                    np.zeros(len(kc), np.uint8), np.full(len(kc), -1, np.int32))
+            assert nm[p] == wn and np.array_equal(assign[p, :len(kc)], wa)
+        r, cands = fs.stats(0)
+        assert cands > 64 * gex.max_keypoints   # the scenario does overflow the initial arena
+    fs.close()
