@@ -440,3 +440,51 @@ def test_frame_to_frame_search_regrows_its_candidate_arena(gpu, oracle):
         r, cands = fs.stats(0)
         assert cands > 64 * gex.max_keypoints   # the scenario does overflow the initial arena
     fs.close()
+
+
+def test_search_by_bow_on_the_set_searches_the_root_node_of_a_ragged_tree(gpu, oracle):
+    """A word that is a leaf ABOVE the FeatureVector's level keeps node id 0 (DBoW2: `*nid = 0`), so a frame can hold one node
+    more than the level has vocabulary nodes.  The batched search launched one workgroup per node of the LEVEL and never
+    searched the node with the highest id (found by tools/fuzz_tracking.py).  Hand-built tree: k = 3, L = 3, one level-1 node
+    is a leaf; at levelsup = 1 the FeatureVectors have the six level-2 nodes + node 0."""
+    from orbslamm_amd import ORBextractor, ORBmatcher, ORBVocabulary, make_grid, synth
+    rng = np.random.default_rng(5)
+    parent = [0, 0, 0] + [2] * 3 + [3] * 3 + sum([[p] * 3 for p in range(4, 10)], [])
+    is_leaf = [1, 0, 0] + [0] * 6 + [1] * 18
+    desc = [None] * len(parent)
+    root = rng.integers(0, 256, 32, dtype=np.uint8)
+    for i, p in enumerate(parent):
+        d = (root if p == 0 else desc[p - 1]).copy()
+        for b in rng.integers(0, 256, 40):
+            d[b // 8] ^= np.uint8(1 << (b % 8))
+        desc[i] = d
+    voc = dict(parent=np.array(parent, np.int32), is_leaf=np.array(is_leaf, np.uint8), desc=np.stack(desc),
+               weight=rng.uniform(0.5, 3.0, len(parent)).astype(np.float64))
+    k, L, levelsup = 3, 3, 1
+    G = ORBVocabulary(k, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"], device=0)
+    O = oracle.Vocabulary(k, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    w, h, nf, B = 640, 480, 1000, 3
+    fr = synth.make_frames(w, h, B, stream=14)
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=0)
+    gex.extract_batch_device(*gex.upload_frames(fr))
+    host = [gex.download(f) for f in range(B)]
+    m = ORBmatcher(0.9, False, device=0)
+    g = make_grid(0.0, 0.0, float(w), float(h))
+    fs = m.frame_set(B, gex.max_keypoints, TUM_K, [0, 0, 0, 0, 0], g, [0.0, float(w), 0.0, float(h)], np.array(gex.GetScaleFactors(), np.float32))
+    fs.build_from_extractor(0, gex)
+    fs.compute_bow(G, 0, B, levelsup)
+    fvs = [O.transform(host[f][1], levelsup)[1] for f in range(B)]
+    assert all(len(fv[0]) == 7 and fv[0][0] == 0 for fv in fvs)   # six level-2 nodes + the root's
+    kf, cur = [0, 1, 2], [1, 2, 0]
+    fs.search_by_bow(kf, cur, nnratio=0.9, check_ori=False)
+    match, nm = fs.bow_results()
+    in_last_node = 0
+    for p in range(3):
+        (kq, dq), (kt, dt) = host[kf[p]], host[cur[p]]
+        want, wn = oracle.search_by_bow(dq, kq["angle"], None, fvs[kf[p]], dt, kt["angle"], None, fvs[cur[p]], 0.9, False, True)
+        assert nm[p] == wn and np.array_equal(match[p, :len(kt)], want)
+        node, start, idx = fvs[kf[p]]
+        last = set(idx[start[-2]:start[-1]].tolist())   # the KeyFrame features of the node with the highest id
+        in_last_node += sum(1 for q in want if q in last)
+    assert in_last_node > 0   # the scenario has matches that only a search of that node finds
+    fs.close(); m.close(); G.close(); gex.close()
