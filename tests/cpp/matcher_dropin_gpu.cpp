@@ -25,6 +25,8 @@ static int fails = 0;
 static const int W = 640, H = 480, NLEVELS = 8;
 static const float FX = 520.f, FY = 515.f, CX = 318.f, CY = 243.f, SCALE = 1.2f;
 static std::mt19937 rng(20260929);
+static bool g_fuzz = false;   // other seeds than the committed one: the "scenario is meaningful" thresholds do not apply
+#define SC(cond) ((cond) || g_fuzz)
 static float urand(float a, float b) { return a + (b - a) * (float)(rng() & 0xFFFFFF) / 16777216.f; }
 
 struct Pose { double R[9], t[3]; };
@@ -301,10 +303,12 @@ static bool same_state(const World& w, const Shadow& s)
     return true;
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    // optional: seed and world size (tools/fuzz_dropin.sh runs the whole program over many seeds)
+    if (argc > 1) { rng.seed((unsigned)std::strtoul(argv[1], nullptr, 10)); g_fuzz = true; }
     World w;
-    build_world(w, 1400);
+    build_world(w, argc > 2 ? std::atoi(argv[2]) : 1400);
     Frame::fx = FX; Frame::fy = FY; Frame::cx = CX; Frame::cy = CY;
     Frame::mnMinX = 0; Frame::mnMaxX = W; Frame::mnMinY = 0; Frame::mnMaxY = H;
     Frame::mfGridElementWidthInv = 64.f / W; Frame::mfGridElementHeightInv = 48.f / H;
@@ -350,7 +354,7 @@ int main()
         const ORBmatcher::FlatCall& c = m.last;
         std::vector<int32_t> as;
         check_projection(c, 0.8f, true, as);
-        EXPECT(c.nq == expectQueries && c.mode == 3 && c.thDist == 100 && n == c.nmatches && n > 250);
+        EXPECT(c.nq == expectQueries && c.mode == 3 && c.thDist == 100 && n == c.nmatches && SC(n > 250));
         EXPECT((c.turight != nullptr) == stereo);
         for (int q = 0; q < c.nq; q++) {  // (3) the flattening
             MapPoint* p = vp[c.qidx[q]];
@@ -393,7 +397,7 @@ int main()
         const ORBmatcher::FlatCall& c = m.last;
         std::vector<int32_t> as;
         check_projection(c, 0.9f, true, as);
-        EXPECT(c.mode == 4 && c.thDist == 100 && n == c.nmatches && n > 150 && c.nq > 300 && c.nq <= nLastPts);
+        EXPECT(c.mode == 4 && c.thDist == 100 && n == c.nmatches && SC(n > 150) && SC(c.nq > 300) && c.nq <= nLastPts);
         EXPECT((c.turight != nullptr) == !bMono);
         // the camera's motion along the last frame's optical axis against the baseline mb (:1349-1350); Last sits at the origin
         double Oc[3]; cam_center(Pc, Oc);
@@ -418,7 +422,7 @@ int main()
             EXPECT(Cur.mvpMapPoints[t] == want);
             pruned += as[t] == -1;
         }
-        EXPECT(pruned > 0);
+        EXPECT(SC(pruned > 0));
         std::printf("2.%d SearchByProjection(Cur, Last, th=%g, bMono=%d): %d queries, %d matches, %d pruned by rotation\n", variant, th, (int)bMono, c.nq, n, pruned);
     }
 
@@ -437,7 +441,7 @@ int main()
         const ORBmatcher::FlatCall& c = m.last;
         std::vector<int32_t> as;
         check_projection(c, 0.9f, true, as);
-        EXPECT(c.mode == 5 && c.thDist == ORBdist && n == c.nmatches && n > 100);
+        EXPECT(c.mode == 5 && c.thDist == ORBdist && n == c.nmatches && SC(n > 100));
         for (int q = 0; q < c.nq; q++) {
             MapPoint* p = kf0->mvpMapPoints[c.qidx[q]];
             EXPECT(p && !found.count(p) && c.qangle[q] == kf0->mvKeysUn[c.qidx[q]].angle);
@@ -468,7 +472,7 @@ int main()
         const ORBmatcher::FlatCall& c = m.last;
         std::vector<int32_t> as;
         check_projection(c, 0.75f, true, as);
-        EXPECT(c.mode == 6 && c.thDist == 50 && n == c.nmatches && n > 200);
+        EXPECT(c.mode == 6 && c.thDist == 50 && n == c.nmatches && SC(n > 200));
         std::set<MapPoint*> already(before.begin(), before.end());
         for (int q = 0; q < c.nq; q++) {
             MapPoint* p = vpPoints[c.qidx[q]];
@@ -494,14 +498,14 @@ int main()
         OrcFeatVec a = ofv(c.qfv), b = ofv(c.tfv);
         const int on = orc_search_by_bow(kf0->mDescriptors.ptr<uint8_t>(0), c.qangle.data(), c.qvalid.data(), c.nq, &a, F.mDescriptors.ptr<uint8_t>(0),
                                          c.tangle.data(), nullptr, c.nt, &b, 0.7f, 1, 1, om.data());
-        EXPECT(on == n && n > 150 && (int)out.size() == F.N && om == c.match);
+        EXPECT(on == n && SC(n > 150) && (int)out.size() == F.N && om == c.match);
         for (int i = 0; i < c.nq; i++) EXPECT(c.qvalid[i] == (kf0->mvpMapPoints[i] && !kf0->mvpMapPoints[i]->mbBad) && c.qangle[i] == kf0->mvKeysUn[i].angle);
         int right = 0;
         for (int t = 0; t < F.N; t++) {
             EXPECT(out[t] == (om[t] >= 0 ? kf0->mvpMapPoints[om[t]] : nullptr));
             right += out[t] && owner[t] >= 0 && w.origin[owner[t]] == w.origin[out[t]->id];
         }
-        EXPECT(right > n * 8 / 10);   // the scenario is meaningful: matches are mostly the true correspondences (twins sit on unrelated features of kf0)
+        EXPECT(SC(right > n * 8 / 10));   // the scenario is meaningful: matches are mostly the true correspondences (twins sit on unrelated features of kf0)
         w.mps[5]->mbBad = false; w.mps[77]->mbBad = false;
         std::printf("5   SearchByBoW(KF, Frame): %d matches (%d true correspondences)\n", n, right);
     }
@@ -516,7 +520,7 @@ int main()
         OrcFeatVec a = ofv(c.qfv), b = ofv(c.tfv);
         const int on = orc_search_by_bow(kf0->mDescriptors.ptr<uint8_t>(0), c.qangle.data(), c.qvalid.data(), c.nq, &a, kf1->mDescriptors.ptr<uint8_t>(0),
                                          c.tangle.data(), c.tvalid.data(), c.nt, &b, 0.8f, 1, 0, om.data());
-        EXPECT(on == n && n > 100 && (int)out.size() == kf0->N && om == c.match);
+        EXPECT(on == n && SC(n > 100) && (int)out.size() == kf0->N && om == c.match);
         for (int i = 0; i < c.nt; i++) EXPECT(c.tvalid[i] == (kf1->mvpMapPoints[i] && !kf1->mvpMapPoints[i]->mbBad));
         for (int i = 0; i < kf0->N; i++) EXPECT(out[i] == (om[i] >= 0 ? kf1->mvpMapPoints[om[i]] : nullptr));
         w.mps[9]->mbBad = false;
@@ -538,7 +542,7 @@ int main()
         std::vector<int32_t> om(F1.N, -1);
         const int on = orc_search_for_initialization(c.q_xy.data(), 100.f, (const OrcKeyPoint*)c.qkeys, F1.mDescriptors.ptr<uint8_t>(0), c.nq, &G.gp,
                                                      (const OrcKeyPoint*)c.tkeys, G.start.data(), G.idx.data(), F2.mDescriptors.ptr<uint8_t>(0), c.nt, 0.9f, 1, om.data());
-        EXPECT(on == n && n > 40 && (int)m12.size() == F1.N);
+        EXPECT(on == n && SC(n > 40) && (int)m12.size() == F1.N);
         for (int i = 0; i < F1.N; i++) {
             EXPECT(m12[i] == om[i]);
             if (m12[i] >= 0) EXPECT(prev[i].x == F2.mvKeysUn[m12[i]].pt.x && prev[i].y == F2.mvKeysUn[m12[i]].pt.y);  // :517-519
@@ -572,7 +576,7 @@ int main()
         const int on = orc_search_for_triangulation((const OrcKeyPoint*)c.qkeys, A->mDescriptors.ptr<uint8_t>(0), c.skip1.data(), A->mvuRight.data(), A->N, &a,
                                                     (const OrcKeyPoint*)c.tkeys, B->mDescriptors.ptr<uint8_t>(0), c.skip2.data(), B->mvuRight.data(), B->N, &b,
                                                     c.F12.data(), c.ex, c.ey, B->mvScaleFactors.data(), B->mvLevelSigma2.data(), 0, variant == 0, om.data());
-        EXPECT(on == n && n > 20 && (int)pairs.size() == n);
+        EXPECT(on == n && SC(n > 20) && (int)pairs.size() == n);
         size_t k = 0;
         for (int i = 0; i < A->N; i++) if (om[i] >= 0) { EXPECT(k < pairs.size() && pairs[k].first == (size_t)i && pairs[k].second == (size_t)om[i]); k++; }
         for (int i = 0; i < A->N; i++) EXPECT(c.skip1[i] == (A->mvpMapPoints[i] != nullptr));
@@ -611,7 +615,7 @@ int main()
                 want++;
             }
         }
-        EXPECT(q == c.nq && n == want && n > 100 && replaced > 10 && added > 10);
+        EXPECT(q == c.nq && n == want && SC(n > 100) && SC(replaced > 10) && SC(added > 10));
         EXPECT(same_state(w, sh));
         w.mps[21]->mbBad = false;
         std::printf("9.%d Fuse(KF, MapPoints, 3): %d queries, %d fused (%d replaced, %d added)\n", variant, c.nq, n, replaced, added);
@@ -644,7 +648,7 @@ int main()
                 want++;
             }
         }
-        EXPECT(n == want && n > 30);
+        EXPECT(n == want && SC(n > 30));
         for (size_t i = 0; i < pts.size(); i++) EXPECT((repl[i] ? repl[i]->id : -1) == wantRepl[i]);
         EXPECT(same_state(w, sh));
         std::printf("10  Fuse(KF, Scw, points, 4, replace): %d queries, %d fused\n", c.nq, n);
@@ -680,7 +684,7 @@ int main()
             if (v1[i] >= 0 && v2[v1[i]] == i) { exp = kf1->mvpMapPoints[v1[i]]; want++; }
             EXPECT(m12[i] == exp);
         }
-        EXPECT(n == want && n > 30 && pre == 25);
+        EXPECT(n == want && SC(n > 30) && pre == 25);
         for (int q = 0; q < m.last.nq; q++) {
             EXPECT(!before[m.last.qidx[q]]);
             MapPoint* p = kf0->mvpMapPoints[m.last.qidx[q]];
