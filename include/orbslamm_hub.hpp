@@ -72,11 +72,16 @@ public:
             if ((rc = orbx_scale_tables(ex_, sf, nullptr, nullptr, nullptr))) { close(); return rc; }
             const float bounds[4] = {0.f, (float)c.w, 0.f, (float)c.h};   // undistorted image bounds of an undistorted camera (Frame.cc:430-462)
             OrbmGrid g{0.f, 0.f, 64.f / (float)c.w, 48.f / (float)c.h, 64, 48};
-            nslots_ = 4 * c.cameras;
+            // C (C + 2) slots: a batch takes a run of B <= C consecutive slots that holds NO camera's newest frame -- with at
+            // most C such slots in the ring a free run of C always exists -- so a camera that falls several batches behind the
+            // others (its thread descheduled, a long local-map search) still finds its previous frame when it comes back.
+            // (Round 4's ring of 4 C slots handed the oldest slot out whatever it held: one frame in ~10^4 lost its previous
+            // frame that way under --hub-wait 0, found by tools/fuzz_multi_robot.py.)
+            nslots_ = c.cameras * (c.cameras + 2);
             if ((rc = orbm_frameset_create(m_, nslots_, cap_, c.K, c.D, &g, bounds, sf, orbx_levels(ex_), &fs_))) { close(); return rc; }
             if ((rc = orbm_frameset_attach(fs_, ex_))) { close(); return rc; }
         }
-        for (int s = 0; s < 4 * kMaxCameras; s++) { slotCam_[s] = -1; slotSeq_[s] = 0; }
+        for (int s = 0; s < kMaxSlots; s++) { slotCam_[s] = -1; slotSeq_[s] = 0; }
         for (int j = 0; j < kMaxCameras; j++) { lastSlot_[j] = -1; seq_[j] = 0; lastN_[j] = 0; req_[j].state.store(0); }
         cursor_ = 0; pendingTicket_ = -1;   // (a hub reopened with another camera count starts its ring afresh)
         return ORBX_OK;
@@ -231,11 +236,18 @@ private:
         if (!strideOk) rc = ORBX_E_INVALID;
         if (!rc) rc = orbx_submit_batch(ex_, imgs, B, cfg_.w, cfg_.h, req_[cams[0]].stride, nullptr, &ticket);
         if (!rc && fs_) {
-            // a ring of slots: this batch's frames take B consecutive ones; a camera's previous frame is searched against as
-            // long as its slot has not been handed to another frame since (4 x cameras slots: at least three batches)
-            if (cursor_ + B > nslots_) cursor_ = 0;
-            const int slot0 = cursor_;
-            cursor_ += B;
+            // a ring of slots: this batch's frames take the next run of B consecutive ones that holds no camera's newest frame
+            // (the `last` operands of this batch's searches and the frames the absent cameras will come back to)
+            auto newest = [&](int s) { return slotCam_[s] >= 0 && lastSlot_[slotCam_[s]] == s; };
+            int slot0 = -1;
+            for (int s = cursor_, tries = 0; slot0 < 0 && tries <= 2 * nslots_; tries++) {
+                if (s + B > nslots_) { s = 0; continue; }
+                int bad = -1;
+                for (int p = 0; p < B; p++) if (newest(s + p)) bad = s + p;
+                if (bad < 0) slot0 = s; else s = bad + 1;
+            }
+            if (slot0 < 0) slot0 = 0;   // (cannot happen: C newest frames leave a free run of C in C (C + 2) slots)
+            cursor_ = slot0 + B;
             rc = orbm_frameset_build_from_extractor(fs_, slot0, ex_);
             for (int p = 0; p < B; p++) pairOf[p] = -1;
             for (int p = 0; p < B && !rc; p++) {
@@ -285,7 +297,8 @@ private:
     Config cfg_{};
     orbx_t* ex_ = nullptr; orbm_t* m_ = nullptr; orbm_frameset_t* fs_ = nullptr;
     int cap_ = 0, nslots_ = 0, cursor_ = 0;
-    int slotCam_[4 * kMaxCameras]; int64_t slotSeq_[4 * kMaxCameras];
+    static constexpr int kMaxSlots = kMaxCameras * (kMaxCameras + 2);
+    int slotCam_[kMaxSlots]; int64_t slotSeq_[kMaxSlots];
     int lastSlot_[kMaxCameras]; int64_t seq_[kMaxCameras]; int lastN_[kMaxCameras];
     Request req_[kMaxCameras];
     LocalRequest lreq_[kMaxCameras];

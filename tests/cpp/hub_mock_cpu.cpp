@@ -22,7 +22,7 @@ static std::atomic<int> g_fail{0};
 #define MOCK_CHECK(c) do { if (!(c)) { std::fprintf(stderr, "MOCK FAIL %s:%d %s\n", __FILE__, __LINE__, #c); g_fail++; } } while (0)
 
 namespace {
-constexpr int kCap = 64, kSlots = 32, kTickets = 3;
+constexpr int kCap = 64, kSlots = 80, kTickets = 3;   // kSlots: C (C + 2) for a hub of eight cameras
 struct Guard {   // the library's calls on one (extractor, frame set) pair come from one thread at a time
     static std::atomic<bool> busy;
     Guard() { MOCK_CHECK(!busy.exchange(true)); }
@@ -169,7 +169,7 @@ static Outcome run(int cameras, int nframes, int wait_us, int slowCam, int track
             std::vector<OrbxKeyPoint> kps(kCap); std::vector<uint8_t> desc(kCap * 32); std::vector<int32_t> assign(kCap);
             for (int s = 0; s < nframes; s++) {
                 frame[0] = cam; frame[1] = s;
-                if (cam == slowCam) std::this_thread::sleep_for(std::chrono::microseconds(rng() % 300));
+                if (cam == slowCam) std::this_thread::sleep_for(std::chrono::microseconds(rng() % 3000));
                 else if (rng() % 16 == 0) std::this_thread::yield();
                 orbslamm::CameraHub::Result r;
                 MOCK_CHECK(hub.track(cam, (const uint8_t*)frame.data(), 64, kps.data(), desc.data(), assign.data(), &r) == ORBX_OK);
@@ -199,7 +199,7 @@ static Outcome run(int cameras, int nframes, int wait_us, int slowCam, int track
                         bool tab = true;
                         for (int t = 0; t < r.n; t++) tab = tab && assign[t] == 7000000 + cam * 100000 + s * 10 + t % 10;
                         MOCK_CHECK(tab);
-                    } else MOCK_CHECK(rc3 == ORBX_E_INVALID);   // (the ring went round: the frame has left the set)
+                    } else MOCK_CHECK(rc3 == ORBX_OK);   // (the camera's newest frame never leaves the set)
                 }
                 out[cam].frames++; out[cam].batchSum += r.batch;
             }
@@ -222,11 +222,12 @@ int main(int argc, char** argv)
         MOCK_CHECK(o.lost == 0 && o.searched == (long)cams * (nframes - 1));
         std::printf("cameras %d wait 20 ms: %ld frames in %ld batches (mean %.2f), %ld searched, %ld lost\n", cams, o.frames, M.batches, (double)o.batchSum / o.frames, o.searched, o.lost);
     }
-    // no wait at all / one slow camera: batches are whatever happens to wait; a camera may lose its previous frame only when
-    // the ring (4 x cameras slots) went round in between -- whatever is searched is searched against the right frame
+    // no wait at all / one slow camera (it sleeps up to 3 ms before a frame: dozens of the others' batches pass): batches are
+    // whatever happens to wait, and NOBODY loses its previous frame -- a batch never takes a slot that holds a camera's newest
+    // frame (round 4's ring of 4 x cameras slots lost the slow camera's whenever it went round in between)
     for (int wait : {0, 50}) {
         const Outcome o = run(6, nframes, wait, 2, 1);
-        MOCK_CHECK(o.searched + o.lost == 6L * (nframes - 1));
+        MOCK_CHECK(o.lost == 0 && o.searched == 6L * (nframes - 1));
         std::printf("cameras 6 wait %d us, camera 2 slow: %ld frames in %ld batches (mean %.2f), %ld searched, %ld lost\n", wait, o.frames, M.batches, (double)o.batchSum / o.frames, o.searched, o.lost);
     }
     {   // extraction only

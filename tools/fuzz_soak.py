@@ -76,7 +76,7 @@ def main():
     kinds = ["scene", "noise", "band", "checker", "ramp", "natural", "clipped", "lowcontrast", "halfflat"]
     gm = ORBmatcher(0.7, True, device=0)
     done = refused = 0
-    nkp = nmatch = 0
+    nkp = nmatch = nframes = 0
     per_kind = {k: 0 for k in kinds}
     t0 = time.time()
     while done < ncases:
@@ -88,8 +88,9 @@ def main():
         nl = int(rng.integers(1, 11))
         ini, mn = int(rng.integers(5, 80)), int(rng.integers(1, 30))
         kind = kinds[int(rng.integers(0, len(kinds)))]
+        B = int(rng.choice([2, 2, 2, 3, 4, 6, 9]))
         try:
-            gex = ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=2, device=0)
+            gex = ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B, device=0)
         except Exception as e:  # shapes the reference would crash on are refused (ORBX_E_UNSUPPORTED)
             if getattr(e, "code", 0) != -5:
                 raise
@@ -97,21 +98,26 @@ def main():
             continue
         a = make_image(rng, kind, w, h, naturals)
         b = np.roll(a, (int(rng.integers(-3, 4)), int(rng.integers(-6, 7))), (0, 1))   # the "next frame"
+        # more frames of OTHER statistics in the same call: calls of more than two frames take the throughput graph
+        # (sub-batches on their own streams), one or two the latency chain
+        more = [make_image(rng, kinds[int(rng.integers(0, len(kinds)))], w, h, naturals) for _ in range(B - 2)]
+        batch = [a, b] + more
         try:
             oex = ob.Extractor(nf, sf, nl, ini, mn)
-            ra, rb = oex(a), oex(b)
+            refs = [oex(im) for im in batch]
+            ra, rb = refs[0], refs[1]
         except RuntimeError:
             refused += 1
             continue
-        case = dict(case=done, kind=kind, w=w, h=h, nf=nf, sf=sf, nl=nl, ini=ini, mn=mn, seed=seed)
+        case = dict(case=done, kind=kind, w=w, h=h, nf=nf, sf=sf, nl=nl, ini=ini, mn=mn, B=B, seed=seed)
         try:
-            kps, desc = gex.extract_batch(np.stack([a, b]))
+            kps, desc = gex.extract_batch(np.stack(batch))
         except Exception as e:
             print("ERROR in the product path:", e, case)
             return 1
-        for ref, k, d, tag in ((ra, kps[0], desc[0], "a"), (rb, kps[1], desc[1], "b")):
+        for tag, (ref, k, d) in enumerate(zip(refs, kps, desc)):
             if len(ref["kps"]) != len(k) or ref["kps"].tobytes() != k.tobytes() or ref["desc"].tobytes() != d.tobytes():
-                print("DIFFERENCE frame %s: %d vs %d keypoints" % (tag, len(ref["kps"]), len(k)), case)
+                print("DIFFERENCE frame %d: %d vs %d keypoints" % (tag, len(ref["kps"]), len(k)), case)
                 return 1
         if len(ra["kps"]) and len(rb["kps"]):
             m_ref, n_ref = ob.match_bruteforce(rb["desc"], rb["kps"]["angle"], ra["desc"], ra["kps"]["angle"], 0.7, 50, True)
@@ -120,12 +126,13 @@ def main():
                 print("DIFFERENCE match: %d vs %d" % (n_ref, n_gpu), case)
                 return 1
             nmatch += int(n_gpu)
-        nkp += len(kps[0]) + len(kps[1])
+        nkp += sum(len(k) for k in kps)
+        nframes += B
         per_kind[kind] += 1
         done += 1
         del gex
     print("fuzz soak: %d cases (seed %d, %d shapes refused like the reference would crash), %d frames, %d keypoints, %d matches, "
-          "all keypoint records, descriptor bytes and match tables equal to the oracle's; %.0f s" % (done, seed, refused, 2 * done, nkp, nmatch, time.time() - t0))
+          "all keypoint records, descriptor bytes and match tables equal to the oracle's; %.0f s" % (done, seed, refused, nframes, nkp, nmatch, time.time() - t0))
     print("cases per content kind:", per_kind)
     return 0
 
