@@ -39,6 +39,7 @@ def levels_of(oex, pyr, w, h, nl):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    nfmax = int(sys.argv[3]) if len(sys.argv) > 3 else 2400   # features per frame below this (above ~4000 the set's BoW sort leaves LDS)
     rng = np.random.default_rng(seed)
     shapes = [(640, 480), (1241, 376), (752, 480), (401, 263), (512, 384)]
     counts = {"frames_built": 0, "track_pairs": 0, "stereo_pairs": 0, "transforms": 0}
@@ -46,7 +47,7 @@ def main():
     for r in range(rounds):
         # ------------------------------------------------------------ frame set + batched tracking search
         w, h = shapes[int(rng.integers(0, len(shapes)))]
-        nf = int(rng.integers(200, 2400))
+        nf = int(rng.integers(200, nfmax))
         B = int(rng.integers(2, 9))
         fr = synth.make_frames(w, h, B, stream=int(rng.integers(0, 500)))
         gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=0)

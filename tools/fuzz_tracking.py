@@ -39,13 +39,14 @@ def local_map_queries(rng, frames, sf, th, nq_target):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    nfmax = int(sys.argv[3]) if len(sys.argv) > 3 else 2400   # features per frame below this (above ~4000 the set's BoW sort leaves LDS)
     rng = np.random.default_rng(seed)
     shapes = [(640, 480), (1241, 376), (752, 480), (512, 384)]
     counts = {"local_points": 0, "projected": 0, "bow_vectors": 0, "bow_pairs": 0}
     t0 = time.time()
     for r in range(rounds):
         w, h = shapes[int(rng.integers(0, len(shapes)))]
-        nf = int(rng.integers(300, 2400))
+        nf = int(rng.integers(300, nfmax))
         B = int(rng.integers(3, 7))
         fr = synth.make_frames(w, h, B, stream=int(rng.integers(0, 500)))
         gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=0)
