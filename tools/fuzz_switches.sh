@@ -1,0 +1,29 @@
+#!/bin/bash
+# every A/B switch of the library (docs/experiments.md) must leave every result byte alone: the extractor + stream soaks under
+# each of them.  bash tools/fuzz_switches.sh [cases] > gpurun_out/fuzz_switches.txt
+R=${GRAFT_REPO_ROOT:-/root/repo}
+N=${1:-150}
+run() { # NAME=VALUE ...
+  out=$(env "$@" python $R/tools/fuzz_soak.py $N 61 2>&1 | grep -E "^fuzz soak|DIFFERENCE|ERROR|Error" | head -2)
+  out2=$(env "$@" python $R/tools/fuzz_stream.py 200 62 2>&1 | grep -E "^stream soak|DIFFERENCE|ERROR|Error" | head -2)
+  echo "$* :: ${out:0:110} :: ${out2:0:90}"
+}
+run ORBX_NONE=1
+run ORBX_MATCH_POPCOUNT=1
+run ORBX_BLUR_MFMA=0
+run ORBX_FUSE_EXPAND=0
+run ORBX_FUSE_BLUR=0
+run ORBX_FUSE_PACK=0
+run ORBX_SPLIT=1
+run ORBX_SPLIT=3
+run ORBX_SPLIT=4
+run ORBX_SERIAL=1
+run ORBX_LAT_STREAMS=2
+run ORBX_LAT_DMA=1
+run ORBX_LAT_PRIO=0
+run ORBX_DOWN_ENGINE=0
+run ORBX_DOWN_GATHER=0
+run ORBX_STAGE_NT=0
+run ORBX_PYR_GRID=8x4
+run ORBX_PYR_REFINE=1
+run ORBX_SHARE_STREAMS=0
