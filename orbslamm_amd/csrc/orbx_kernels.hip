@@ -104,12 +104,16 @@ __global__ __launch_bounds__(256) void k_resize_level(const Geom* __restrict__ g
 // (ping-pong) and writes only the owned pixels to HBM.  The level-0 source tile is
 // staged with aligned dword loads.  Same fixed-point arithmetic as k_resize.
 constexpr int kPyrStrips = 2;   // level-0 tile of k_pyramid: strips per block (host sizing and kernel)
+#ifndef ORBX_PYR_THREADS
+#define ORBX_PYR_THREADS 256
+#endif
+constexpr int kPyrThreads = ORBX_PYR_THREADS;   // threads of a k_pyramid workgroup (host launch and kernel)
 struct PyrRange {
     int16_t ox0, ox1, oy0, oy1;   // owned output range at this level (exclusive ends)
     int16_t nx0, nx1, ny0, ny1;   // computed range (owned + halo needed by the next level)
 };
 
-__global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, FrameSrc src, ResizeTabs tabs,
+__global__ __launch_bounds__(kPyrThreads) void k_pyramid(const Geom* __restrict__ g, FrameSrc src, ResizeTabs tabs,
                                                 const PyrRange* __restrict__ ranges, int bufAWords, int bufBWords,
                                                 int tabCap)
 {
@@ -142,25 +146,26 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     // rows [r0, r1) of level 0 into buffer A: aligned dword loads (ranges have 4-aligned x origins).  A strip of up to
     // 4096 dwords travels through 16 registers per thread: fetched (loads issued) before the previous strip's rows are
     // computed, committed to LDS after -- only the first strip's latency is exposed.  Larger strips load in place.
-    constexpr int kStripRegs = 16;
+    constexpr int T = kPyrThreads;
+    constexpr int kStripRegs = 4096 / T;   // a strip of up to 4096 dwords through the registers
     uint32_t sreg[kStripRegs];
     auto strip_rows = [&](int strip, int chh1, const uint2* yt, int& r0, int& r1) {  // level-0 rows read by the strip's level-1 rows
         const int ya = (int)((int64_t)chh1 * strip / kPyrStrips), yb = (int)((int64_t)chh1 * (strip + 1) / kPyrStrips);
         r0 = r1 = 0;
         if (yb > ya) { r0 = (int16_t)(yt[ya].x & 0xFFFF); r1 = min((int)(int16_t)(yt[yb - 1].x >> 16) + 1, (int)p.ny1); }
     };
-    // element k * 256 + tid of a strip is (row, dword column); stepping by 256 elements without a division per load
-    const int q256 = have0 ? 256 / ndw0 : 0, m256 = have0 ? 256 - q256 * ndw0 : 0;
+    // element k * T + tid of a strip is (row, dword column); stepping by 256 elements without a division per load
+    const int q256 = have0 ? T / ndw0 : 0, m256 = have0 ? T - q256 * ndw0 : 0;
     const int rowT = have0 ? tid / ndw0 : 0, colT = have0 ? tid - rowT * ndw0 : 0;
     auto fetch0 = [&](int r0, int r1) {
         const int total = (r1 - r0) * ndw0;
-        if (total <= 0 || total > 256 * kStripRegs) return;
+        if (total <= 0 || total > T * kStripRegs) return;
         const uint8_t* Sr = S0 + (int64_t)r0 * stride0;
         int r = rowT, c = colT;
 #pragma unroll
         for (int k = 0; k < kStripRegs; k++) {
-            if (k * 256 < total) {   // uniform
-                if (k * 256 + tid < total) sreg[k] = *(const uint32_t*)(Sr + (int64_t)r * stride0 + 4 * c);
+            if (k * T < total) {   // uniform
+                if (k * T + tid < total) sreg[k] = *(const uint32_t*)(Sr + (int64_t)r * stride0 + 4 * c);
                 r += q256; c += m256;
                 if (c >= ndw0) { c -= ndw0; r++; }
             }
@@ -169,26 +174,26 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
     auto commit0 = [&](int r0, int r1) {
         const int total = (r1 - r0) * ndw0;
         if (total <= 0) return;
-        if (total <= 256 * kStripRegs) {
+        if (total <= T * kStripRegs) {
 #pragma unroll
             for (int k = 0; k < kStripRegs; k++) {
-                const int i = k * 256 + tid;
+                const int i = k * T + tid;
                 if (i < total) plds[i] = sreg[k];
             }
             return;
         }
         const uint8_t* Sr = S0 + (int64_t)r0 * stride0;
-        for (int i0 = 0; i0 < total; i0 += 256 * 8) {
+        for (int i0 = 0; i0 < total; i0 += T * 8) {
             uint32_t regs[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = min(i0 + k * 256 + tid, total - 1);
+                const int i = min(i0 + k * T + tid, total - 1);
                 const int r = i / ndw0, c = i - r * ndw0;
                 regs[k] = *(const uint32_t*)(Sr + (int64_t)r * stride0 + 4 * c);
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = i0 + k * 256 + tid;
+                const int i = i0 + k * T + tid;
                 if (i < total) plds[i] = regs[k];
             }
         }
@@ -204,8 +209,8 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
         const uint2* __restrict__ gx_tab = (const uint2*)tabs.xtab[l];
         const uint2* __restrict__ gy_tab = (const uint2*)tabs.ytab[l];
         // stage this level's coefficient rows (entries past the level width are never used)
-        for (int i = tid; i < cstride; i += 256) sxt[i] = gx_tab[min(c.nx0 + i, lw - 1)];
-        for (int i = tid; i < chh; i += 256) syt[i] = gy_tab[c.ny0 + i];
+        for (int i = tid; i < cstride; i += T) sxt[i] = gx_tab[min(c.nx0 + i, lw - 1)];
+        for (int i = tid; i < chh; i += T) syt[i] = gy_tab[c.ny0 + i];
         __syncthreads();  // also orders the previous level's tile writes before the reads below
         const int offP = offBuf[(l - 1) & 1], offC = offBuf[l & 1];
         const bool strips = l == 1 && have0 && chh > 0;
@@ -227,9 +232,9 @@ __global__ __launch_bounds__(256) void k_pyramid(const Geom* __restrict__ g, Fra
         if (gpr > 0 && yb > ya) {
             // thread = (dword group gx, row lane): the four x-coefficient entries of the group are unpacked once
             // and reused down the rows the thread owns (rows yy0, yy0 + dr, ...)
-          for (int gxb = 0; gxb < gpr; gxb += 256) {  // one pass unless the tile is wider than 1024 px
-            const int cols = min(256, gpr - gxb);
-            const int dr = 256 / cols;           // row lanes
+          for (int gxb = 0; gxb < gpr; gxb += T) {  // one pass unless the tile is wider than 1024 px
+            const int cols = min(T, gpr - gxb);
+            const int dr = T / cols;           // row lanes
             const int yy0 = tid / cols, gx = gxb + tid - yy0 * cols;
             if (yy0 < dr) {
                 int sx[4], a0[4], a1[4];
