@@ -192,6 +192,12 @@ int orbx_compute_stereo_matches(orbx_t* left, orbx_t* right, int frame, float mb
  * (see DESIGN.md "candidate record"), unordered; returns count in *n */
 int orbx_level_candidates(orbx_t* h, int frame, int level, uint64_t* dst, int cap, int* n);
 
+/* waits for everything the handle has enqueued; returns the device error flag.  The handles of one device and process share
+ * their pipeline streams (four for the batched mode, a pool of four chains for the one-frame-per-call mode), so this call --
+ * like a call with a new frame shape, which synchronises before it re-configures -- also waits for the work OTHER handles
+ * of the device have in those streams: correct, but a robot that syncs in its loop couples its latency to its neighbours'.
+ * The results of a call are published behind flags / events of their own (orbx_collect_*, orbm_track_results): a steady
+ * loop needs no orbx_sync. */
 int orbx_sync(orbx_t* h);
 
 /* Convenience for hosts that do not link HIP themselves (the reference does not):
