@@ -76,7 +76,7 @@ public:
             // most C such slots in the ring a free run of C always exists -- so a camera that falls several batches behind the
             // others (its thread descheduled, a long local-map search) still finds its previous frame when it comes back.
             // (Round 4's ring of 4 C slots handed the oldest slot out whatever it held: one frame in ~10^4 lost its previous
-            // frame that way under --hub-wait 0, found by tools/fuzz_multi_robot.py.)
+            // frame that way under --hub-wait 0, found by tests/soak/fuzz_multi_robot.py.)
             nslots_ = c.cameras * (c.cameras + 2);
             if ((rc = orbm_frameset_create(m_, nslots_, cap_, c.K, c.D, &g, bounds, sf, orbx_levels(ex_), &fs_))) { close(); return rc; }
             if ((rc = orbm_frameset_attach(fs_, ex_))) { close(); return rc; }

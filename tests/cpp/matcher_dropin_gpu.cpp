@@ -305,7 +305,7 @@ static bool same_state(const World& w, const Shadow& s)
 
 int main(int argc, char** argv)
 {
-    // optional: seed and world size (tools/fuzz_dropin.sh runs the whole program over many seeds)
+    // optional: seed and world size (tests/soak/fuzz_dropin.sh runs the whole program over many seeds)
     if (argc > 1) { rng.seed((unsigned)std::strtoul(argv[1], nullptr, 10)); g_fuzz = true; }
     World w;
     build_world(w, argc > 2 ? std::atoi(argv[2]) : 1400);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the drop-in ORBmatcher classes (include/ORBmatcher_hip.hpp, all eleven members on mock SLAM objects, each call checked against
-# the C oracle inside tests/cpp/matcher_dropin_gpu.cpp) over many seeds of the synthetic world: bash tools/fuzz_dropin.sh [seeds]
+# the C oracle inside tests/cpp/matcher_dropin_gpu.cpp) over many seeds of the synthetic world: bash tests/soak/fuzz_dropin.sh [seeds]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 N=${1:-40}
 EXE=/tmp/matcher_dropin_gpu

@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""Differential soak of the Tracking-shaped front-end against the CPU oracle (test infrastructure, like tests/):
+"""Differential soak of the Tracking-shaped front-end against the CPU oracle (test infrastructure under tests/):
   * frame sets: extractor -> UndistortKeyPoints + grid on the device -> batched SearchByProjection(Cur, Last) over random
     pairs of slots, random camera / distortion / bounds / thresholds / batch sizes / shapes;
   * Frame::ComputeStereoMatches on rectified pairs with random band disparities, baselines and shapes;
   * ORBVocabulary::transform on random trees (branching, depth, raggedness, scoring, weighting, levelsup).
-On the GPU box:  python tools/fuzz_frontend.py [rounds] [seed] > gpurun_out/fuzz_frontend.txt"""
+On the GPU box:  python tests/soak/fuzz_frontend.py [rounds] [seed] > gpurun_out/fuzz_frontend.txt"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import binding as ob  # noqa: E402

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Differential soak of the ORBmatcher entry points against the CPU oracle (test infrastructure, like tests/ and
-tools/fuzz_soak.py): random sizes, thresholds, ratios and seeds through the case generators of tests/matcher_cases.py --
+"""Differential soak of the ORBmatcher entry points against the CPU oracle (test infrastructure under tests/ and
+tests/soak/fuzz_soak.py): random sizes, thresholds, ratios and seeds through the case generators of tests/matcher_cases.py --
 brute force, SearchByBoW (both forms), SearchByProjection modes 3-6, the windowed best (Fuse / SearchBySim3 device part),
 SearchForInitialization, SearchForTriangulation, ComputeDistinctiveDescriptors, GetFeaturesInArea.  On the GPU box:
-    python tools/fuzz_matchers.py [rounds] [seed] > gpurun_out/fuzz_matchers.txt
+    python tests/soak/fuzz_matchers.py [rounds] [seed] > gpurun_out/fuzz_matchers.txt
 Exit code 1 on the first difference (the case is printed)."""
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from matcher_cases import make_bow_case, make_init_case, make_proj_case, make_tri_case, noisy_copies  # noqa: E402

@@ -4,9 +4,9 @@ stream of results must not depend on HOW it is driven.  Per round a random (mode
 plain form -- a handle per robot, one ticket deep, attached frame set, pinned camera ring -- and then in random other
 forms (two tickets deep, detached, pageable frames, one or two latency streams, behind camera hubs of random size and
 waiting time); the per-robot checksum (keypoint counts, descriptor words, match-table entries of every frame) and the
-means must be equal.  Bit-exactness of these entry points against the oracle is tests/ and tools/fuzz_*.py; this soak is
+means must be equal.  Bit-exactness of these entry points against the oracle is tests/ and tests/soak/fuzz_*.py; this soak is
 about concurrency: threads, shared stream pools, hubs.  On the GPU box:
-    python tools/fuzz_multi_robot.py [rounds] [seed] > gpurun_out/fuzz_multi_robot.txt"""
+    python tests/soak/fuzz_multi_robot.py [rounds] [seed] > gpurun_out/fuzz_multi_robot.txt"""
 import json
 import os
 import subprocess
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Differential soak of the HIP extractor + stream matcher against the CPU oracle (test infrastructure, like tests/):
+"""Differential soak of the HIP extractor + stream matcher against the CPU oracle (test infrastructure under tests/):
 N random cases of (shape, ORBextractor parameters, image statistics), keypoint records and descriptor bytes compared
 byte for byte, then the brute-force match of the case's two frames.  On the GPU box:
-    python tools/fuzz_soak.py [cases] [seed] > gpurun_out/fuzz_soak.txt
+    python tests/soak/fuzz_soak.py [cases] [seed] > gpurun_out/fuzz_soak.txt
 Content kinds: the bench's synthetic scene, white noise, band-limited noise at several scales, checkerboards, ramps +
 noise, crops of the photographs in tests/golden/natural.npz, the same clipped / compressed in contrast (saturation and
 the minThFAST retry), images with flat halves (empty cells).  Exit code 1 on the first difference (the case is printed)."""
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import binding as ob  # noqa: E402

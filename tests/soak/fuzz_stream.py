@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""Stateful differential soak of ONE extractor handle as a camera stream (test infrastructure, like tests/): a random
+"""Stateful differential soak of ONE extractor handle as a camera stream (test infrastructure under tests/): a random
 schedule of the host entries (synchronous calls, pipelined tickets up to three in flight, collected as copies), the
 device-resident entry (upload + extract + match + per-frame downloads), stream resets and SHAPE CHANGES on the same
 handle, batch sizes 1..8 so that latency-mode and throughput-mode calls alternate.  Every frame's keypoints, descriptors
 and match table against the stream's previous frame are compared with the oracle's.  On the GPU box:
-    python tools/fuzz_stream.py [ops] [seed] > gpurun_out/fuzz_stream.txt"""
+    python tests/soak/fuzz_stream.py [ops] [seed] > gpurun_out/fuzz_stream.txt"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import binding as ob  # noqa: E402
 from orbslamm_amd import ORBextractor, synth  # noqa: E402

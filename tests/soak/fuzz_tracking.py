@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
 """Differential soak of the frame-set searches with caller-supplied queries and of the BoW side (test infrastructure, like
-tests/; companion of tools/fuzz_frontend.py):
+tests/; companion of tests/soak/fuzz_frontend.py):
   * Tracking::SearchLocalPoints' search (orbm_track_local_points, mode 3): a random local map against a resident frame,
     th in {1, 3, 5}, with and without features already taken;
   * TrackWithMotionModel's search with a caller's pose (orbm_track_frame_projected, modes 4 and 5): a random similarity
     applied to LastFrame's keypoints, random validity / observation flags;
   * Frame::ComputeBoW for random slot ranges + SearchByBoW(KeyFrame, Frame) over random slot pairs on random trees.
-On the GPU box:  python tools/fuzz_tracking.py [rounds] [seed] > gpurun_out/fuzz_tracking.txt"""
+On the GPU box:  python tests/soak/fuzz_tracking.py [rounds] [seed] > gpurun_out/fuzz_tracking.txt"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import binding as ob  # noqa: E402

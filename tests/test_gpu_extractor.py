@@ -520,7 +520,7 @@ def test_soak_256_frames_bit_exact(gpu, oracle):
 def test_quadtree_node_list_at_the_lds_limit(gpu, oracle, nf):
     """One pyramid level with ~2 050 features (at 640 x 480: 2 044 and 2 052 fall in the window) puts k_distribute's node list (19 words per node) within a few KB of the CU's
     160 KB of LDS: below the limit the list lives in LDS, above it in a global scratch region, and in between the kernel's own
-    static LDS used to make the launch attribute fail (found by tools/fuzz_soak.py).  All sizes must extract like the oracle."""
+    static LDS used to make the launch attribute fail (found by tests/soak/fuzz_soak.py).  All sizes must extract like the oracle."""
     w, h = 640, 480
     rng = np.random.default_rng(nf)
     img = rng.integers(0, 256, (h, w), dtype=np.uint8)   # white noise: far more corners than features asked for

@@ -403,7 +403,7 @@ def test_track_with_projections_from_the_host(gpu, oracle):
 def test_frame_to_frame_search_regrows_its_candidate_arena(gpu, oracle):
     """A small, dense frame (2 400 features on 401 x 263) searched against itself with a wide window (th = 60) lists far
     more than the arena's 64 candidates per feature: orbm_track_results grows the arena and runs the search again (it used to
-    return ORBX_E_CAPACITY -- found by tools/fuzz_frontend.py); the table equals the sequential oracle's."""
+    return ORBX_E_CAPACITY -- found by tests/soak/fuzz_frontend.py); the table equals the sequential oracle's."""
     from orbslamm_amd import ORBextractor, ORBmatcher, make_grid, synth
     w, h, nf, B = 401, 263, 2400, 2
     # a periodic texture: every corner looks like every other, so all the spatial neighbours of a query survive the Hamming
@@ -445,7 +445,7 @@ def test_frame_to_frame_search_regrows_its_candidate_arena(gpu, oracle):
 def test_search_by_bow_on_the_set_searches_the_root_node_of_a_ragged_tree(gpu, oracle):
     """A word that is a leaf ABOVE the FeatureVector's level keeps node id 0 (DBoW2: `*nid = 0`), so a frame can hold one node
     more than the level has vocabulary nodes.  The batched search launched one workgroup per node of the LEVEL and never
-    searched the node with the highest id (found by tools/fuzz_tracking.py).  Hand-built tree: k = 3, L = 3, one level-1 node
+    searched the node with the highest id (found by tests/soak/fuzz_tracking.py).  Hand-built tree: k = 3, L = 3, one level-1 node
     is a leaf; at levelsup = 1 the FeatureVectors have the six level-2 nodes + node 0."""
     from orbslamm_amd import ORBextractor, ORBmatcher, ORBVocabulary, make_grid, synth
     rng = np.random.default_rng(5)
