@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import binding as ob  # noqa: E402
 from orbslamm_amd import ORBextractor, ORBmatcher, synth, unpack_candidates  # noqa: E402
 
