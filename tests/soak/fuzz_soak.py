@@ -70,6 +70,13 @@ def make_image(rng, kind, w, h, naturals):
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    # optional: smallest side, largest width / height, largest area (defaults 96, 1400, 720, 700 000; e.g. 34 3000 1700 4000000
+    # for tiny frames the reference cannot handle -- refused -- up to 4 Mpx ones that leave the LDS-resident forms)
+    minside = int(sys.argv[3]) if len(sys.argv) > 3 else 96
+    maxw = int(sys.argv[4]) if len(sys.argv) > 4 else 1400
+    maxh = int(sys.argv[5]) if len(sys.argv) > 5 else 720
+    maxarea = int(sys.argv[6]) if len(sys.argv) > 6 else 700000
+    nfmax = int(sys.argv[7]) if len(sys.argv) > 7 else 4000   # nfeatures below this
     rng = np.random.default_rng(seed)
     z = np.load(os.path.join(ROOT, "tests", "golden", "natural.npz"))
     naturals = [z[k] for k in z.files if z[k].ndim == 2 and z[k].dtype == np.uint8 and min(z[k].shape) >= 200]
@@ -80,10 +87,10 @@ def main():
     per_kind = {k: 0 for k in kinds}
     t0 = time.time()
     while done < ncases:
-        w, h = int(rng.integers(96, 1400)), int(rng.integers(96, 720))
-        if (w - 32) / max(h - 32, 1) < 0.5 or w * h > 700000:
+        w, h = int(rng.integers(minside, maxw)), int(rng.integers(minside, maxh))
+        if (w - 32) / max(h - 32, 1) < 0.5 or w * h > maxarea:
             continue
-        nf = int(rng.integers(20, 4000))
+        nf = int(rng.integers(20, nfmax))
         sf = float(np.float32(rng.choice([1.1, 1.2, 1.2, 1.2, 1.3, 1.5, float(rng.uniform(1.05, 1.9))])))
         nl = int(rng.integers(1, 11))
         ini, mn = int(rng.integers(5, 80)), int(rng.integers(1, 30))
