@@ -325,7 +325,10 @@ typedef struct {
  * Per query: (u, v, radius), level window [minLevel,maxLevel] with GetFeaturesInArea's
  * convention, descriptor, angle (modes 4/5), valid, obs_pos (MapPoint::Observations()>0).
  * t_occ (in/out, nt): train feature must be skipped.  assign (in/out, nt): query index
- * holding train feature t, -1 = NULL. */
+ * holding train feature t, -1 = NULL.
+ * Sizes: the frame's grid lives in one CU's LDS -- at most 8192 train features per frame (ORBX_E_UNSUPPORTED beyond; the
+ * reference takes any number, its frames hold 1000-5000); any number of queries.  The same ceiling of 8192 features per
+ * frame holds for orbv_transform / orbm_frameset_compute_bow, 65535 for orbx_compute_stereo_matches. */
 typedef struct {
     int32_t mode;
     float nnratio;

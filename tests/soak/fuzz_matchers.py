@@ -26,6 +26,7 @@ def rand_desc(rng, n):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    big = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # size multiplier of the cases (3: up to ~9 000 features a side)
     rng = np.random.default_rng(seed)
     counts = {}
     t0 = time.time()
@@ -41,7 +42,7 @@ def main():
         ratio = float(np.float32(rng.choice([0.6, 0.7, 0.75, 0.8, 0.9, float(rng.uniform(0.5, 0.99))])))
         ori = bool(rng.integers(0, 2))
         # ---- brute force (the stream matcher's rule), sizes across the tile / chunk boundaries
-        nq, nt = int(rng.integers(0, 2600)), int(rng.integers(0, 2600))
+        nq, nt = int(rng.integers(0, 2600 * big)), int(rng.integers(0, 2600 * big))
         if rng.integers(0, 4) == 0:
             nt = int(rng.integers(2040, 5200))
         base = rand_desc(rng, max(nt, 1))[:nt]
@@ -55,7 +56,7 @@ def main():
             return fail("brute force", nq=nq, nt=nt, ratio=ratio, ori=ori, th=th, round=r)
         tally("bruteforce")
         # ---- SearchByBoW, both forms
-        nq, nt, nn = int(rng.integers(1, 2400)), int(rng.integers(1, 2400)), int(rng.integers(1, 120))
+        nq, nt, nn = int(rng.integers(1, 2400 * big)), int(rng.integers(1, 2400 * big)), int(rng.integers(1, 120 * big))
         c = make_bow_case(rng, nq, nt, nn)
         for by_train in (True, False):
             tv = None if by_train else c["tv"]
@@ -65,7 +66,7 @@ def main():
                 return fail("SearchByBoW", nq=nq, nt=nt, nnodes=nn, by_train=by_train, ratio=ratio, ori=ori, round=r)
             tally("bow")
         # ---- SearchByProjection modes 3-6
-        nq, nt = int(rng.integers(1, 3200)), int(rng.integers(1, 3200))
+        nq, nt = int(rng.integers(1, 3200 * big)), min(int(rng.integers(1, 3200 * big)), 8192)   # (the projection searches keep the frame's grid in LDS: at most 8 192 train features, refused beyond)
         c = make_proj_case(rng, nq, nt)
         g = make_grid(0.0, 0.0, c["w"], c["h"])
         for mode in (3, 4, 5, 6):
@@ -96,7 +97,7 @@ def main():
                 return fail("GetFeaturesInArea", x=x, y=y, r=rad, lo=lo, hi=hi, nt=nt, round=r)
             tally("area")
         # ---- SearchForInitialization
-        n1, n2 = int(rng.integers(1, 2400)), int(rng.integers(1, 2400))
+        n1, n2 = int(rng.integers(1, 2400 * big)), int(rng.integers(1, 2400 * big))
         ic = make_init_case(rng, n1, n2)
         gi_ = make_grid(0.0, 0.0, ic["w"], ic["h"])
         win = float(rng.choice([30.0, 50.0, 100.0]))
@@ -106,7 +107,7 @@ def main():
             return fail("SearchForInitialization", n1=n1, n2=n2, win=win, ratio=ratio, ori=ori, round=r)
         tally("init")
         # ---- SearchForTriangulation
-        n1, n2, nn = int(rng.integers(1, 2200)), int(rng.integers(1, 2200)), int(rng.integers(1, 80))
+        n1, n2, nn = int(rng.integers(1, 2200 * big)), int(rng.integers(1, 2200 * big)), int(rng.integers(1, 80 * big))
         tc = make_tri_case(rng, n1, n2, nn)
         cc = tc["c"]
         gmm, gn = gm.SearchForTriangulation(tc["k1"], cc["qd"], 1 - cc["qv"], cc["qfv"], tc["k2"], cc["td"], 1 - cc["tv"], cc["tfv"],
