@@ -440,13 +440,31 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
         const int mS1 = min(max(B1, oB1), min(S1, oS1)), mB1 = min(B1, oB1);
         const int myB = half ? mB1 : mB0, myS = half ? mS1 : mS0;
         const int qi = q0 + wave * 64 + lane;  // = block (lane >> 5), row lane & 31
-        if (qi < nq) {
-            const uint32_t h1 = (uint32_t)myB >> 16, h2 = (uint32_t)myS >> 16;  // empty: 0x7FFF
-            const uint32_t k1 = h1 >= 256u ? 0xFFFFFFFFu : ((h1 << 20) | ((uint32_t)myB & 0xFFFFu));
-            const uint32_t k2 = ((h2 >= 256u ? 256u : h2) << 20) | 0xFFFFFu;
-            if (nchunks > 1) partial[((int64_t)f * nchunks + chunk) * partialPitch + qi] = make_uint2(k1, k2);
-            else accept_one(acc, f, qi, k1, k2);
+        const uint32_t h1 = (uint32_t)myB >> 16, h2 = (uint32_t)myS >> 16;  // empty: 0x7FFF
+        const uint32_t k1 = h1 >= 256u ? 0xFFFFFFFFu : ((h1 << 20) | ((uint32_t)myB & 0xFFFFu));
+        const uint32_t k2 = ((h2 >= 256u ? 256u : h2) << 20) | 0xFFFFFu;
+        if (nchunks > 1) {
+            if (qi < nq) partial[((int64_t)f * nchunks + chunk) * partialPitch + qi] = make_uint2(k1, k2);
+            return;
         }
+        // the rotation histogram of the workgroup's 256 queries is counted in LDS (the ring is free: every wave's tile loads
+        // have landed) and leaves as at most 30 global atomics: one atomic per accepted match was 2.4 of the kernel's 2.6 MB
+        // of writes per step
+        int* const sh = (int*)tileB;
+        __syncthreads();
+        if (tid < 32) sh[tid] = 0;
+        __syncthreads();
+        if (qi < nq) {
+            int bin;
+            const int m = accept_decide(acc, f, qi, k1, k2, bin);
+            if (bin >= 0) {
+                acc.binOf[(int64_t)f * acc.matchPitch + qi] = (uint8_t)bin;
+                atomicAdd(&sh[bin], 1);
+            }
+            acc.match[(int64_t)f * acc.matchPitch + qi] = m;
+        }
+        __syncthreads();
+        if (tid < 32 && sh[tid]) atomicAdd(&acc.hist[f * 32 + tid], sh[tid]);
     }
 }
 

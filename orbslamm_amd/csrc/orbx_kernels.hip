@@ -1811,7 +1811,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
                                                     const int32_t* __restrict__ keptCount,
                                                     OrbxKeyPointDev* __restrict__ outKps,
                                                     uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount, int nframes,
-                                                    uint8_t* __restrict__ outX, int64_t xPitch)
+                                                    uint8_t* __restrict__ outX, int64_t xPitch, int64_t xAngOff)
 {
 #ifdef ORBX_ORIENT_TIMING
     uint64_t ts[10]; int nts = 0;
@@ -2067,6 +2067,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     }
     if (active) {
         ((uint16_t*)(outDesc + ((int64_t)f * g->maxKp + o) * 32))[ql] = (uint16_t)myWord;
+        if (ql == 1 && outX) *(float*)(outX + (int64_t)f * xPitch + xAngOff + (int64_t)o * 4) = angle;   // the stream matcher's compact angle array
         if (ql == 0) {
             OrbxKeyPointDev kp;
             kp.x = __fmul_rn((float)cx, L.scale);  // level 0: scale == 1.0f, identity (:1095-1101)
@@ -2116,7 +2117,7 @@ __global__ void k_raise_flag(int32_t* flag, int32_t value)
 __global__ __launch_bounds__(256) void k_roll_prev(const uint32_t* __restrict__ kpsSrc, const uint32_t* __restrict__ descSrc,
                                                   const int32_t* __restrict__ countSrc, uint32_t* __restrict__ kpsDst,
                                                   uint32_t* __restrict__ descDst, int32_t* __restrict__ countDst,
-                                                  const uint4* __restrict__ xSrc, uint4* __restrict__ xDst)
+                                                  const uint4* __restrict__ xSrc, uint4* __restrict__ xDst, int xAng16)
 {
     const int n = *countSrc;
     const int t = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
@@ -2125,6 +2126,7 @@ __global__ __launch_bounds__(256) void k_roll_prev(const uint32_t* __restrict__ 
     if (xSrc) {  // the +-1 form travels with the descriptors (whole 32-feature blocks of 4 KiB)
         const int n16 = ((n + 31) >> 5) * 256;
         for (int i = t; i < n16; i += step) xDst[i] = xSrc[i];
+        for (int i = t; i < (n + 3) >> 2; i += step) xDst[xAng16 + i] = xSrc[xAng16 + i];   // and the angles behind them
     }
     if (t == 0) *countDst = n;
 }
