@@ -238,7 +238,7 @@ constexpr int kMfmaRowsPerBlock = 64 * kMfmaWaves;
 // workgroup each, which leave their (k1, k2) keys in `partial` for k_match_accept to merge -- 9 workgroups walking
 // 63 tiles each become 72 walking 8.
 constexpr int kMfmaEmpty = 0x7FFFFFFF;                 // absolute keys (H << 16 | j)
-constexpr int kMfmaEmptyRel = 0x7F7FFFFF;              // running keys: FLT_MAX (stays FLT_MAX under "- 16")
+constexpr float kMfmaEmptyRelF = 3.402823466e+38f;     // running keys: FLT_MAX (stays FLT_MAX under "- 16")
 constexpr int kMfmaTileBytes = 32 * kMfmaDescBytes;    // 4 KiB: one global_load_lds_dwordx4 per thread
 #ifndef ORBM_XCD_RUN
 #define ORBM_XCD_RUN 1
@@ -248,7 +248,10 @@ constexpr int kMfmaTileBytes = 32 * kMfmaDescBytes;    // 4 KiB: one global_load
 #endif
 constexpr int kMfmaRing = ORBM_MFMA_RING;              // train tiles in LDS
 constexpr int kMfmaLdsBytes = kMfmaRing * kMfmaTileBytes;
-constexpr int kMfmaGroup = 4; // tiles per barrier (even)
+#ifndef ORBM_MFMA_GROUP
+#define ORBM_MFMA_GROUP 4
+#endif
+constexpr int kMfmaGroup = ORBM_MFMA_GROUP; // tiles per barrier (even)
 constexpr int kMfmaAhead = kMfmaRing - kMfmaGroup; // a group's loads are issued this many tiles ahead of its first tile
 static_assert((kMfmaRing & (kMfmaRing - 1)) == 0 && kMfmaAhead - kMfmaGroup <= 63, "ring slot by mask; vmcnt has six bits");
 __device__ __forceinline__ int mfma_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
                      "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
     };
     // (tied to the last key of the step so that the wait stays behind the step's arithmetic)
-    auto landed = [&](int& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(kMfmaAhead - kMfmaGroup) : "memory"); };
+    auto landed = [&](float& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(kMfmaAhead - kMfmaGroup) : "memory"); };
     // queries negated (E2M1 sign bits: x ^ 0x88888888): the accumulator counts -(a . b); using the fragments here also
     // retires their loads before the asm loads start counting
 #pragma unroll
@@ -338,46 +341,56 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
     constexpr float kBias = 524288.f;  // 2^19: every key a positive float
     const v16f rowIdx = {kBias, kBias + 1, kBias + 2, kBias + 3, kBias + 4, kBias + 5, kBias + 6, kBias + 7,
                          kBias + 8, kBias + 9, kBias + 10, kBias + 11, kBias + 12, kBias + 13, kBias + 14, kBias + 15};
-    int b0 = kMfmaEmptyRel, s0 = kMfmaEmptyRel, b1 = kMfmaEmptyRel, s1 = kMfmaEmptyRel;  // keys relative to the tile folded last
+    // running keys, relative to the tile folded last -- kept and compared AS FLOATS: every key is a positive normal float (no NaN, no
+    // denormal), so the float order is the integer order of the bits, and on floats hipcc forms v_min3_f32 and takes v_med3_f32
+    // from a builtin -- on the bit patterns it shares min(best, k) between its med3 pattern and the best's update and loses the v_min3
+    float b0 = kMfmaEmptyRelF, s0 = kMfmaEmptyRelF, b1 = kMfmaEmptyRelF, s1 = kMfmaEmptyRelF;
     int B0 = kMfmaEmpty, S0 = kMfmaEmpty, B1 = kMfmaEmpty, S1 = kMfmaEmpty;              // H << 16 | j, of the epochs flushed so far
     int nfold = 0;
     auto mfma = [](const v4i& a, const v4i& b, const v16f& c) {  // fp4 x fp4 (cbsz = blgp = 4), block scales 2^5 each
         const v8i a8 = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8 = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 132, 0, 132);
     };
-    auto products = [&](int slot, v16f& a0, v16f& a1) {
+    // a tile's fragments are read from the ring one tile AHEAD of their products (two register sets): read at its point of
+    // use, the LDS latency of every tile stood in front of its first MFMA -- a quarter of the kernel (round 5 ablation)
+    struct Tile { v4i s[4]; };
+    auto read_tile = [&](int slot, Tile& T) {
         const v4i* bt = (const v4i*)(tileB + slot * kTileItems);
-        v4i T[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) T[s] = bt[s * 64 + lane];
-        a0 = mfma(T[0], Q[0][0], rowIdx);
-        a1 = mfma(T[0], Q[1][0], rowIdx);
+        for (int s = 0; s < 4; s++) T.s[s] = bt[s * 64 + lane];
+    };
+    auto products = [&](const Tile& T, v16f& a0, v16f& a1) {
+        a0 = mfma(T.s[0], Q[0][0], rowIdx);
+        a1 = mfma(T.s[0], Q[1][0], rowIdx);
 #pragma unroll
         for (int s = 1; s < 4; s++) {
-            a0 = mfma(T[s], Q[0][s], a0);
-            a1 = mfma(T[s], Q[1][s], a1);
+            a0 = mfma(T.s[s], Q[0][s], a0);
+            a1 = mfma(T.s[s], Q[1][s], a1);
         }
     };
     auto flush = [&]() {  // relative keys of this epoch -> absolute, merged behind the earlier epochs (which win ties)
         const int now = tile0 + nfold - 1;
-        const int cb0 = mfma_key_abs(b0, now, half), cs0 = mfma_key_abs(s0, now, half);
-        const int cb1 = mfma_key_abs(b1, now, half), cs1 = mfma_key_abs(s1, now, half);
+        const int cb0 = mfma_key_abs(__float_as_int(b0), now, half), cs0 = mfma_key_abs(__float_as_int(s0), now, half);
+        const int cb1 = mfma_key_abs(__float_as_int(b1), now, half), cs1 = mfma_key_abs(__float_as_int(s1), now, half);
         S0 = min(max(B0, cb0), min(S0, cs0)); B0 = min(B0, cb0);
         S1 = min(max(B1, cb1), min(S1, cs1)); B1 = min(B1, cb1);
-        b0 = s0 = b1 = s1 = kMfmaEmptyRel;
+        b0 = s0 = b1 = s1 = kMfmaEmptyRelF;
     };
-    auto older = [](int bits) { return __float_as_int(__int_as_float(bits) - 16.f); };
+    auto older = [](float key) { return key - 16.f; };
     auto fold = [&](const v16f& a0, const v16f& a1) {
         // compiler-visible VALU ops on the accumulator: hipcc pads the MFMA -> VALU read hazard itself
         // (an inline-asm consumer would read the accumulator too early)
         b0 = older(b0); s0 = older(s0); b1 = older(b1); s1 = older(s1);
+        // two keys per step: the new second is min(second, median(best, k, k')) -- the runner-up of {best, k, k'} is their
+        // median, and the old second only has to beat that -- the new best min3(best, k, k'): v_med3 + v_min3 per two keys and
+        // one v_min3 per four for the seconds, 2.5 instructions per two keys where min + med3 per key took four (round 5)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int k0 = __float_as_int(a0[r]), k1 = __float_as_int(a1[r]);
-            s0 = med3i(b0, k0, s0);
-            b0 = min(b0, k0);
-            s1 = med3i(b1, k1, s1);
-            b1 = min(b1, k1);
+        for (int r = 0; r < 16; r += 2) {
+            const float k0 = a0[r], k0n = a0[r + 1], k1 = a1[r], k1n = a1[r + 1];
+            s0 = __builtin_fminf(s0, __builtin_amdgcn_fmed3f(b0, k0, k0n));
+            b0 = __builtin_fminf(__builtin_fminf(b0, k0), k0n);
+            s1 = __builtin_fminf(s1, __builtin_amdgcn_fmed3f(b1, k1, k1n));
+            b1 = __builtin_fminf(__builtin_fminf(b1, k1), k1n);
         }
         ++nfold;  // (the epoch's flush is the caller's: a branch here parts the fold from the products it should run beside)
     };
@@ -385,13 +398,14 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
         b0 = older(b0); s0 = older(s0); b1 = older(b1); s1 = older(s1);
         const int jrow = (tile0 + ntiles - 1) * 32 + 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const bool in = jrow + (r & 3) + 8 * (r >> 2) < nt;
-            const int k0 = in ? __float_as_int(a0[r]) : kMfmaEmptyRel, k1 = in ? __float_as_int(a1[r]) : kMfmaEmptyRel;
-            s0 = med3i(b0, k0, s0);
-            b0 = min(b0, k0);
-            s1 = med3i(b1, k1, s1);
-            b1 = min(b1, k1);
+        for (int r = 0; r < 16; r += 2) {
+            const bool in = jrow + (r & 3) + 8 * (r >> 2) < nt, inn = jrow + ((r + 1) & 3) + 8 * ((r + 1) >> 2) < nt;
+            const float k0 = in ? a0[r] : kMfmaEmptyRelF, k0n = inn ? a0[r + 1] : kMfmaEmptyRelF;
+            const float k1 = in ? a1[r] : kMfmaEmptyRelF, k1n = inn ? a1[r + 1] : kMfmaEmptyRelF;
+            s0 = __builtin_fminf(s0, __builtin_amdgcn_fmed3f(b0, k0, k0n));
+            b0 = __builtin_fminf(__builtin_fminf(b0, k0), k0n);
+            s1 = __builtin_fminf(s1, __builtin_amdgcn_fmed3f(b1, k1, k1n));
+            b1 = __builtin_fminf(__builtin_fminf(b1, k1), k1n);
         }
         nfold++;
         flush();
@@ -405,26 +419,36 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
         __syncthreads();
         // two tiles per barrier: tile a's products into one accumulator set while the other (tile a - 1) is folded,
         // then the same with the sets exchanged
-        auto group_step = [&](int a, auto first) {
+        // (a whole group is one basic block: the tile reads of the group's later tiles can rise above the folds before them)
+        auto group_step = [&](int a, auto first, auto whole) {
 #pragma unroll
             for (int i = 0; i < kMfmaGroup; i++) issue(a + kMfmaAhead + i);
-            products(a & (kMfmaRing - 1), accE0, accE1);
-            if (!decltype(first)::value) fold(accO0, accO1);
+            Tile TE, TO;
+            read_tile(a & (kMfmaRing - 1), TE);
 #pragma unroll
-            for (int i = 1; i < kMfmaGroup; i++) {
-                if (a + i >= ntiles) break;
-                if (i & 1) { products((a + i) & (kMfmaRing - 1), accO0, accO1); fold(accE0, accE1); }
-                else       { products((a + i) & (kMfmaRing - 1), accE0, accE1); fold(accO0, accO1); }
+            for (int i = 0; i < kMfmaGroup; i++) {
+                if (!decltype(whole)::value && i > 0 && a + i >= ntiles) break;
+                // (a slot past the frame's last tile holds that tile again: read, never multiplied)
+                if (i + 1 < kMfmaGroup) read_tile((a + i + 1) & (kMfmaRing - 1), (i & 1) ? TE : TO);
+                __builtin_amdgcn_sched_barrier(0);  // the reads stay up here
+                if (i & 1) { products(TO, accO0, accO1); fold(accE0, accE1); }
+                else {
+                    products(TE, accE0, accE1);
+                    if (i > 0 || !decltype(first)::value) fold(accO0, accO1);
+                }
             }
             landed(s1);
             __syncthreads();
         };
-        group_step(0, std::true_type());
+        if (kMfmaGroup <= ntiles) group_step(0, std::true_type(), std::true_type());
+        else group_step(0, std::true_type(), std::false_type());
         // epochs of whole groups, 64 - kMfmaGroup tiles at most (the first holds the first group's folds as well, the last fold_last's): 64 folds at most between flushes
         constexpr int kEpoch = (64 - kMfmaGroup) / kMfmaGroup * kMfmaGroup;
         for (int e0 = kMfmaGroup; e0 < ntiles; e0 += kEpoch) {
             const int e1 = min(ntiles, e0 + kEpoch);
-            for (int a = e0; a < e1; a += kMfmaGroup) group_step(a, std::false_type());
+            int a = e0;
+            for (; a + kMfmaGroup <= e1; a += kMfmaGroup) group_step(a, std::false_type(), std::true_type());
+            if (a < e1) group_step(a, std::false_type(), std::false_type());
             flush();
         }
         if (ntiles & 1) fold_last(accE0, accE1); else fold_last(accO0, accO1);

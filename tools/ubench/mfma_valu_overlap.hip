@@ -1,0 +1,71 @@
+// micro-benchmark: does VALU work issue in the shadow of v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 operands) on gfx950?
+// One loop iteration = 8 MFMAs in two accumulator chains (the stream matcher's tile step) + NV independent v_min3_f32 of the
+// same wave, interleaved.  Waves per SIMD 1 or 2.  If the time per iteration is max(MFMA, VALU) the two overlap; if it is the sum
+// they do not.
+//   hipcc --offload-arch=gfx950 -O2 tools/ubench/mfma_valu_overlap.hip -o build_ub/mfma_valu_overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+template <int NV, bool MF>
+__global__ __launch_bounds__(256) void k(float* out, int iters)
+{
+    v8i A = {(int)threadIdx.x, 2, 3, 4, 0, 0, 0, 0}, B = {5, (int)threadIdx.x * 7, 7, 8, 0, 0, 0, 0};
+    v16f c0 = {}, c1 = {};
+    float m[8];
+    for (int i = 0; i < 8; i++) m[i] = (float)(threadIdx.x + i);
+    const float x = out[0], y = out[1];
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (MF) {
+                c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c0, 4, 4, 0, 127, 0, 127);
+#pragma unroll
+                for (int v = 0; v < NV / 8; v++) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(m[v & 7]) : "v"(x), "v"(y));
+                c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B, A, c1, 4, 4, 0, 127, 0, 127);
+#pragma unroll
+                for (int v = 0; v < NV / 8; v++) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(m[(v + 4) & 7]) : "v"(x), "v"(y));
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV / 4; v++) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(m[v & 7]) : "v"(x), "v"(y));
+            }
+        }
+    }
+    float r = 0;
+    for (int i = 0; i < 16; i++) r += c0[i] + c1[i];
+    for (int i = 0; i < 8; i++) r += m[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int NV, bool MF>
+static void run(float* d, int wgPerCu, const char* what)
+{
+    const int iters = 20000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(e0);
+        k<NV, MF><<<256 * wgPerCu, 256>>>(d, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("%-22s NV=%2d waves/SIMD=%d: %.1f ns per iteration per wave-slot (%.1f ns per iteration of the SIMD)\n", what, NV, wgPerCu,
+           ms * 1e6 / iters / wgPerCu, ms * 1e6 / iters);
+}
+
+int main()
+{
+    float* d; hipMalloc(&d, 256 * 2 * 256 * 4); hipMemset(d, 0, 256 * 2 * 256 * 4);
+    for (int w = 1; w <= 2; w++) {
+        run<0, true>(d, w, "8 MFMA");
+        run<32, false>(d, w, "VALU only");
+        run<64, false>(d, w, "VALU only");
+        run<16, true>(d, w, "8 MFMA + VALU");
+        run<32, true>(d, w, "8 MFMA + VALU");
+        run<48, true>(d, w, "8 MFMA + VALU");
+        run<64, true>(d, w, "8 MFMA + VALU");
+        run<96, true>(d, w, "8 MFMA + VALU");
+    }
+    return 0;
+}
