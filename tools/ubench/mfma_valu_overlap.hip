@@ -54,6 +54,45 @@ static void run(float* d, int wgPerCu, const char* what)
            ms * 1e6 / iters / wgPerCu, ms * 1e6 / iters);
 }
 
+// one wave, FOUR accumulator chains: 16 MFMAs + NV VALU per iteration (a wave that owns four query blocks)
+template <int NV>
+__global__ __launch_bounds__(256) void k4(float* out, int iters)
+{
+    v8i A = {(int)threadIdx.x, 2, 3, 4, 0, 0, 0, 0}, B = {5, (int)threadIdx.x * 7, 7, 8, 0, 0, 0, 0};
+    v16f c[4] = {};
+    float m[8];
+    for (int i = 0; i < 8; i++) m[i] = (float)(threadIdx.x + i);
+    const float x = out[0], y = out[1];
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                c[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c[q], 4, 4, 0, 127, 0, 127);
+#pragma unroll
+                for (int v = 0; v < NV / 16; v++) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(m[(v + q * 2) & 7]) : "v"(x), "v"(y));
+            }
+    }
+    float r = 0;
+    for (int q = 0; q < 4; q++) for (int i = 0; i < 16; i++) r += c[q][i];
+    for (int i = 0; i < 8; i++) r += m[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int NV>
+static void run4(float* d)
+{
+    const int iters = 20000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(e0);
+        k4<NV><<<256, 256>>>(d, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("16 MFMA in 4 chains + VALU NV=%3d, 1 wave/SIMD: %.1f ns per iteration of the SIMD\n", NV, ms * 1e6 / iters);
+}
+
 int main()
 {
     float* d; hipMalloc(&d, 256 * 2 * 256 * 4); hipMemset(d, 0, 256 * 2 * 256 * 4);
@@ -67,5 +106,6 @@ int main()
         run<64, true>(d, w, "8 MFMA + VALU");
         run<96, true>(d, w, "8 MFMA + VALU");
     }
+    run4<0>(d); run4<64>(d); run4<96>(d); run4<128>(d); run4<160>(d);
     return 0;
 }
