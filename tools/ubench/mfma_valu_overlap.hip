@@ -93,6 +93,62 @@ static void run4(float* d)
     printf("16 MFMA in 4 chains + VALU NV=%3d, 1 wave/SIMD: %.1f ns per iteration of the SIMD\n", NV, ms * 1e6 / iters);
 }
 
+// the matcher's real pattern: 8 MFMAs into one accumulator set while the VALU folds the OTHER set (written by the MFMAs of
+// the iteration before): 40 v_min3/v_med3 reading accumulator registers.  MODE 0: fold reads the other set; 1: fold reads
+// plain registers (same instruction mix, no MFMA-written sources)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k5  // (…, 2): accumulators in VGPRs -- with one wave per SIMD allowed hipcc moves them to AGPRs and reads every key back with v_accvgpr_read
+(float* out, int iters)
+{
+    v8i A = {(int)threadIdx.x, 2, 3, 4, 0, 0, 0, 0}, B = {5, (int)threadIdx.x * 7, 7, 8, 0, 0, 0, 0};
+    v16f e0 = {}, e1 = {}, o0 = {}, o1 = {}, p0, p1;
+    for (int i = 0; i < 16; i++) { p0[i] = out[i] + threadIdx.x; p1[i] = out[i + 16] - threadIdx.x; }
+    float b0 = out[2], s0 = out[3], b1 = out[4], s1 = out[5];
+    auto fold = [&](const v16f& a0, const v16f& a1) {
+        b0 -= 16.f; s0 -= 16.f; b1 -= 16.f; s1 -= 16.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            s0 = __builtin_fminf(s0, __builtin_amdgcn_fmed3f(b0, a0[r], a0[r + 1]));
+            b0 = __builtin_fminf(__builtin_fminf(b0, a0[r]), a0[r + 1]);
+            s1 = __builtin_fminf(s1, __builtin_amdgcn_fmed3f(b1, a1[r], a1[r + 1]));
+            b1 = __builtin_fminf(__builtin_fminf(b1, a1[r]), a1[r + 1]);
+        }
+    };
+    auto prod = [&](v16f& a0, v16f& a1) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, a0, 4, 4, 0, 127, 0, 127);
+            a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B, A, a1, 4, 4, 0, 127, 0, 127);
+        }
+    };
+    for (int it = 0; it < iters; it += 2) {
+        asm volatile("" : "+v"(A), "+v"(B));
+        prod(e0, e1); if (MODE == 0) fold(o0, o1); else { asm volatile("" : "+v"(p0), "+v"(p1)); fold(p0, p1); }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(A), "+v"(B));
+        prod(o0, o1); if (MODE == 0) fold(e0, e1); else { asm volatile("" : "+v"(p0), "+v"(p1)); fold(p0, p1); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float r = b0 + s0 + b1 + s1;
+    for (int i = 0; i < 16; i++) r += e0[i] + e1[i] + o0[i] + o1[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int MODE>
+static void run5(float* d, int wgPerCu)
+{
+    const int iters = 20000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(e0);
+        k5<MODE><<<256 * wgPerCu, 256>>>(d, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("8 MFMA + the matcher's fold (44 VALU) %s, waves/SIMD=%d: %.1f ns per iteration of the SIMD\n",
+           MODE == 0 ? "reading the other accumulator set" : "reading plain registers", wgPerCu, ms * 1e6 / iters);
+}
+
 int main()
 {
     float* d; hipMalloc(&d, 256 * 2 * 256 * 4); hipMemset(d, 0, 256 * 2 * 256 * 4);
@@ -106,6 +162,7 @@ int main()
         run<64, true>(d, w, "8 MFMA + VALU");
         run<96, true>(d, w, "8 MFMA + VALU");
     }
+    run5<0>(d, 1); run5<1>(d, 1); run5<0>(d, 2); run5<1>(d, 2);
     run4<0>(d); run4<64>(d); run4<96>(d); run4<128>(d); run4<160>(d);
     return 0;
 }
