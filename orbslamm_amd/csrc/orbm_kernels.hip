@@ -240,6 +240,12 @@ constexpr int kMfmaRowsPerBlock = 64 * kMfmaWaves;
 constexpr int kMfmaEmpty = 0x7FFFFFFF;                 // absolute keys (H << 16 | j)
 constexpr float kMfmaEmptyRelF = 3.402823466e+38f;     // running keys: FLT_MAX (stays FLT_MAX under "- 16")
 constexpr int kMfmaTileBytes = 32 * kMfmaDescBytes;    // 4 KiB: one global_load_lds_dwordx4 per thread
+#ifndef ORBM_ROWIDX_RESIDENT
+#define ORBM_ROWIDX_RESIDENT 1
+#endif
+#ifndef ORBM_FILL_FIRST
+#define ORBM_FILL_FIRST 1
+#endif
 #ifndef ORBM_XCD_RUN
 #define ORBM_XCD_RUN 1
 #endif
@@ -304,12 +310,6 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
     const uint4* tsrc = (const uint4*)(xdesc + (int64_t)(tslot0 + f) * xPitch) + (int64_t)tile0 * kTileItems;
     const int qblk0 = (q0 >> 5) + wave * 2;
 
-    v4i Q[2][4];
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-        for (int s = 0; s < 4; s++) Q[qb][s] = *(const v4i*)(qx + (int64_t)(qblk0 + qb) * kMfmaTileBytes + s * 1024 + lane * 16);
-
     // train tiles go from memory straight into the LDS ring (global_load_lds_dwordx4: the wave's 64 lanes fill one
     // contiguous KiB at M0; wave w owns KiB w of a tile), kMfmaAhead tiles ahead: a tile's first reader in an XCD
     // waits for HBM, and a few tiles of distance do not cover that (int8 form, 0.65 us per tile: four ahead 0.094 ms,
@@ -325,6 +325,20 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
                      "global_load_lds_dwordx4 %1, off\n\t"
                      "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
     };
+#if ORBM_FILL_FIRST
+    // the ring's first fills go out BEFORE the query fragments are fetched: both wait for memory, and behind each other
+    // they cost the workgroup two round trips before its first product (all 512 workgroups of a step start together)
+    if (ntiles > 0) {
+#pragma unroll
+        for (int t = 0; t < kMfmaAhead; t++) issue(t);
+    }
+#endif
+    v4i Q[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) Q[qb][s] = *(const v4i*)(qx + (int64_t)(qblk0 + qb) * kMfmaTileBytes + s * 1024 + lane * 16);
+
     // (tied to the last key of the step so that the wait stays behind the step's arithmetic)
     auto landed = [&](float& after) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(after) : "n"(kMfmaAhead - kMfmaGroup) : "memory"); };
     // queries negated (E2M1 sign bits: x ^ 0x88888888): the accumulator counts -(a . b); using the fragments here also
@@ -339,8 +353,13 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     constexpr float kBias = 524288.f;  // 2^19: every key a positive float
-    const v16f rowIdx = {kBias, kBias + 1, kBias + 2, kBias + 3, kBias + 4, kBias + 5, kBias + 6, kBias + 7,
-                         kBias + 8, kBias + 9, kBias + 10, kBias + 11, kBias + 12, kBias + 13, kBias + 14, kBias + 15};
+    v16f rowIdx = {kBias, kBias + 1, kBias + 2, kBias + 3, kBias + 4, kBias + 5, kBias + 6, kBias + 7,
+                   kBias + 8, kBias + 9, kBias + 10, kBias + 11, kBias + 12, kBias + 13, kBias + 14, kBias + 15};
+#if ORBM_ROWIDX_RESIDENT
+    // sixteen registers that stay: as constants hipcc rebuilds them in front of every tile's first products (8 v_mov_b64 per
+    // tile and wave, two passes each), as registers they are just the C operand of a chain's first MFMA
+    asm volatile("" : "+v"(rowIdx));
+#endif
     // running keys, relative to the tile folded last -- kept and compared AS FLOATS: every key is a positive normal float (no NaN, no
     // denormal), so the float order is the integer order of the bits, and on floats hipcc forms v_min3_f32 and takes v_med3_f32
     // from a builtin -- on the bit patterns it shares min(best, k) between its med3 pattern and the best's update and loses the v_min3
@@ -413,8 +432,10 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
 
     if (ntiles > 0) {
         v16f accE0, accE1, accO0, accO1;
+#if !ORBM_FILL_FIRST
 #pragma unroll
         for (int t = 0; t < kMfmaAhead; t++) issue(t);
+#endif
         landed(s1);
         __syncthreads();
         // two tiles per barrier: tile a's products into one accumulator set while the other (tile a - 1) is folded,
