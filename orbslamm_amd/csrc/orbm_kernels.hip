@@ -246,6 +246,9 @@ constexpr int kMfmaTileBytes = 32 * kMfmaDescBytes;    // 4 KiB: one global_load
 #ifndef ORBM_FILL_FIRST
 #define ORBM_FILL_FIRST 1
 #endif
+#ifndef ORBM_MATCH_PRIO
+#define ORBM_MATCH_PRIO 3
+#endif
 #ifndef ORBM_XCD_RUN
 #define ORBM_XCD_RUN 1
 #endif
@@ -276,6 +279,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
                                                       AcceptArgs acc, int nqb, int nframes,
                                                       uint2* __restrict__ partial, int64_t partialPitch)
 {
+#if ORBM_MATCH_PRIO
+    __builtin_amdgcn_s_setprio(ORBM_MATCH_PRIO);
+#endif
     const int32_t* __restrict__ count = acc.q.count;  // q.count and t.count index the same slot table here
     const int qslot0 = acc.qslot0, tslot0 = acc.tslot0;
     extern __shared__ uint4 tileB[];  // [kMfmaRing][256]

@@ -104,6 +104,18 @@ __global__ __launch_bounds__(256) void k_resize_level(const Geom* __restrict__ g
 // (ping-pong) and writes only the owned pixels to HBM.  The level-0 source tile is
 // staged with aligned dword loads.  Same fixed-point arithmetic as k_resize.
 constexpr int kPyrStrips = 2;   // level-0 tile of k_pyramid: strips per block (host sizing and kernel)
+#ifndef ORBX_DESC_PRIO
+#define ORBX_DESC_PRIO 0
+#endif
+#ifndef ORBX_BLUR_PRIO
+#define ORBX_BLUR_PRIO 0
+#endif
+#ifndef ORBX_DIST_PRIO
+#define ORBX_DIST_PRIO 0
+#endif
+#ifndef ORBX_PYR_PRIO
+#define ORBX_PYR_PRIO 3
+#endif
 #ifndef ORBX_PYR_THREADS
 #define ORBX_PYR_THREADS 256
 #endif
@@ -119,6 +131,9 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(const Geom* __restrict_
 {
     // one LDS array addressed with integer offsets (keeps every access in the LDS address space)
     extern __shared__ __attribute__((aligned(16))) uint32_t plds[];
+#if ORBX_PYR_PRIO
+    __builtin_amdgcn_s_setprio(ORBX_PYR_PRIO);
+#endif
     uint8_t* const ldsb = (uint8_t*)plds;
     const int offBuf[2] = {0, bufAWords * 4};            // even / odd levels (bytes)
     uint2* const sxt = (uint2*)(plds + bufAWords + bufBWords);  // staged {sx,a0 | a1,interp}
@@ -1366,6 +1381,9 @@ __device__ __forceinline__ void distribute_body(const DistArgs& da, const int bx
 template <bool LDS>
 __global__ __launch_bounds__(kDistThreads) void k_distribute(DistArgs da)
 {
+#if ORBX_DIST_PRIO
+    __builtin_amdgcn_s_setprio(ORBX_DIST_PRIO);
+#endif
     distribute_body<LDS>(da, (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -1701,6 +1719,9 @@ __device__ __forceinline__ void blur_mfma_tile(const Geom* __restrict__ g, const
 
 __global__ __launch_bounds__(256, 2) void k_blur_mfma(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt, int nframes)
 {
+#if ORBX_BLUR_PRIO
+    __builtin_amdgcn_s_setprio(ORBX_BLUR_PRIO);
+#endif
     __shared__ __attribute__((aligned(16))) uint32_t in[kBlurMfmaInWords];
     __shared__ uint32_t outT[kBlurMfmaOutWords];
     int bx, fr;
@@ -1813,6 +1834,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
                                                     uint8_t* __restrict__ outDesc, int32_t* __restrict__ outCount, int nframes,
                                                     uint8_t* __restrict__ outX, int64_t xPitch, int64_t xAngOff)
 {
+#if ORBX_DESC_PRIO
+    __builtin_amdgcn_s_setprio(ORBX_DESC_PRIO);
+#endif
 #ifdef ORBX_ORIENT_TIMING
     uint64_t ts[10]; int nts = 0;
 #define OSTAMP() ts[nts++] = wall_clock64()
