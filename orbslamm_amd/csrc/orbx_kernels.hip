@@ -815,6 +815,7 @@ __device__ __forceinline__ void wave_divide(const uint64_t* __restrict__ srcb, u
 struct DistArgs {
     const Geom* g; const uint64_t* candRaw; uint64_t* candA; uint64_t* candB; const Cell* cells; const int32_t* cellCount;
     int32_t* candCount; uint64_t* kept; int32_t* keptCount; int32_t* errFlag; int cap, f0; uint32_t* gscratch; int scratchWords, l0;
+    int xcdFrames;   // >= 8: grid (levels, xcd_grid_y(frames)), a frame's levels on the XCD that ran its FAST cells and will run its descriptors
 };
 
 // the body of k_distribute for block (bxLevel, by) of a (levels, frames) grid
@@ -1384,7 +1385,9 @@ __global__ __launch_bounds__(kDistThreads) void k_distribute(DistArgs da)
 #if ORBX_DIST_PRIO
     __builtin_amdgcn_s_setprio(ORBX_DIST_PRIO);
 #endif
-    distribute_body<LDS>(da, (int)blockIdx.x, (int)blockIdx.y);
+    int lvl = (int)blockIdx.x, fr = (int)blockIdx.y;
+    if (da.xcdFrames >= 8 && !xcd_block_frame(da.xcdFrames, lvl, fr)) return;
+    distribute_body<LDS>(da, lvl, fr);
 }
 
 // ------------------------------------------------------------------ Gaussian 7x7 sigma 2
