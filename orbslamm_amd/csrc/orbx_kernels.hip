@@ -127,7 +127,7 @@ struct PyrRange {
 
 __global__ __launch_bounds__(kPyrThreads) void k_pyramid(const Geom* __restrict__ g, FrameSrc src, ResizeTabs tabs,
                                                 const PyrRange* __restrict__ ranges, int bufAWords, int bufBWords,
-                                                int tabCap)
+                                                int tabCap, int xcdFrames)
 {
     // one LDS array addressed with integer offsets (keeps every access in the LDS address space)
     extern __shared__ __attribute__((aligned(16))) uint32_t plds[];
@@ -138,9 +138,13 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(const Geom* __restrict_
     const int offBuf[2] = {0, bufAWords * 4};            // even / odd levels (bytes)
     uint2* const sxt = (uint2*)(plds + bufAWords + bufBWords);  // staged {sx,a0 | a1,interp}
     uint2* const syt = sxt + tabCap;                              // staged {sy0,sy1 | b0,b1}
-    const int f = blockIdx.y + src.f0;
+    // xcdFrames >= 8: grid (blocks, xcd_grid_y(frames)) -- a frame's blocks on the XCD that runs its FAST cells, blur tiles and
+    // descriptors (the plain grid puts block b of every frame on XCD b mod 8)
+    int pblk = (int)blockIdx.x, pfr = (int)blockIdx.y;
+    if (xcdFrames >= 8 && !xcd_block_frame(xcdFrames, pblk, pfr)) return;
+    const int f = pfr + src.f0;
     const int nl = g->nlevels;
-    const PyrRange* R = ranges + (int64_t)blockIdx.x * nl;
+    const PyrRange* R = ranges + (int64_t)pblk * nl;
     const int tid = threadIdx.x;
 
     // Level 0 is the caller's frame: its tile (the largest, 22 KB of the 41 KB this kernel used to hold -- exactly a

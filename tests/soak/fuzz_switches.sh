@@ -19,6 +19,7 @@ run ORBX_SPLIT=3
 run ORBX_SPLIT=4
 run ORBX_SERIAL=1
 run ORBX_DIST_XCD=0
+run ORBX_PYR_XCD=0
 run ORBX_LAT_STREAMS=2
 run ORBX_LAT_DMA=1
 run ORBX_LAT_PRIO=0
