@@ -2,7 +2,7 @@
 """Differential soak of the HIP extractor + stream matcher against the CPU oracle (test infrastructure under tests/):
 N random cases of (shape, ORBextractor parameters, image statistics), keypoint records and descriptor bytes compared
 byte for byte, then the brute-force match of the case's two frames.  On the GPU box:
-    python tests/soak/fuzz_soak.py [cases] [seed] > gpurun_out/fuzz_soak.txt
+    python tests/soak/fuzz_soak.py [cases] [seed] [minside maxw maxh maxarea nfmax [frames-per-call choices, e.g. 8,17,33,64]] > gpurun_out/fuzz_soak.txt
 Content kinds: the bench's synthetic scene, white noise, band-limited noise at several scales, checkerboards, ramps +
 noise, crops of the photographs in tests/golden/natural.npz, the same clipped / compressed in contrast (saturation and
 the minThFAST retry), images with flat halves (empty cells).  Exit code 1 on the first difference (the case is printed)."""
@@ -77,6 +77,7 @@ def main():
     maxh = int(sys.argv[5]) if len(sys.argv) > 5 else 720
     maxarea = int(sys.argv[6]) if len(sys.argv) > 6 else 700000
     nfmax = int(sys.argv[7]) if len(sys.argv) > 7 else 4000   # nfeatures below this
+    bchoices = [int(x) for x in sys.argv[8].split(',')] if len(sys.argv) > 8 else [2, 2, 2, 3, 4, 6, 9]   # frames per call (sub-batches of >= 8 frames take the XCD-aware grids)
     rng = np.random.default_rng(seed)
     z = np.load(os.path.join(ROOT, "tests", "golden", "natural.npz"))
     naturals = [z[k] for k in z.files if z[k].ndim == 2 and z[k].dtype == np.uint8 and min(z[k].shape) >= 200]
@@ -95,7 +96,7 @@ def main():
         nl = int(rng.integers(1, 11))
         ini, mn = int(rng.integers(5, 80)), int(rng.integers(1, 30))
         kind = kinds[int(rng.integers(0, len(kinds)))]
-        B = int(rng.choice([2, 2, 2, 3, 4, 6, 9]))
+        B = int(rng.choice(bchoices))
         try:
             gex = ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B, device=0)
         except Exception as e:  # shapes the reference would crash on are refused (ORBX_E_UNSUPPORTED)
