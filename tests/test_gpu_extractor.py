@@ -529,3 +529,17 @@ def test_quadtree_node_list_at_the_lds_limit(gpu, oracle, nf):
     k, d = gex(img)
     assert len(k) > 2000
     assert_same(ref, k, d)
+
+
+@pytest.mark.parametrize("B", [17, 27, 40])
+def test_sub_batches_on_the_xcd_aware_grids(gpu, oracle, B):
+    """Calls of 16+ frames run as two sub-batches of 8+ frames: pyramid, FAST, quadtree, blur and descriptors then deal a
+    frame's workgroups to ONE XCD (grid rows padded to a multiple of 8, surplus workgroups return).  Odd sub-batch sizes
+    (8 + 9, 13 + 14, 20 + 20), every frame against the oracle."""
+    w, h, nf = 417, 301, 600
+    fr = frames_for(w, h, B, stream=1)
+    gex = gpu_extractor(nf, w, h, B=B)
+    kb, db = gex.extract_batch(fr)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    for f in range(B):
+        assert_same(oex(fr[f]), kb[f], db[f])
