@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the (untimed) host-buffer entry measurements")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of two frames of the last timed step")
+    ap.add_argument("--no-natural", action="store_true", help="skip the (untimed) 64-frame steps over natural-image sequences (tests/golden/natural.npz)")
     ap.add_argument("--no-tracking-path", action="store_true", help="skip the (untimed) Tracking-shaped matcher measurements")
     ap.add_argument("--no-live-streams", action="store_true", help="skip the (untimed) one-frame-per-robot-per-call measurements (examples/multi_robot)")
     ap.add_argument("--live-full", action="store_true", help="every live-stream configuration (default: the five the record's targets and DESIGN.md quote)")
@@ -750,6 +751,23 @@ def live_streams(cfg, dev_index=0, frames=400, budget=None, full=False):
     return out
 
 
+def pci_code(bus_id):
+    """"0000:c1:00.0" -> a number that survives the float64 all_gather (-1: unknown)"""
+    try:
+        dom, bus, rest = bus_id.split(":")
+        dev, fn = rest.split(".")
+        return float((int(dom, 16) << 20) | (int(bus, 16) << 12) | (int(dev, 16) << 4) | int(fn, 16))
+    except (AttributeError, ValueError):
+        return -1.0
+
+
+def pci_text(code):
+    if code is None or code < 0:
+        return None
+    c = int(code)
+    return "%04x:%02x:%02x.%x" % (c >> 20, (c >> 12) & 0xFF, (c >> 4) & 0xFF, c & 0xF)
+
+
 def pin_to_gpu_numa(dev_index):
     """Pin this rank to the cores of its GPU's NUMA node (os.sched_setaffinity): the HBM-resident headline does not
     care, the host-fed entries on a two-socket box do (staging copies and pinned buffers on the far socket cross the
@@ -792,6 +810,76 @@ def parity_check(ex, cfg, host_frames, frames_idx):
             bad.append(int(f))
     return {"frames": len(frames_idx), "ok": not bad, "mismatching_frames": bad, "checked": [int(f) for f in frames_idx],
             "what": "keypoints, descriptors and match table of these frames of the last timed step, byte for byte against the CPU oracle on the same input"}
+
+
+def natural_sequences(W, H, B):
+    """The 64-frame step on frames with natural statistics (the reference's inputs are photographs,
+    mono_tum.cc:60-78 -- absent here).  From tests/golden/natural.npz (scikit-image photographs, 1241x376 only):
+      retina_pan  a camera panning back and forth over the retina photograph at native resolution (origin as synth.py pans
+                  its canvas): LOW texture -- nearly every cell comes back empty at iniThFAST and runs again at minThFAST
+      mosaic      camera | astronaut | gravel side by side, a static camera with +-1 sensor noise per frame: mixed
+      hubble      the Hubble deep field (x1.241), static camera with +-1 noise: point-like texture everywhere
+    Returns name -> [B, H, W] uint8 (deterministic: seeded noise)."""
+    import numpy as np
+    from orbslamm_amd import synth
+    path = os.path.join(_ROOT, "tests", "golden", "natural.npz")
+    if not os.path.exists(path) or (W, H) != (1241, 376):
+        return {}
+    z = np.load(path)
+    seqs = {}
+    cv = z["c3_canvas"]
+    seqs["retina_pan"] = np.stack([np.ascontiguousarray(cv[synth._tri(t, 16):synth._tri(t, 16) + H, synth._tri(2 * t, 64):synth._tri(2 * t, 64) + W]) for t in range(B)])
+    for name, seed in (("mosaic", 11), ("hubble", 12)):
+        base = z["c3_" + name].astype(np.int16)
+        rng = np.random.Generator(np.random.PCG64(0x4E41 + seed))
+        seqs[name] = np.stack([np.clip(base + rng.integers(-1, 2, size=base.shape, dtype=np.int16), 0, 255).astype(np.uint8) for _ in range(B)])
+    return seqs
+
+
+def natural_block(ex, cfg, B, stride, steps=40, warmup=8):
+    """Untimed side block: the headline's step (extract + brute-force match of B frames resident in HBM) on each natural
+    sequence -- frames/s, k_fast's average launch inside those steps, what fraction of the cells the reference's loop runs
+    a second time at minThFAST (ORBextractor.cc:808-816; counted by the oracle on one frame), keypoints per frame, and
+    two frames of the last step byte for byte against the oracle."""
+    import numpy as np
+    from oracle import binding as ob
+    W, H = cfg["w"], cfg["h"]
+    out = {"what": "the timed region's step on %d-frame batches of natural images (tests/golden/natural.npz), untimed side block: %d steps after %d warm-up steps; "
+                   "cells_retry = share of FAST cells empty at iniThFAST and run again at minThFAST (oracle count on one frame)" % (B, steps, warmup)}
+    oex = ob.Extractor(cfg["nfeat"], 1.2, 8, 20, 7)
+    for name, frames in natural_sequences(W, H, B).items():
+        d = ex.upload_frames(frames, stride=stride)
+
+        def step():
+            ex.extract_batch_device(*d)
+            ex.match_prev_batch_device(0.7, 50, True)
+        for _ in range(warmup):
+            step()
+        ex.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ex.sync()
+        dt = time.perf_counter() - t0
+        ex.profile_select("k_fast")
+        ex.profile_enable(True)
+        ex.profile_read(reset=True)
+        for _ in range(8):
+            step()
+        pr = ex.profile_read(reset=True)
+        ex.profile_enable(False)
+        ex.profile_select(None)
+        kf = pr.get("k_fast", (0.0, 0))
+        # the batch repeats, so the last step's frame f followed frame f - 1 of the same batch (f >= 1)
+        par = parity_check(ex, cfg, {f: frames[f] for f in (B - 3, B - 2, B - 1)}, [B - 2, B - 1])
+        cells, retry, empty = oex.cell_stats(frames[B // 2])
+        kps, _ = ex.download(B - 1)
+        _, nm = ex.download_matches(B - 1)
+        out[name] = {"fps": B * steps / dt, "ms_per_step": dt / steps * 1e3, "k_fast_avg_launch_ms": kf[0] / kf[1] if kf[1] else None,
+                     "k_fast_ms_per_step": kf[0] / 8.0 if kf[1] else None, "cells": cells, "cells_retry": retry / max(cells, 1),
+                     "cells_empty_at_both_thresholds": empty / max(cells, 1), "keypoints_last_frame": int(len(kps)), "matches_last_frame": int(nm),
+                     "parity_ok": bool(par["ok"])}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -924,6 +1012,14 @@ def run_rank(args):
         state["i"] = 0
     dt = streams.timed_region(step, args.steps, sync, world)
     state["sample"] = False
+    # Self-diagnosis of a rank (the first 8-GPU run is the first time `device != 0` executes): the shader
+    # clock right behind the region -- a cold (2.0 GHz) or throttled GPU reads differently from a slow pipeline --, which
+    # device this rank really drove (ordinal + PCI bus id) and where it was pinned.  All of it rides in the gathered record.
+    diag = {"device": dev_index, "pci": None, "clock_mhz": None}
+    if not os.environ.get("ORBX_BENCH_EXTRACTOR"):
+        from orbslamm_amd import _lib as _l
+        diag["clock_mhz"] = _l.shader_clock_mhz(dev_index)
+        diag["pci"] = _l.device_pci_bus_id(dev_index)
     prof = ex.profile_read(reset=True) if not args.no_profile else {}
     ex.profile_enable(False)
     ex.profile_select(None)
@@ -941,6 +1037,15 @@ def run_rank(args):
         par = parity_check(ex, cfg, hf, [B - 2, B - 1])
         if not par["ok"]:
             sys.stderr.write("bench.py: rank %d: frames %s of the last step differ from the CPU oracle\n" % (rank, par["mismatching_frames"]))
+    nat = None
+    if real and world == 1 and not args.no_natural and B >= 3 and budget.allows("natural", 8.0):
+        t_blk = time.time()
+        nat = natural_block(ex, cfg, B, STRIDE)
+        # the synthetic headline frames, for the same two statistics
+        from oracle import binding as _ob
+        c_, r_, e_ = _ob.Extractor(NFEAT, 1.2, 8, 20, 7).cell_stats(first_batch[B // 2])
+        nat["synthetic_headline_frames"] = {"cells": c_, "cells_retry": r_ / max(c_, 1), "cells_empty_at_both_thresholds": e_ / max(c_, 1)}
+        budget.charge("natural", t_blk)
     # The Tracking-shaped block runs BEFORE the host-buffer entries: those give the handle its copy streams (two of them on
     # hardware queues of their own), and with more than ~4 queues alive in the process the GPU rotates them -- the
     # batched extraction + search step then reads 113 k pairs/s instead of 150 k (idle queues count)
@@ -959,7 +1064,10 @@ def run_rank(args):
     gathered, dt_max = streams.gather_stats((B * args.steps, len(kps_last), nmatch_last, dt,
                                              -1.0 if par is None else float(par["ok"]),
                                              0.0 if hp is None else hp.get("pipelined_fps", 0.0),
-                                             0.0 if hp is None else hp.get("b1_ms_median", 0.0)), world, device)
+                                             0.0 if hp is None else hp.get("b1_ms_median", 0.0),
+                                             float(diag["device"]), pci_code(diag["pci"]),
+                                             -1.0 if pin.get("numa_node") is None else float(pin["numa_node"]), float(bool(pin.get("pinned"))),
+                                             -1.0 if diag["clock_mhz"] is None else float(diag["clock_mhz"])), world, device)
 
     # serialized replay (untimed): the same steps with every kernel alone on the GPU, to tell
     # kernel cost from overlap.  `value` above is NOT affected by it.
@@ -991,6 +1099,10 @@ def run_rank(args):
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            # SURVEY.md 8(d)'s protocol figure (H2D of the frames and D2H of keypoints, descriptors and matches INSIDE the clock;
+            # pipelined 64-frame tickets from pinned host frames) beside `value`, which is the HBM-resident rate of BASELINE config 4
+            "value_host_inclusive": None if hp is None else hp.get("pipelined_pinned_fps"),
+            "value_host_inclusive_pageable": None if hp is None else hp.get("pipelined_fps"),
             "config": {"workload": cfg["workload"], "name": args.config,
                        "frames_per_step_per_gpu": B, "streams": world, "parallelism": "1 independent stream per GPU",
                        "resident_pool_frames_per_gpu": pool * B, "resident_pool_mb_per_gpu": pool * B * STRIDE * H / 1e6,
@@ -1101,10 +1213,23 @@ def run_rank(args):
                 out["host_path"]["per_rank_pipelined_fps"] = [g[5] for g in gathered]
                 out["host_path"]["per_rank_b1_ms_median"] = [g[6] for g in gathered]
         out["numa"] = pin
+        # one line per rank: read THIS first when the driver's scaling efficiency is below ~0.95
+        per_rank = []
+        for r, g in enumerate(gathered):
+            per_rank.append({"rank": r, "device": int(g[7]), "pci_bus_id": pci_text(g[8]), "numa_node": None if g[9] < 0 else int(g[9]),
+                             "pinned_to_numa_node": bool(g[10] > 0), "ms_per_step": g[3] / args.steps * 1e3, "fps": g[0] / g[3] if g[3] > 0 else 0.0,
+                             "shader_clock_mhz_after_region": None if g[11] < 0 else g[11], "parity_ok": None if g[4] < 0 else bool(g[4] > 0),
+                             "keypoints_last_frame": int(g[1]), "matches_last_frame": int(g[2])})
+        out["per_rank"] = per_rank
+        fr_ = [q["fps"] for q in per_rank]
+        out["per_rank_fps"] = {"min": min(fr_), "max": max(fr_), "spread": (max(fr_) - min(fr_)) / max(fr_) if max(fr_) > 0 else 0.0,
+                               "distinct_devices": len({(q["device"], q["pci_bus_id"]) for q in per_rank})}
         if par is not None:
             out["parity_check"] = par
             if world > 1:
                 out["parity_check"]["per_rank_ok"] = [bool(g[4] > 0) for g in gathered]
+        if nat is not None:
+            out["natural"] = nat
         if trk is not None:
             out["tracking_path"] = trk
         out["replayed_pmc"] = replay
@@ -1128,6 +1253,9 @@ def run_rank(args):
     streams.finalize(world)
     if par is not None and not par["ok"]:
         return 4  # the metric promises bit-exact results
+    if rank == 0 and any(0 <= g[4] < 0.5 for g in gathered):
+        sys.stderr.write("bench.py: ranks %s differ from the CPU oracle\n" % [r for r, g in enumerate(gathered) if 0 <= g[4] < 0.5])
+        return 4  # ... on EVERY rank: the launch fails when any GPU's results differ
     return 0
 
 

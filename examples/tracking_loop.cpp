@@ -344,7 +344,7 @@ int main(int argc, char** argv)
                 Last.mvpMapPoints = TL.mps; Last.mvbOutlier.assign((size_t)Last.N, false); Last.mvScaleFactors = scaleFactors; Last.mTcw = TL.Tcw;
                 voc.computeBoW(Cur.mDescriptors, Cur.N, Cur.mFeatVec, wid, wval, node, fstart, fidx);
                 auto raw_proj = [&](ORBmatcher& m, Member& mem, int expect) {
-                    ORBmatcher::FlatCall& c = m.last;
+                    ORBmatcher::FlatCall& c = m.last();
                     OrbmProjParams pp = {c.mode, m.flat().mfNNratio, m.flat().mbCheckOrientation ? 1 : 0, c.thDist};
                     std::vector<uint8_t> occ; std::vector<int32_t> assign;
                     for (int variant = 0; variant < (A.oldPattern ? 2 : 1); variant++) {
@@ -379,7 +379,7 @@ int main(int argc, char** argv)
                 {
                     ORBmatcher m(0.7f, true);
                     const int n = m.SearchByBoW(TL.kf.get(), Cur, vpMapPointMatches);
-                    ORBmatcher::FlatCall& c = m.last;
+                    ORBmatcher::FlatCall& c = m.last();
                     OrbmFeatVec qa = c.qfv.view(), ta = c.tfv.view();
                     std::vector<int32_t> match((size_t)c.nt);
                     for (int variant = 0; variant < (A.oldPattern ? 2 : 1); variant++) {

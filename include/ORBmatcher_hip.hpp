@@ -401,7 +401,7 @@ public:
 
     // ORBmatcher.cc:41-43: two parameters, nothing else -- the object is a stack temporary in the reference
     ORBmatcherT(float nnratio = 0.6f, bool checkOri = true, int device = 0)
-        : last(threadScratch(0)), last2(threadScratch(1)), flat_(nnratio, checkOri, device) {}
+        : flat_(nnratio, checkOri, device) {}
 
     // What the last member call OF THIS THREAD handed to the device and got back (flattened arrays + the query -> object
     // index map).  The storage is per thread, not per matcher (the matcher is a temporary; its flattening scratch must
@@ -425,9 +425,11 @@ public:
         std::vector<float> tangle, F12; float ex = 0, ey = 0;
         int nmatches = 0;
     };
-    FlatCall& last;
+    // resolved at call time: a matcher built on one thread and used on another reads and writes the CALLING thread's scratch,
+    // and the object stays copyable / assignable like the reference's (it holds no reference)
+    static FlatCall& last() { return threadScratch(0); }
     // second pass of SearchBySim3 (KF2's points into KF1)
-    FlatCall& last2;
+    static FlatCall& last2() { return threadScratch(1); }
 
     // static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)   ORBmatcher.h:45, ORBmatcher.cc:1649-1665
     // ONE pair: eight xor + popcount on the host.  The reference calls this per pair from loops the device entries
@@ -814,14 +816,14 @@ public:
                 if (c.bestDist[q] <= TH_HIGH && c.bestIdx[q] >= 0) vnMatch[c.qidx[q]] = c.bestIdx[q];
         };
         std::vector<int> vnMatch1, vnMatch2;
-        pass(last, "SearchBySim3(1->2)", vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, vnMatch1);
-        pass(last2, "SearchBySim3(2->1)", vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12v, pKF1, vnMatch2);
+        pass(last(), "SearchBySim3(1->2)", vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, vnMatch1);
+        pass(last2(), "SearchBySim3(2->1)", vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12v, pKF1, vnMatch2);
         int nFound = 0;  // :1306-1322
         for (int i1 = 0; i1 < N1; i1++) {
             const int idx2 = vnMatch1[i1];
             if (idx2 >= 0 && vnMatch2[idx2] == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; nFound++; }
         }
-        last.nmatches = nFound;
+        last().nmatches = nFound;
         return nFound;
     }
 
@@ -833,7 +835,7 @@ protected:
 
     FlatMatcher flat_;
 
-    FlatCall& begin(const char* fn, int mode, int thDist) { reset(last, fn, mode, thDist); return last; }
+    FlatCall& begin(const char* fn, int mode, int thDist) { FlatCall& c = last(); reset(c, fn, mode, thDist); return c; }
     static void reset(FlatCall& c, const char* fn, int mode, int thDist)
     {
         c.fn = fn; c.mode = mode; c.thDist = thDist; c.nq = c.nt = 0; c.chi2 = 0; c.nmatches = 0;

@@ -40,6 +40,11 @@ int orbx_device_count(void);
 /* PCI bus id of a HIP device ("0000:c1:00.0", cap >= 16): /sys/bus/pci/devices/<id>/numa_node names the NUMA node whose
  * cores and memory sit next to it (a rank that feeds host frames should be pinned there) */
 int orbx_device_pci_bus_id(int device, char* out, int cap);
+/* the shader clock (MHz) the device runs at now UNDER LOAD, measured by a ~0.1 ms probe kernel that fills every SIMD (s_memtime
+ * against the 100 MHz s_memrealtime in its first wave).  Diagnostics for multi-GPU launches (one robot per GPU, MultipleRobotsScenario/Examples/Monocular/
+ * mono_kitti.cc:80-101): a rank that reports it right behind its timed steps tells a cold or throttled GPU from a slow
+ * pipeline.  Synchronous; uses the device's null stream. */
+int orbx_device_shader_clock_mhz(int device, float* mhz);
 
 /* ---------------------------------------------------------------- extractor
  * replaces class ORBextractor (include/ORBextractor.h:45-111). */
@@ -399,12 +404,19 @@ int orbm_search_for_triangulation(orbm_t* h,
  * extractor's result sets are reused two batches later) into ONE block taken from the creating handle's pool and given
  * back by orbm_frame_destroy (from any thread): a Frame per image allocates nothing in steady state, and neither call
  * waits for the device.  Any matcher handle of the same device may search a frame; the creating handle lives until its
- * last frame is destroyed. */
+ * last frame is destroyed.
+ * LIFETIME OF THE INPUTS: orbm_frame_create returns with the build ENQUEUED on the creating handle's stream; d_keys and
+ * d_desc must stay untouched until the build has read them -- i.e. until the first search, BoW or download on the frame
+ * has returned (each returns after its own results, enqueued behind the build, have landed), or until
+ * orbm_frame_settle(f).  A caller that recycles the input buffers at once (orbx_upload into them, the extractor's next
+ * but one batch) calls orbm_frame_settle first; Tracking's shape -- create, then search -- needs nothing. */
 typedef struct orbm_frame orbm_frame_t;
 int orbm_frame_create(orbm_t* h, const OrbxKeyPoint* d_keys, const uint8_t* d_desc, int n,
                       const float K[4], const float D[5], const OrbmGrid* grid, orbm_frame_t** out);
 int orbm_frame_destroy(orbm_frame_t* f);
 int orbm_frame_size(const orbm_frame_t* f);
+/* waits (once; later calls return at once) until the frame's build has finished reading d_keys / d_desc */
+int orbm_frame_settle(orbm_frame_t* f);
 /* mvKeysUn for the host side of Tracking (pose optimisation reads it) */
 int orbm_frame_download_keys_un(orbm_frame_t* f, OrbxKeyPoint* keys_un);
 /* orbm_search_by_projection with the frame as train side (CurrentFrame of modes 3-5, the KeyFrame of mode 6) */

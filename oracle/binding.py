@@ -140,6 +140,21 @@ class Extractor:
             out["pyramid"] = pyr
         return out
 
+    def cell_stats(self, img):
+        """(cells, cells run again at minThFAST, cells empty at both thresholds) over all levels of one frame (ref:808-816)"""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        pyr = self(img, want_pyramid=True)["pyramid"]
+        tot, off = [0, 0, 0], 0
+        for l in range(self.nlevels):
+            lw, lh = self.level_size(w, h, l)
+            lvl = np.ascontiguousarray(pyr[off:off + lw * lh].reshape(lh, lw))
+            off += lw * lh
+            a, b, c = C.c_int(), C.c_int(), C.c_int()
+            self.L.orc_level_cell_stats(C.byref(self.ex), _p(lvl), lw, lh, lw, C.byref(a), C.byref(b), C.byref(c))
+            tot[0] += a.value; tot[1] += b.value; tot[2] += c.value
+        return tuple(tot)
+
     def level_candidates(self, level_img):
         level_img = np.ascontiguousarray(level_img, dtype=np.uint8)
         h, w = level_img.shape

@@ -442,6 +442,41 @@ int orc_level_candidates(const OrcExtractor* ex, const uint8_t* img, int w, int 
     return n < cap ? n : -1;
 }
 
+/* How many cells of a level the reference's loop visits, how many of them come back empty from cv::FAST at iniThFAST and
+ * are run again at minThFAST (ref:808-816), and how many stay empty: the statistic bench.py's `natural` block reports beside
+ * its throughput (the synthetic frames retry 0.14 % of their cells, photographs and low-texture scenes far more). */
+void orc_level_cell_stats(const OrcExtractor* ex, const uint8_t* img, int w, int h, int stride, int* ncells, int* nretry, int* nempty)
+{
+    const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+    const int maxBorderX = w - EDGE_THRESHOLD + 3, maxBorderY = h - EDGE_THRESHOLD + 3;
+    const float width = (float)(maxBorderX - minBorderX), height = (float)(maxBorderY - minBorderY);
+    const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+    *ncells = *nretry = *nempty = 0;
+    if (nCols < 1 || nRows < 1) return;
+    const int wCell = (int)ceil((double)(width / nCols)), hCell = (int)ceil((double)(height / nRows));
+    OrcCorner* cell = (OrcCorner*)malloc(sizeof(OrcCorner) * 64 * 64);
+    for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minBorderY + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBorderY - 3) continue;
+        if (maxY > maxBorderY) maxY = (float)maxBorderY;
+        for (int j = 0; j < nCols; j++) {
+            const float iniX = (float)(minBorderX + j * wCell);
+            float maxX = iniX + wCell + 6;
+            if (iniX >= maxBorderX - 6) continue;
+            if (maxX > maxBorderX) maxX = (float)maxBorderX;
+            const uint8_t* roi = img + (size_t)(int)iniY * stride + (int)iniX;
+            const int rw = (int)maxX - (int)iniX, rh = (int)maxY - (int)iniY;
+            (*ncells)++;
+            if (orc_fast9_16(roi, rw, rh, stride, ex->iniThFAST, cell, 64 * 64) == 0) {
+                (*nretry)++;
+                if (orc_fast9_16(roi, rw, rh, stride, ex->minThFAST, cell, 64 * 64) == 0) (*nempty)++;
+            }
+        }
+    }
+    free(cell);
+}
+
 /* ------------------------------------------------------------------ ref:481-763 quadtree */
 typedef struct QNode {
     int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;

@@ -99,6 +99,8 @@ void orc_brief(const uint8_t* blurred, int stride, int x, int y, float angle_deg
  * coordinates are window-relative (minBorder not added).  returns count (<= cap) */
 int  orc_level_candidates(const OrcExtractor* ex, const uint8_t* img, int w, int h, int stride,
                           OrcCorner* out, int cap);
+/* cells visited / cells run again at minThFAST / cells empty at both thresholds (ref:808-816) */
+void orc_level_cell_stats(const OrcExtractor* ex, const uint8_t* img, int w, int h, int stride, int* ncells, int* nretry, int* nempty);
 /* DistributeOctTree: in = candidates (window-relative), out = kept, list order */
 int  orc_distribute(const OrcCorner* in, int n, int minX, int maxX, int minY, int maxY,
                     int N, OrcCorner* out, int cap);

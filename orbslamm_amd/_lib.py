@@ -62,7 +62,7 @@ class OrbmProjParams(C.Structure):
 
 # every symbol include/orbslamm_hip.h declares (tests check that all of them resolve)
 EXPORTS = [
-    "orbx_last_error", "orbx_device_count", "orbx_device_pci_bus_id", "orbx_create", "orbx_create_live", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
+    "orbx_last_error", "orbx_device_count", "orbx_device_pci_bus_id", "orbx_device_shader_clock_mhz", "orbx_create", "orbx_create_live", "orbx_destroy", "orbx_levels", "orbx_scale_factor",
     "orbx_scale_tables", "orbx_features_per_level", "orbx_umax", "orbx_max_keypoints", "orbx_extract",
     "orbx_extract_batch", "orbx_submit_batch", "orbx_submit_batch_into", "orbx_collect", "orbx_host_alloc", "orbx_collect_view", "orbx_release", "orbx_collect_batch", "orbx_extract_match_batch",
     "orbx_host_alloc_frames", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_device_results", "orbx_download",
@@ -70,7 +70,7 @@ EXPORTS = [
     "orbx_device_matches", "orbx_download_matches", "orbx_reset_stream", "orbx_set_serial", "orbx_profile_enable",
     "orbx_profile_read", "orbx_debug_pair_overlap", "orbx_debug_link_rate", "orbx_debug_stage_rows", "orbx_profile_select", "orbm_create", "orbm_destroy", "orbm_thread_handle", "orbm_alloc_stats", "orbm_distance_matrix", "orbm_match_bruteforce",
     "orbm_search_by_bow", "orbm_search_by_projection", "orbm_search_by_projection_stereo", "orbm_features_in_area", "orbm_window_best",
-    "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_distinctive_descriptors", "orbm_descriptors_to_text", "orbm_descriptors_from_text", "orbm_undistort_keypoints", "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_size",
+    "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_distinctive_descriptors", "orbm_descriptors_to_text", "orbm_descriptors_from_text", "orbm_undistort_keypoints", "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_size", "orbm_frame_settle",
     "orbm_frame_download_keys_un", "orbm_search_by_projection_frame", "orbm_frame_compute_bow", "orbm_search_by_bow_frames", "orbm_search_for_initialization_frames", "orbm_window_best_frame", "orbm_search_for_triangulation_frames",
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_transform",
     "orbm_last_search_stats", "orbm_frameset_create", "orbm_frameset_destroy", "orbm_frameset_build", "orbm_frameset_build_from_extractor",
@@ -148,6 +148,24 @@ def check(rc):
 
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_pci_bus_id(device):
+    """"0000:c1:00.0" or None"""
+    buf = C.create_string_buffer(32)
+    try:
+        return buf.value.decode().lower() if lib().orbx_device_pci_bus_id(int(device), buf, 32) == 0 else None
+    except Exception:
+        return None
+
+
+def shader_clock_mhz(device):
+    """the shader clock the device runs at now (orbx_device_shader_clock_mhz), or None"""
+    v = C.c_float(0)
+    try:
+        return float(v.value) if lib().orbx_device_shader_clock_mhz(int(device), C.byref(v)) == 0 else None
+    except Exception:
+        return None
 
 
 def numa_cpus_of_device(device):

@@ -240,27 +240,12 @@ constexpr int kMfmaRowsPerBlock = 64 * kMfmaWaves;
 constexpr int kMfmaEmpty = 0x7FFFFFFF;                 // absolute keys (H << 16 | j)
 constexpr float kMfmaEmptyRelF = 3.402823466e+38f;     // running keys: FLT_MAX (stays FLT_MAX under "- 16")
 constexpr int kMfmaTileBytes = 32 * kMfmaDescBytes;    // 4 KiB: one global_load_lds_dwordx4 per thread
-#ifndef ORBM_ROWIDX_RESIDENT
-#define ORBM_ROWIDX_RESIDENT 1
-#endif
-#ifndef ORBM_FILL_FIRST
-#define ORBM_FILL_FIRST 1
-#endif
 #ifndef ORBM_MATCH_PRIO
 #define ORBM_MATCH_PRIO 3
 #endif
-#ifndef ORBM_XCD_RUN
-#define ORBM_XCD_RUN 1
-#endif
-#ifndef ORBM_MFMA_RING
-#define ORBM_MFMA_RING 16
-#endif
-constexpr int kMfmaRing = ORBM_MFMA_RING;              // train tiles in LDS
+constexpr int kMfmaRing = 16;                          // train tiles in LDS
 constexpr int kMfmaLdsBytes = kMfmaRing * kMfmaTileBytes;
-#ifndef ORBM_MFMA_GROUP
-#define ORBM_MFMA_GROUP 4
-#endif
-constexpr int kMfmaGroup = ORBM_MFMA_GROUP; // tiles per barrier (even)
+constexpr int kMfmaGroup = 4;               // tiles per barrier (even)
 constexpr int kMfmaAhead = kMfmaRing - kMfmaGroup; // a group's loads are issued this many tiles ahead of its first tile
 static_assert((kMfmaRing & (kMfmaRing - 1)) == 0 && kMfmaAhead - kMfmaGroup <= 63, "ring slot by mask; vmcnt has six bits");
 __device__ __forceinline__ int mfma_row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -290,13 +275,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
     // consecutive pairs, whose slots overlap: 41.9 -> 25.0 MB of HBM traffic per 64-pair step, 0.054 -> 0.050 ms alone
     // (profiles/r05_match_xcd_ab.txt; 18.4 MB of +-1 descriptors + the keypoint angles and the tables is the floor)
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-#if ORBM_XCD_RUN
     // an XCD takes a RUN of consecutive frame pairs: pair f reads slots f (train) and f + 1 (queries), pair f + 1 slots
     // f + 1 and f + 2 -- with pairs dealt round-robin every slot is fetched into two L2s
     const int f = xcd * ((nframes + 7) >> 3) + k / nqb;
-#else
-    const int f = (k / nqb) * 8 + xcd;
-#endif
     if (f >= nframes) return;
     const int nq = count[qslot0 + f], nt = count[tslot0 + f];
     const int q0 = (k % nqb) * kMfmaRowsPerBlock;
@@ -331,14 +312,12 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
                      "global_load_lds_dwordx4 %1, off\n\t"
                      "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
     };
-#if ORBM_FILL_FIRST
     // the ring's first fills go out BEFORE the query fragments are fetched: both wait for memory, and behind each other
     // they cost the workgroup two round trips before its first product (all 512 workgroups of a step start together)
     if (ntiles > 0) {
 #pragma unroll
         for (int t = 0; t < kMfmaAhead; t++) issue(t);
     }
-#endif
     v4i Q[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; qb++)
@@ -361,11 +340,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
     constexpr float kBias = 524288.f;  // 2^19: every key a positive float
     v16f rowIdx = {kBias, kBias + 1, kBias + 2, kBias + 3, kBias + 4, kBias + 5, kBias + 6, kBias + 7,
                    kBias + 8, kBias + 9, kBias + 10, kBias + 11, kBias + 12, kBias + 13, kBias + 14, kBias + 15};
-#if ORBM_ROWIDX_RESIDENT
     // sixteen registers that stay: as constants hipcc rebuilds them in front of every tile's first products (8 v_mov_b64 per
     // tile and wave, two passes each), as registers they are just the C operand of a chain's first MFMA
     asm volatile("" : "+v"(rowIdx));
-#endif
     // running keys, relative to the tile folded last -- kept and compared AS FLOATS: every key is a positive normal float (no NaN, no
     // denormal), so the float order is the integer order of the bits, and on floats hipcc forms v_min3_f32 and takes v_med3_f32
     // from a builtin -- on the bit patterns it shares min(best, k) between its med3 pattern and the best's update and loses the v_min3
@@ -438,10 +415,6 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_match_mfma(const uint8_t* _
 
     if (ntiles > 0) {
         v16f accE0, accE1, accO0, accO1;
-#if !ORBM_FILL_FIRST
-#pragma unroll
-        for (int t = 0; t < kMfmaAhead; t++) issue(t);
-#endif
         landed(s1);
         __syncthreads();
         // two tiles per barrier: tile a's products into one accumulator set while the other (tile a - 1) is folded,

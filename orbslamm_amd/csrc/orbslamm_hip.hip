@@ -95,6 +95,49 @@ extern "C" int orbx_device_pci_bus_id(int device, char* out, int cap)
     return ORBX_OK;
 }
 
+// The shader clock the device runs at NOW, UNDER LOAD: a ~0.1 ms kernel that fills every SIMD with FMA chains
+// (tools/ubench/clock_ramp.hip's measurement as a library call) reads s_memtime (the shader clock's counter) against
+// s_memrealtime (a constant 100 MHz counter) in its first wave.  (A one-wave probe reads the governor's light-load boost,
+// 2.43 GHz whatever came before.)  After an idle gap an MI355X starts a loaded kernel at ~2.0 GHz and needs ~40 ms of load to
+// reach its ~2.37 GHz; a rank of a multi-GPU job that reports its clock right behind its timed region tells a cold or
+// throttled GPU from a slow pipeline (bench.py, per rank).
+__global__ __launch_bounds__(256) void k_clock_probe(uint64_t* out, float* sink, int iters)
+{
+    uint64_t c0 = 0, r0 = 0;
+    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = (float)threadIdx.x * 0.5f + (float)i;
+    for (int it = 0; it < iters; it++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += a[i];
+    if (s == 12345.f) sink[0] = s;   // (keeps the chains alive)
+    if (stamp) { out[0] = __builtin_readcyclecounter() - c0; out[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+}
+extern "C" int orbx_device_shader_clock_mhz(int device, float* mhz)
+{
+    if (!mhz) return fail(ORBX_E_INVALID, "bad argument");
+    int prev = 0;
+    HIPCHK(hipGetDevice(&prev));
+    HIPCHK(hipSetDevice(device));
+    uint64_t* d = nullptr;
+    uint64_t h[2] = {0, 0};
+    hipError_t e = hipMalloc(&d, sizeof h + 8);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_clock_probe, dim3(2048), dim3(256), 0, nullptr, d, (float*)(d + 2), 1000);
+        e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+    }
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return fail(ORBX_E_HIP, "clock probe failed: %s", hipGetErrorString(e));
+    *mhz = h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : 0.f;
+    return ORBX_OK;
+}
+
 // spin-wait hint of the latency path's poll
 static inline void cpu_relax()
 {

@@ -4,7 +4,7 @@
 //   k_pyramid       ComputePyramid :1107-1132 (cv::resize INTER_LINEAR, fixed point; k_resize_level = per-level fallback)
 //   k_fast          ComputeKeyPointsOctTree cell loop :789-829 (cv::FAST 9/16 + NMS + minTh retry)
 //   k_distribute    DistributeOctTree :539-763 + DivideNode :481-537
-//   k_blur          GaussianBlur 7x7 sigma 2 :1085-1086
+//   k_blur_mfma     GaussianBlur 7x7 sigma 2 :1085-1086 (two banded int8 products on the matrix cores, exact in int32)
 //   k_orient_desc   IC_Angle :77-104, computeOrbDescriptor :108-147, scale/pack :837-847,1095-1101
 //
 // Integer/bitwise path, VALU-issue bound: the kernels are shaped to shed instructions (dot4/dot2/perm/min3/med3,
@@ -318,8 +318,7 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(const Geom* __restrict_
 //            are compacted again, in place.
 //   stage 3  3x3 non-max suppression and emission run on that corner list only.
 // Window-9 minima of the 16-ring with three-input min: m3[k] = min3(d[k..k+2]),
-// m9[k] = min3(m3[k], m3[k+3], m3[k+6]) (full-rate VOP3; packed i16 min/max issue at half rate
-// on gfx950, tools/ubench/valu_rate.hip).
+// m9[k] = min3(m3[k], m3[k+3], m3[k+6]) -- the two-sided form of the cell whose one-sided lists do not fit (fast_S).
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
@@ -351,19 +350,6 @@ template <int TSB> __device__ __forceinline__ void ring_load(const uint8_t* __re
     r[12] = p[RingOff<TSB, 12>::v]; r[13] = p[RingOff<TSB, 13>::v]; r[14] = p[RingOff<TSB, 14>::v]; r[15] = p[RingOff<TSB, 15>::v];
 }
 
-__device__ __forceinline__ int arc_min_of_max(const int (&d)[16])
-{
-    int m3[16], m9[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) m3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) m9[k] = max3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
-    int a5[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) a5[k] = min3i(m9[3 * k], m9[3 * k + 1], m9[3 * k + 2]);
-    return min(min3i(a5[0], a5[1], a5[2]), min3i(a5[3], a5[4], m9[15]));
-}
-
 // Round 5: the same window minima two ring pixels per instruction.  gfx950's v_pk_minimum3_f16 / v_pk_maximum3_f16
 // (IEEE-754-2019 minimum / maximum on two f16 lanes) issue at the full VALU rate, and on bytes widened to 16 bits they ARE
 // the integer min3 / max3: positive f16 bit patterns order like the integers they spell, 0..255 are denormals, and the
@@ -372,15 +358,6 @@ __device__ __forceinline__ int arc_min_of_max(const int (&d)[16])
 // X[k] = p[k] | p[k+8] << 16, so "index + 8" is an exchange of the two halves, which VOP3P's op_sel does for free in the
 // operand fetch -- the 16 windows of three are 8 instructions, the 16 windows of nine 8 more, the fold over them 5.
 // 8 (pairing) + 21 instead of 40 per visit; the visit's other ~25 instructions (list entry, addresses, ballot, stores) stay.
-#ifndef ORBX_FAST_PK
-#define ORBX_FAST_PK 1
-#endif
-#ifndef ORBX_FAST_PK1
-#define ORBX_FAST_PK1 1   // k_fast stage 1: the compass test two pixels per instruction
-#endif
-#ifndef ORBX_BRIEF_PK
-#define ORBX_BRIEF_PK 1   // k_orient_desc: the steered BRIEF coordinates on packed fp32
-#endif
 // operand j's halves are exchanged when bit j of SW is set (op_sel = low lane's source half, op_sel_hi = high lane's)
 template <int SW> __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -441,21 +418,13 @@ template <int TSB> __device__ __forceinline__ int fast_S_dark(const uint8_t* __r
 {
     int r[16];
     ring_load<TSB>(p, r);
-#if ORBX_FAST_PK
     return max((int)p[0] - arc_fold_pk<false>(r), 0);
-#else
-    return max((int)p[0] - arc_min_of_max(r), 0);
-#endif
 }
 template <int TSB> __device__ __forceinline__ int fast_S_bright(const uint8_t* __restrict__ p)
 {
     int r[16];
     ring_load<TSB>(p, r);
-#if ORBX_FAST_PK
     return max(arc_fold_pk<true>(r) - (int)p[0], 0);
-#else
-    return max(arc_max_of_min(r) - (int)p[0], 0);
-#endif
 }
 
 // both sides (the cell whose one-sided lists would not fit)
@@ -594,7 +563,6 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                 const uint64_t mY = ballot64(y < dh);
                 const uint32_t* q = tile + (rowOk ? y : 0) * TSD + (x4 >> 2);
                 const uint32_t N = q[1], C0 = q[3 * TSD], C1 = q[3 * TSD + 1], C2 = q[3 * TSD + 2], S = q[6 * TSD + 1];
-#if ORBX_FAST_PK1
                 // two pixels per instruction: the five dwords widened to 16-bit pairs (ten v_perm), the compass min / max on
                 // v_pk_min_u16 / v_pk_max_u16 (twelve), the thresholds added in packed form (four): 26 + 8 compares for four
                 // pixels against 40
@@ -612,22 +580,11 @@ __global__ __launch_bounds__(64) void k_fast(const Geom* __restrict__ g, const C
                     loP[m] = __builtin_elementwise_max(__builtin_elementwise_min(n2[m], s2[m]), __builtin_elementwise_min(w2[m], e2[m])) + th2;
                     vtP[m] = v2[m] + th2;
                 }
-#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-#if ORBX_FAST_PK1
                     const unsigned short hk = k & 1 ? hiP[k >> 1].y : hiP[k >> 1].x, lk = k & 1 ? loP[k >> 1].y : loP[k >> 1].x;
                     const unsigned short vtk = k & 1 ? vtP[k >> 1].y : vtP[k >> 1].x, vk = k & 1 ? v2[k >> 1].y : v2[k >> 1].x;
                     const bool br = hk > vtk, dk = vk > lk;   // hi - v > th, v - lo > th
-#else
-                    const int v = (C1 >> (8 * k)) & 0xFF;
-                    const int pn = (N >> (8 * k)) & 0xFF, ps = (S >> (8 * k)) & 0xFF;
-                    const int pw = k < 3 ? (C0 >> (8 * (k + 1))) & 0xFF : C1 & 0xFF;
-                    const int pe = k == 0 ? C1 >> 24 : (C2 >> (8 * (k - 1))) & 0xFF;
-                    const int hi = min(max(pn, ps), max(pw, pe));   // bright: hi - v > th
-                    const int lo = max(min(pn, ps), min(pw, pe));   // dark:   v - lo > th
-                    const bool br = hi - v > th, dk = v - lo > th;
-#endif
                     const uint64_t mIn = mX[k] & mY, mBr = ballot64(br) & mIn, mDk = ballot64(dk) & mIn;
                     const bool in = rowOk && x4 + k < dw;
                     const int e = (y << 7) | (x4 + k);
@@ -1411,7 +1368,7 @@ __device__ __forceinline__ int reflect101(int p, int n)
 // 120x32 output tile per 256-thread block; input 128 x 38 (4 px / 3 rows of halo, dword aligned) in LDS.
 constexpr int kBlurTW = 120, kBlurTH = 32;
 
-// Input tile of k_blur / k_blur_mfma: (TH+6) rows x 32 dwords at a pitch of IN_STRIDE dwords, every dword XORed with XORV on the way
+// Input tile of k_blur_mfma: (TH+6) rows x 32 dwords at a pitch of IN_STRIDE dwords, every dword XORed with XORV on the way
 // in.  Global traffic is aligned dwords, all loads issued before the first LDS store.  Ends with the tile complete and
 // the workgroup synchronised.
 template <int IN_STRIDE, uint32_t XORV>
@@ -1484,120 +1441,6 @@ __device__ __forceinline__ void blur_load_tile(uint32_t* __restrict__ in, const 
             if (bd < 4 * IN_DW && bs >= 0) inb[r * IN_STRIDE * 4 + bd] = inb[r * IN_STRIDE * 4 + bs];
         }
         __syncthreads();
-    }
-}
-
-// 7x7 Gaussian as two exact integer passes on the dot-product units.  The separable sum has no intermediate
-// rounding, so the pass order is free: the VERTICAL pass runs first, on bytes (v_dot4_u32_u8 over 4x4 byte
-// transposes of the input dwords; row sums <= 257*255 fit 16 bits), the horizontal pass then works on the
-// 16-bit sums, whose horizontally adjacent pairs are naturally packed for v_dot2_u32_u16.  Every thread owns 4 adjacent
-// pixels in both passes, so LDS is read as b32/b64 and the result leaves as one dword.
-__global__ __launch_bounds__(256) void k_blur(const Geom* __restrict__ g, FrameSrc src, BlurTiles bt, int nframes)
-{
-    constexpr int TW = kBlurTW, TH = kBlurTH;
-    constexpr int IN_DW = (TW + 8) / 4;       // 32 dwords per input row (4 px margin each side)
-    constexpr int IN_STRIDE = IN_DW + 1;      // 33
-    constexpr int VS_STRIDE = IN_DW * 2 + 2;  // 66 dwords of u16 pairs per row, even for b64 access
-    __shared__ uint32_t in[(TH + 6) * IN_STRIDE];
-    __shared__ uint32_t vs[TH * VS_STRIDE];
-    int bx, fr;
-    if (!xcd_block_frame(nframes, bx, fr)) return;
-    const int f = fr + src.f0;
-    int l = 0;
-    while (l + 1 < g->nlevels && bx >= bt.base[l + 1]) l++;
-    const int tIdx = bx - bt.base[l];
-    const int tx0 = (tIdx % bt.tilesX[l]) * TW, ty0 = (tIdx / bt.tilesX[l]) * TH;
-    const LevelGeom& L = g->lv[l];
-    const int w = L.w, h = L.h;
-    int stride;
-    const uint8_t* S = level_ptr(g, src, f, l, stride);
-    const int tid = threadIdx.x;
-
-    blur_load_tile<IN_STRIDE, 0u>(in, S, stride, w, h, tx0, ty0, tid);
-
-    // vertical pass: thread = (dword column c, group of 4 output rows); rows 4rg .. 4rg+9 of the input tile
-    {
-        constexpr uint32_t KA = 18u | (34u << 8) | (49u << 16) | (55u << 24), KB = 49u | (34u << 8) | (18u << 16);
-        const int c = tid & 31, rg = tid >> 5;
-        uint32_t R[12];
-#pragma unroll
-        for (int k = 0; k < 10; k++) R[k] = in[(4 * rg + k) * IN_STRIDE + c];
-        R[10] = R[11] = 0;
-        uint32_t T[3][4];  // T[b][j] = column j of rows 4b .. 4b+3, one byte per row
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-            const uint32_t lo01 = __builtin_amdgcn_perm(R[4 * b + 1], R[4 * b], 0x05010400u);      // r0.b0 r1.b0 r0.b1 r1.b1
-            const uint32_t hi01 = __builtin_amdgcn_perm(R[4 * b + 1], R[4 * b], 0x07030602u);      // r0.b2 r1.b2 r0.b3 r1.b3
-            const uint32_t lo23 = __builtin_amdgcn_perm(R[4 * b + 3], R[4 * b + 2], 0x05010400u);
-            const uint32_t hi23 = __builtin_amdgcn_perm(R[4 * b + 3], R[4 * b + 2], 0x07030602u);
-            T[b][0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);  // low halves
-            T[b][1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);  // high halves
-            T[b][2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
-            T[b][3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
-        }
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-            uint32_t o[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t wa = y == 0 ? T[0][j] : __builtin_amdgcn_alignbyte(T[1][j], T[0][j], y);
-                const uint32_t wb = y == 0 ? T[1][j] : __builtin_amdgcn_alignbyte(T[2][j], T[1][j], y);
-                o[j] = __builtin_amdgcn_udot4(wb, KB, __builtin_amdgcn_udot4(wa, KA, 0u, false), false);  // <= 65535
-            }
-            uint2 st;
-            st.x = o[0] | (o[1] << 16);
-            st.y = o[2] | (o[3] << 16);
-            *(uint2*)&vs[(4 * rg + y) * VS_STRIDE + 2 * c] = st;
-        }
-    }
-    __syncthreads();
-
-#ifdef ORBX_EXP_INFLATE
-    // experiment hook (off in the product build): ORBX_EXP_INFLATE dependency-free VALU instructions per thread, to
-    // measure how much of the overlapped pipeline is instruction issue (build the variant as
-    // build_ub/libB.so with -DORBX_EXP_INFLATE=100 and run tools/ab_bench.sh)
-    {
-        uint32_t zz = tid;
-#pragma unroll
-        for (int i = 0; i < ORBX_EXP_INFLATE; i++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(zz) : "v"(tid));
-        if (zz == 0xdeadbeefu) vs[0] = zz;
-    }
-#endif
-    // horizontal pass on the 16-bit sums: thread = (output dword column cq < 30, rows rq + 8k); outputs
-    // x = tx0 + 4cq + i are columns 4cq + 4 + i of vs and need a[i+1] .. a[i+7] of a[k] = vs column 4cq + k
-    typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
-    const int cq = tid & 31, rq = tid >> 5;
-    const int x = tx0 + 4 * cq;
-    if (cq >= TW / 4 || x >= w) return;
-    uint8_t* D = src.blur + (int64_t)f * g->blurFrameBytes + L.blurOff + (int64_t)(ty0 + rq) * L.blurStride + x;
-    const uint2* pr = (const uint2*)&vs[rq * VS_STRIDE + 2 * cq];
-    const int nrows = min(TH, h - ty0);
-#pragma unroll
-    for (int k = 0; k < TH / 8; k++) {
-        const uint2 q0 = pr[k * 4 * VS_STRIDE], q1 = pr[k * 4 * VS_STRIDE + 1], q2 = pr[k * 4 * VS_STRIDE + 2];
-        const uint32_t P[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};  // P[m] = (a[2m], a[2m+1])
-        uint32_t O[5];                                                // O[m] = (a[2m+1], a[2m+2])
-#pragma unroll
-        for (int m = 0; m < 5; m++) O[m] = __builtin_amdgcn_alignbyte(P[m + 1], P[m], 2);
-        auto dot = [](uint32_t p, uint32_t kk, uint32_t c) {
-            return __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, p), __builtin_bit_cast(v2u16, kk), c, false);
-        };
-        constexpr uint32_t K0 = 18u | (34u << 16), K1 = 49u | (55u << 16), K2 = 49u | (34u << 16), K3 = 18u;
-        uint32_t r4[4];
-        r4[0] = dot(O[3], K3, dot(O[2], K2, dot(O[1], K1, dot(O[0], K0, 1u << 15))));
-        r4[1] = dot(P[4], K3, dot(P[3], K2, dot(P[2], K1, dot(P[1], K0, 1u << 15))));
-        r4[2] = dot(O[4], K3, dot(O[3], K2, dot(O[2], K1, dot(O[1], K0, 1u << 15))));
-        r4[3] = dot(P[5], K3, dot(P[4], K2, dot(P[3], K1, dot(P[2], K0, 1u << 15))));
-        if (rq + 8 * k < nrows) {
-            // (sum + 2^15) >> 16, saturated (the sum can reach 257 * 257 * 255): the four high halves through
-            // v_sat_pk_u8_i16, two per instruction, instead of shift + min + shift-or per pixel
-            const uint32_t h01 = __builtin_amdgcn_perm(r4[1], r4[0], 0x07060302u), h23 = __builtin_amdgcn_perm(r4[3], r4[2], 0x07060302u);
-            uint32_t p01, p23;
-            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p01) : "v"(h01));
-            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p23) : "v"(h23));
-            const uint32_t pk = (p01 & 0xFFFFu) | (p23 << 16);
-            *(uint32_t*)(D + (int64_t)(8 * k) * L.blurStride) = pk;
-        }
     }
 }
 
@@ -2028,7 +1871,6 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
     const uint32_t adj = (uint32_t)((wave * 4 + q) * (PROWS * PDW * 4) + PR * (PDW * 4) + PR) - 0x400000u * (uint32_t)(PDW * 4) - 0x4B400000u;
     static_assert(PDW * 4 == 40, "row pitch is an inline constant of the mad below");
     uint32_t myWord = 0;
-#if ORBX_BRIEF_PK
     // Round 5: the rotation of a sample point as four packed-fp32 instructions instead of eight scalar ones.  v_pk_mul_f32 /
     // v_pk_add_f32 issue at the full VALU rate on gfx950 (tools/ubench/pk_min3_rate.hip) and round each lane like their
     // scalar forms; op_sel broadcasts x (or y) to both lanes and exchanges (cos, sin), neg_lo turns the low lane's factor
@@ -2044,20 +1886,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(const Geom* __restrict__ g,
         asm("v_pk_add_f32 %0, %1, %2" : "=v"(Z) : "v"(W), "v"(KR));
         rx = __float_as_int(Z.x); ry = __float_as_int(Z.y);
     };
-#endif
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         const float4 pt = spat[ql + 16 * t];
-#if ORBX_BRIEF_PK
         int rx0, ry0, rx1, ry1;
         rot(f2v{pt.x, pt.y}, rx0, ry0);
         rot(f2v{pt.z, pt.w}, rx1, ry1);
-#else
-        const int ry0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)), kRnd));
-        const int rx0 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), kRnd));
-        const int ry1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), kRnd));
-        const int rx1 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)), kRnd));
-#endif
         uint32_t o0, o1;
         asm("v_mad_i32_i24 %0, %1, 40, %2" : "=v"(o0) : "v"(ry0), "v"(rx0));
         asm("v_mad_i32_i24 %0, %1, 40, %2" : "=v"(o1) : "v"(ry1), "v"(rx1));

@@ -351,7 +351,7 @@ int main(int argc, char** argv)
         const std::vector<MapPoint*> before = F.mvpMapPoints;
         ORBmatcher m(0.8f, true);
         const int n = m.SearchByProjection(F, vp, th);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> as;
         check_projection(c, 0.8f, true, as);
         EXPECT(c.nq == expectQueries && c.mode == 3 && c.thDist == 100 && n == c.nmatches && SC(n > 250));
@@ -394,7 +394,7 @@ int main(int argc, char** argv)
         ORBmatcher m(0.9f, true);
         const float th = variant == 1 ? 7.f : 15.f;
         const int n = m.SearchByProjection(Cur, Last, th, bMono);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> as;
         check_projection(c, 0.9f, true, as);
         EXPECT(c.mode == 4 && c.thDist == 100 && n == c.nmatches && SC(n > 150) && SC(c.nq > 300) && c.nq <= nLastPts);
@@ -438,7 +438,7 @@ int main(int argc, char** argv)
         const int ORBdist = variant ? 64 : 100;
         const float th = variant ? 3.f : 10.f;
         const int n = m.SearchByProjection(Cur, kf0, found, th, ORBdist);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> as;
         check_projection(c, 0.9f, true, as);
         EXPECT(c.mode == 5 && c.thDist == ORBdist && n == c.nmatches && SC(n > 100));
@@ -469,7 +469,7 @@ int main(int argc, char** argv)
         const std::vector<MapPoint*> before = vpMatched;
         ORBmatcher m(0.75f, true);
         const int n = m.SearchByProjection(kf1, Scw, vpPoints, vpMatched, 10);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> as;
         check_projection(c, 0.75f, true, as);
         EXPECT(c.mode == 6 && c.thDist == 50 && n == c.nmatches && SC(n > 200));
@@ -493,7 +493,7 @@ int main(int argc, char** argv)
         std::vector<MapPoint*> out(3, w.mps[0].get());
         ORBmatcher m(0.7f, true);
         const int n = m.SearchByBoW(kf0, F, out);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> om(F.N, -1);
         OrcFeatVec a = ofv(c.qfv), b = ofv(c.tfv);
         const int on = orc_search_by_bow(kf0->mDescriptors.ptr<uint8_t>(0), c.qangle.data(), c.qvalid.data(), c.nq, &a, F.mDescriptors.ptr<uint8_t>(0),
@@ -515,7 +515,7 @@ int main(int argc, char** argv)
         w.mps[9]->mbBad = true;
         ORBmatcher m(0.8f, true);
         const int n = m.SearchByBoW(kf0, kf1, out);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> om(kf0->N, -1);
         OrcFeatVec a = ofv(c.qfv), b = ofv(c.tfv);
         const int on = orc_search_by_bow(kf0->mDescriptors.ptr<uint8_t>(0), c.qangle.data(), c.qvalid.data(), c.nq, &a, kf1->mDescriptors.ptr<uint8_t>(0),
@@ -537,7 +537,7 @@ int main(int argc, char** argv)
         std::vector<int> m12;
         ORBmatcher m(0.9f, true);
         const int n = m.SearchForInitialization(F1, F2, prev, m12, 100);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         Grid G = oracle_grid(c.grid, c.tkeys, c.nt);
         std::vector<int32_t> om(F1.N, -1);
         const int on = orc_search_for_initialization(c.q_xy.data(), 100.f, (const OrcKeyPoint*)c.qkeys, F1.mDescriptors.ptr<uint8_t>(0), c.nq, &G.gp,
@@ -570,7 +570,7 @@ int main(int argc, char** argv)
         std::vector<std::pair<size_t, size_t> > pairs;
         ORBmatcher m(0.6f, variant == 0);
         const int n = m.SearchForTriangulation(A, B, F12, pairs, false);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> om(A->N, -1);
         OrcFeatVec a = ofv(c.qfv), b = ofv(c.tfv);
         const int on = orc_search_for_triangulation((const OrcKeyPoint*)c.qkeys, A->mDescriptors.ptr<uint8_t>(0), c.skip1.data(), A->mvuRight.data(), A->N, &a,
@@ -595,7 +595,7 @@ int main(int argc, char** argv)
         Shadow sh; clone_world(w, sh);
         ORBmatcher m(0.6f, true);
         const int n = m.Fuse(kf, cand, 3.0f);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> bi, bd;
         check_window(c, kf->mvInvLevelSigma2, bi, bd);
         EXPECT(c.chi2 == 1 && c.turight == kf->mvuRight.data());
@@ -631,7 +631,7 @@ int main(int argc, char** argv)
         Shadow sh; clone_world(w, sh);
         ORBmatcher m(0.8f, true);
         const int n = m.Fuse(kf0, Scw, pts, 4.f, repl);
-        const ORBmatcher::FlatCall& c = m.last;
+        const ORBmatcher::FlatCall& c = m.last();
         std::vector<int32_t> bi, bd;
         check_window(c, kf0->mvInvLevelSigma2, bi, bd);
         KeyFrame* skf = sh.kf(kf0);
@@ -673,11 +673,11 @@ int main(int argc, char** argv)
         const float s12 = 1.0f;
         const int n = m.SearchBySim3(kf0, kf1, m12, s12, R, t, 7.5f);
         std::vector<int32_t> bi1, bd1, bi2, bd2;
-        check_window(m.last, kf1->mvInvLevelSigma2, bi1, bd1);
-        check_window(m.last2, kf0->mvInvLevelSigma2, bi2, bd2);
+        check_window(m.last(), kf1->mvInvLevelSigma2, bi1, bd1);
+        check_window(m.last2(), kf0->mvInvLevelSigma2, bi2, bd2);
         std::vector<int> v1(kf0->N, -1), v2(kf1->N, -1);
-        for (int q = 0; q < m.last.nq; q++) if (bd1[q] <= 100 && bi1[q] >= 0) v1[m.last.qidx[q]] = bi1[q];
-        for (int q = 0; q < m.last2.nq; q++) if (bd2[q] <= 100 && bi2[q] >= 0) v2[m.last2.qidx[q]] = bi2[q];
+        for (int q = 0; q < m.last().nq; q++) if (bd1[q] <= 100 && bi1[q] >= 0) v1[m.last().qidx[q]] = bi1[q];
+        for (int q = 0; q < m.last2().nq; q++) if (bd2[q] <= 100 && bi2[q] >= 0) v2[m.last2().qidx[q]] = bi2[q];
         int want = 0;
         for (int i = 0; i < kf0->N; i++) {
             MapPoint* exp = before[i];
@@ -685,13 +685,13 @@ int main(int argc, char** argv)
             EXPECT(m12[i] == exp);
         }
         EXPECT(n == want && SC(n > 30) && pre == 25);
-        for (int q = 0; q < m.last.nq; q++) {
-            EXPECT(!before[m.last.qidx[q]]);
-            MapPoint* p = kf0->mvpMapPoints[m.last.qidx[q]];
+        for (int q = 0; q < m.last().nq; q++) {
+            EXPECT(!before[m.last().qidx[q]]);
+            MapPoint* p = kf0->mvpMapPoints[m.last().qidx[q]];
             double u, v, z; project(P1, &w.X[3 * p->id], u, v, z);
-            EXPECT(std::fabs(m.last.q_uvr[3 * q] - u) < 5e-2 && std::fabs(m.last.q_uvr[3 * q + 1] - v) < 5e-2);
+            EXPECT(std::fabs(m.last().q_uvr[3 * q] - u) < 5e-2 && std::fabs(m.last().q_uvr[3 * q + 1] - v) < 5e-2);
         }
-        std::printf("11  SearchBySim3: %d + %d queries, %d mutual matches\n", m.last.nq, m.last2.nq, n);
+        std::printf("11  SearchBySim3: %d + %d queries, %d mutual matches\n", m.last().nq, m.last2().nq, n);
     }
     // ------------------------------------------------------------ static DescriptorDistance
     {

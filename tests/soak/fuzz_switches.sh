@@ -1,5 +1,5 @@
 #!/bin/bash
-# every A/B switch of the library (docs/experiments.md) must leave every result byte alone: the extractor + stream soaks under
+# every run-time switch the library still reads (six since round 6: docs/experiments.md) must leave every result byte alone: the extractor + stream soaks under
 # each of them.  bash tests/soak/fuzz_switches.sh [cases] > gpurun_out/fuzz_switches.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 N=${1:-150}
@@ -10,22 +10,8 @@ run() { # NAME=VALUE ...
 }
 run ORBX_NONE=1
 run ORBX_MATCH_POPCOUNT=1
-run ORBX_BLUR_MFMA=0
-run ORBX_FUSE_EXPAND=0
-run ORBX_FUSE_BLUR=0
-run ORBX_FUSE_PACK=0
-run ORBX_SPLIT=1
-run ORBX_SPLIT=3
-run ORBX_SPLIT=4
 run ORBX_SERIAL=1
-run ORBX_DIST_XCD=0
-run ORBX_PYR_XCD=0
 run ORBX_LAT_STREAMS=2
-run ORBX_LAT_DMA=1
 run ORBX_LAT_PRIO=0
-run ORBX_DOWN_ENGINE=0
-run ORBX_DOWN_GATHER=0
 run ORBX_STAGE_NT=0
-run ORBX_PYR_GRID=8x4
-run ORBX_PYR_REFINE=1
-run ORBX_SHARE_STREAMS=0
+run ORBX_COPY_THREADS=2

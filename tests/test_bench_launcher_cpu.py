@@ -110,6 +110,17 @@ def test_eight_ranks_eight_disjoint_streams_one_record(tmp_path):
     r = rec["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert rec["stats_gather"] == "gloo all_gather"   # (the GPU box: "rccl all_gather ..." -- tests/test_gpu_bench_contract.py)
+    # the self-diagnosing part of the record: one entry per rank with the device it drove, where it was pinned,
+    # its own time and rate, the shader clock behind its region and its parity verdict; min / max / spread over the ranks
+    pr = rec["per_rank"]
+    assert [q["rank"] for q in pr] == list(range(8)) and [q["device"] for q in pr] == list(range(8))
+    for q in pr:
+        assert set(q) >= {"rank", "device", "pci_bus_id", "numa_node", "pinned_to_numa_node", "ms_per_step", "fps",
+                          "shader_clock_mhz_after_region", "parity_ok", "keypoints_last_frame", "matches_last_frame"}
+        assert q["ms_per_step"] >= 2.0 * (q["rank"] + 1) * 0.9 and abs(q["fps"] - 4 / (q["ms_per_step"] / 1e3)) < 1e-6 * q["fps"]
+    f = rec["per_rank_fps"]
+    assert f["min"] == min(q["fps"] for q in pr) and f["max"] == max(q["fps"] for q in pr) and 0.8 < f["spread"] < 0.9   # rank 7 is 8 x slower
+    assert f["distinct_devices"] == 8
 
 
 def test_world_size_must_match_gpus(tmp_path):

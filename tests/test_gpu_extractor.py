@@ -207,13 +207,10 @@ def test_matrix_core_scan_equals_popcount_scan(gpu, monkeypatch):
     assert sum(n for _, n in out[0]) > 5000
 
 
-@pytest.mark.parametrize("form", ["1", "0"])
-def test_matrix_core_blur_equals_dot_product_blur(gpu, oracle, monkeypatch, form):
-    """the Gaussian's two forms -- the pair of banded int8 products on the matrix cores (the default since the stream
-    matcher moved to the fp4 path and left them room) and v_dot4/v_dot2 on the vector units (ORBX_BLUR_MFMA=0) -- give
-    the oracle's bytes: blurred levels and the records built on them, on shapes with interior tiles, border tiles on
-    every side, and levels smaller than one tile"""
-    monkeypatch.setenv("ORBX_BLUR_MFMA", form)
+def test_matrix_core_blur_equals_the_oracles_filter(gpu, oracle):
+    """the Gaussian as a pair of banded int8 products on the matrix cores (k_blur_mfma; the dot-product form it replaced
+    was retired in round 6) gives the oracle's bytes: blurred levels and the records built on them, on shapes with
+    interior tiles, border tiles on every side, and levels smaller than one tile"""
     for w, h, nf in ((1241, 376, 2000), (640, 480, 1000), (401, 263, 700), (97, 81, 200)):
         fr = frames_for(w, h, 2, stream=5)
         gex = gpu_extractor(nf, w, h, B=2)

@@ -10,6 +10,10 @@ def kernels_sha():
     h = hashlib.sha256()
     for p in sorted(glob.glob(os.path.join(root, "*_kernels.hip")) + [os.path.join(root, "orbx_common.hpp")]):
         h.update(open(p, "rb").read())
+    # the one run-time switch that selects other KERNELS (the popcount scan instead of the matrix-core scan): a table taken
+    # under it is not a table of the default build.  (ORBX_SERIAL, under which the counter passes run, only removes overlap.)
+    if os.environ.get("ORBX_MATCH_POPCOUNT") == "1":
+        h.update(b"ORBX_MATCH_POPCOUNT=1")
     return h.hexdigest()[:16]
 
 

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # the counter passes FIRST: bench.py replays their tables (profiles/${TAG}_pmc_*.json) and flags them stale when the kernel sources changed since
 export ORBX_SERIAL=1
 pmc() { # tag, counters
-  timeout 240 rocprofv3 --pmc $2 -d /tmp/pmc_$1 -o p -- python $R/bench.py --no-cpu-baseline --no-profile --no-host-path --no-tracking-path --no-parity-check --pool 2 --steps 5 --warmup 2 > /dev/null 2>&1
+  timeout 240 rocprofv3 --pmc $2 -d /tmp/pmc_$1 -o p -- python $R/bench.py --no-cpu-baseline --no-profile --no-host-path --no-tracking-path --no-natural --no-parity-check --pool 2 --steps 5 --warmup 2 > /dev/null 2>&1
 }
 pmc fetch "FETCH_SIZE"; python $R/tools/rocprof_summary.py pmc /tmp/pmc_fetch/p_results.db > $O/${TAG}_pmc_fetch.txt
 pmc write "WRITE_SIZE"; python $R/tools/rocprof_summary.py pmc /tmp/pmc_write/p_results.db > $O/${TAG}_pmc_write.txt
