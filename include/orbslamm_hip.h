@@ -331,9 +331,11 @@ typedef struct {
  * convention, descriptor, angle (modes 4/5), valid, obs_pos (MapPoint::Observations()>0).
  * t_occ (in/out, nt): train feature must be skipped.  assign (in/out, nt): query index
  * holding train feature t, -1 = NULL.
- * Sizes: the frame's grid lives in one CU's LDS -- at most 8192 train features per frame (ORBX_E_UNSUPPORTED beyond; the
- * reference takes any number, its frames hold 1000-5000); any number of queries.  The same ceiling of 8192 features per
- * frame holds for orbv_transform / orbm_frameset_compute_bow, 65535 for orbx_compute_stereo_matches. */
+ * Sizes (the reference's loops take any, its frames hold 1000-5000 features): up to 8192 train features the frame's grid and
+ * the resolve's tables live in one CU's LDS; beyond -- up to 65535 features per frame and 65536 queries per call, the width
+ * of a feature / query index in the candidate lists (ORBX_E_UNSUPPORTED above) -- the same lists and rounds run from memory
+ * (slower; frames built by the general-size kernels).  orbv_transform / orbm_frameset_compute_bow: any number of descriptors
+ * (the sort's keys in memory above 8192); orbx_compute_stereo_matches: 65535 keypoints per frame. */
 typedef struct {
     int32_t mode;
     float nnratio;

@@ -974,6 +974,18 @@ __global__ void k_grid_sort(int ncell, const int32_t* __restrict__ cellStart, in
     }
 }
 
+// the features in GRID order as {x, y, index | octave << 24, 0}: what the projection searches walk (orbt::FrameSetDev::rec), for
+// frames too large for the one-workgroup build (orbt::k_frame_build keeps the whole grid in LDS)
+__global__ void k_grid_records(const KeyDev* __restrict__ keys, const int32_t* __restrict__ cellStart, int ncell,
+                               const int32_t* __restrict__ cellIdx, uint4* __restrict__ rec)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cellStart[ncell]) return;
+    const int i = cellIdx[j];
+    const KeyDev k = keys[i];
+    rec[j] = make_uint4(__float_as_uint(k.x), __float_as_uint(k.y), (uint32_t)i | ((uint32_t)k.octave << 24), 0u);
+}
+
 // GetFeaturesInArea: calls f(featureIndex) in reference order (ix outer, iy inner, insertion order)
 template <class F>
 __device__ __forceinline__ void for_each_in_area(const GridDev& g, const KeyDev* __restrict__ keys,

@@ -37,7 +37,7 @@ using orbm::UndistArgs;
 constexpr int kThreads = ORBT_THREADS;
 constexpr int kWaves = kThreads / 64;
 constexpr int kFree = 0x7FFFFFFF;
-constexpr int kMaxQueryIters = 32;  // decided-bit per (thread, iteration): nq <= 32 * 1024
+constexpr int kMaxQueryIters = 64;  // nq <= 64 * 1024: a query's index is 16 bits in the per-train post (proj_resolve_rounds)
 
 #ifndef ORBT_ROUND
 #define ORBT_ROUND 1   // the round whose phases ORBT_MARK(11..15) time
@@ -291,6 +291,7 @@ struct ProjPair {
     uint2* cand; int32_t candCap;                // {distance << 20 | octave << 16 | train index, query}
     int32_t* qres;                               // [nq]
     int32_t* qscr;                               // [2 nq ints + nq bytes] best / second / state of a query when they do not fit LDS
+    int32_t* tscr;                               // [3 tCap] the per-train tables of the resolve when they do not fit LDS (ProjCommon::big)
     int32_t* stats;                              // optional: [0] rounds, [1] candidates
     int32_t* flag; int32_t flagValue;            // optional (pinned host): raised behind this pair's results -- a caller polling it
                                                  // skips the wake-up of an event wait (the one-frame-per-call path)
@@ -316,6 +317,9 @@ struct ProjCommon {
     int32_t waveTail;    // resolve: the last rounds by the first wave alone (0: the whole workgroup to the end)
     int32_t lanes;       // candidates: lanes per query, kCandLanes or kCandLanesWide (the host sizes the grid of slices by it)
     int32_t interleave;  // candidates: deal the queries to the slices wave by wave instead of in consecutive runs (few pairs)
+    int32_t big;         // more than ~8 K train features (or a grid whose cell table does not fit): the window walk reads the frame's grid
+                         // records and cell starts from memory, the resolve keeps its per-train tables in ProjPair::tscr -- the
+                         // reference's loops take any size (Frame.cc:327-380, ORBmatcher.cc:45-129); up to 65 535 features a frame
 };
 
 constexpr int kCandThreads = 512;
@@ -350,8 +354,8 @@ __device__ __forceinline__ bool area_window(const GridDev& g, float x, float y, 
     return true;
 }
 
-template <class F>
-__device__ __forceinline__ void area_column(const GridDev& g, const uint4* rec, const uint16_t* cst, const AreaWin& w, int ix,
+template <class CST, class F>
+__device__ __forceinline__ void area_column(const GridDev& g, const uint4* rec, const CST* cst, const AreaWin& w, int ix,
                                             float x, float y, float r, int minLevel, int maxLevel, int seg, int nseg, F f)
 {
     int j0 = cst[ix * g.rows + w.y0], j1 = cst[ix * g.rows + w.y1 + 1];
@@ -420,7 +424,7 @@ __device__ __forceinline__ int quad_scan_excl(int v, int c, int* tot)
 // -- one entry per thread and step, all loads independent (inside the divergent window walk every gather would cost the
 // whole wave a memory round trip) -- and what lies within the threshold goes to a chunk of the pair's arena allocated
 // with one atomicAdd.  Lists keep the reference's scan order (GetFeaturesInArea, Frame.cc:327-380): column by column.
-template <int LANES>
+template <int LANES, bool GLDS>
 __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const ProjCommon& c, int slice)
 {
     constexpr int kSeg = LANES / kCandCols;     // lanes per column slot
@@ -429,18 +433,25 @@ __device__ __forceinline__ void proj_candidates_body(const ProjPair& P, const Pr
     extern __shared__ __attribute__((aligned(16))) int32_t tl[];
     __shared__ int wsum[kCandThreads / 64];
     __shared__ int sBase;
-    uint4* rec = (uint4*)tl;
-    uint2* stage = (uint2*)(rec + c.tCap);
-    uint16_t* cst = (uint16_t*)(stage + c.stageCap);
+    // GLDS: the train frame's grid records and cell starts are staged in LDS (every shipped shape); otherwise (ProjCommon::big)
+    // the walk reads them where they lie -- same lists, same order, at memory latency
+    typedef typename std::conditional<GLDS, uint16_t, int32_t>::type CstT;
+    const uint4* rec; uint2* stage; const CstT* cst;
+    if constexpr (GLDS) { rec = (const uint4*)tl; stage = (uint2*)((uint4*)tl + c.tCap); cst = (const CstT*)(stage + c.stageCap); }
+    else { rec = P.trec; stage = (uint2*)tl; cst = (const CstT*)P.cellStart; }
     const int tid = threadIdx.x, lc = tid & (LANES - 1), lcol = lc / kSeg, lseg = lc % kSeg;
     const int nt = min(P.ntPtr ? *P.ntPtr : P.nt, c.tCap);
     const int nq = min(P.nqPtr ? (P.nq > 0 ? min(*P.nqPtr, P.nq) : *P.nqPtr) : P.nq, kMaxQueryIters * kThreads);
     if (nt <= 0 || (c.interleave ? slice * kWaveQ : slice * kSliceQ) >= nq) return;
     ORBT_MARK(4);
     const int ncell = min(P.grid.cols * P.grid.rows, c.cellCap - 1);
-    for (int ci = tid; ci <= ncell; ci += kCandThreads) cst[ci] = (uint16_t)P.cellStart[ci];
-    const int ngrid = min(P.cellStart[ncell], nt);
-    for (int j = tid; j < ngrid; j += kCandThreads) rec[j] = P.trec[j];
+    if constexpr (GLDS) {
+        uint16_t* cstW = (uint16_t*)(stage + c.stageCap);
+        uint4* recW = (uint4*)tl;
+        for (int ci = tid; ci <= ncell; ci += kCandThreads) cstW[ci] = (uint16_t)P.cellStart[ci];
+        const int ngrid = min(P.cellStart[ncell], nt);
+        for (int j = tid; j < ngrid; j += kCandThreads) recW[j] = P.trec[j];
+    }
     // the query's search window; !ok = the reference skips this query before GetFeaturesInArea
     // Few pairs (a live stream): the slices INTERLEAVE the queries, in units of a wave's 16.  Queries come ordered by pyramid
     // level and a coarse-level window holds many times the features of a fine one: with consecutive runs the last
@@ -871,15 +882,18 @@ __device__ __forceinline__ void proj_resolve_rounds(const ProjPair& P, const Pro
     ORBT_MARK(3);
 }
 
-__device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjCommon& c)
+// the resolve's few static words, declared ONCE in the kernel (a __shared__ inside the templated body would be laid out once per
+// instantiation, and every byte of static LDS comes off the dynamic budget the plan hands out: kProjLdsBudget)
+struct ResolveShared { int hist[32]; int sPending[3]; int sInd[3]; int sCount; int sLive[2]; };
+
+template <bool TLDS>
+__device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjCommon& c, ResolveShared& rs)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t tl[];
-    __shared__ int hist[32];
-    __shared__ int sPending[3];
-    __shared__ int sInd[3];
-    __shared__ int sCount;
-    __shared__ int sLive[2];
-    int32_t* occBy = tl;                   // kFree, -1 (occupied on entry) or the blocking query that took the feature
+    int* const hist = rs.hist; int* const sPending = rs.sPending; int* const sInd = rs.sInd; int* const sLive = rs.sLive;
+    int& sCount = rs.sCount;
+    int32_t* occBy;                        // kFree, -1 (occupied on entry) or the blocking query that took the feature
+    if constexpr (TLDS) occBy = tl; else occBy = P.tscr;
     int32_t* minUnd0 = occBy + c.tCap;     // keyed by round (proj_resolve_rounds)
     int32_t* winner = occBy + 2 * c.tCap;  // last query (in query order) that took the feature in this call
     int32_t* qtab = occBy + 3 * c.tCap;
@@ -902,21 +916,23 @@ __device__ __forceinline__ void proj_resolve_body(const ProjPair& P, const ProjC
         proj_publish(P);
         return;
     }
-    if (total <= c.ldsCand && nq <= c.qCap) proj_resolve_rounds<true>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount, sLive);
+    if (TLDS && total <= c.ldsCand && nq <= c.qCap) proj_resolve_rounds<true>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount, sLive);
     else proj_resolve_rounds<false>(P, c, nq, nt, total, occBy, minUnd0, winner, qtab, hist, sPending, sInd, &sCount, sLive);
 }
 
 __global__ __launch_bounds__(kCandThreads) void k_proj_candidates(const ProjPair* __restrict__ pairs, ProjCommon c)
 {
     const ProjPair P = pairs[blockIdx.y];
-    if (c.lanes == kCandLanesWide) proj_candidates_body<kCandLanesWide>(P, c, blockIdx.x);
-    else proj_candidates_body<kCandLanes>(P, c, blockIdx.x);
+    if (c.big) proj_candidates_body<kCandLanes, false>(P, c, blockIdx.x);
+    else if (c.lanes == kCandLanesWide) proj_candidates_body<kCandLanesWide, true>(P, c, blockIdx.x);
+    else proj_candidates_body<kCandLanes, true>(P, c, blockIdx.x);
 }
 
 __global__ __launch_bounds__(kThreads) void k_proj_resolve(const ProjPair* __restrict__ pairs, ProjCommon c)
 {
     const ProjPair P = pairs[blockIdx.x];
-    proj_resolve_body(P, c);
+    __shared__ ResolveShared rs;
+    if (c.big) proj_resolve_body<false>(P, c, rs); else proj_resolve_body<true>(P, c, rs);
 }
 
 // The frame-to-frame search over pairs of a frame set's slots: the pair records are made here from the slot numbers
@@ -927,7 +943,7 @@ struct TrackArgs {
     GridDev grid;
     float th, minX, maxX, minY, maxY;
     uint8_t* occ; int32_t* assign; int32_t* nmatch; int32_t* stats;   // [pair][cap], [pair][cap] (pinned host), [pair], [pair][2]
-    int32_t* total; int32_t* candOff; int32_t* candCnt; uint2* cand; int32_t candCap; int32_t* qres; int32_t* qscr;  // [pair], [pair][cap] x2, [pair][candCap], [pair][cap], [pair][3 cap]
+    int32_t* total; int32_t* candOff; int32_t* candCnt; uint2* cand; int32_t candCap; int32_t* qres; int32_t* qscr; int32_t* tscr;  // [pair], [pair][cap] x2, [pair][candCap], [pair][cap], [pair][3 cap], big: [pair][3 tCap]
     int32_t pair0;
     int32_t* flag; int32_t flagValue;   // [pair] (pinned host) or null
     int16_t cur[kTrackMaxPairs], last[kTrackMaxPairs];
@@ -952,6 +968,7 @@ __device__ __forceinline__ ProjPair track_pair(const TrackArgs& a, int b)
     P.total = a.total + p;
     P.candOff = a.candOff + p * C; P.candCnt = a.candCnt + p * C; P.cand = a.cand + (int64_t)p * a.candCap; P.candCap = a.candCap;
     P.qres = a.qres + p * C; P.qscr = a.qscr + p * C * 3; P.stats = a.stats + 2 * p;
+    P.tscr = a.tscr ? a.tscr + (int64_t)p * 3 * (((int64_t)C + 63) & ~(int64_t)63) : nullptr;
     P.flag = a.flag ? a.flag + p : nullptr; P.flagValue = a.flagValue;
     return P;
 }
@@ -959,14 +976,16 @@ __device__ __forceinline__ ProjPair track_pair(const TrackArgs& a, int b)
 __global__ __launch_bounds__(kCandThreads) void k_track_candidates(TrackArgs a, ProjCommon c)
 {
     const ProjPair P = track_pair(a, blockIdx.y);
-    if (c.lanes == kCandLanesWide) proj_candidates_body<kCandLanesWide>(P, c, blockIdx.x);
-    else proj_candidates_body<kCandLanes>(P, c, blockIdx.x);
+    if (c.big) proj_candidates_body<kCandLanes, false>(P, c, blockIdx.x);
+    else if (c.lanes == kCandLanesWide) proj_candidates_body<kCandLanesWide, true>(P, c, blockIdx.x);
+    else proj_candidates_body<kCandLanes, true>(P, c, blockIdx.x);
 }
 
 __global__ __launch_bounds__(kThreads) void k_track_resolve(TrackArgs a, ProjCommon c)
 {
     const ProjPair P = track_pair(a, blockIdx.x);
-    proj_resolve_body(P, c);
+    __shared__ ResolveShared rs;
+    if (c.big) proj_resolve_body<false>(P, c, rs); else proj_resolve_body<true>(P, c, rs);
 }
 
 }  // namespace orbt

@@ -193,17 +193,21 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* keys, uint64_t* tmp, i
     __syncthreads();
 }
 
-template <bool ACC_LDS>  // word values staged in LDS (P <= 4096) or worked on in place in outW
+// KEYS_MEM: more than 8192 descriptors (P * 12 bytes of keys and group indices no longer fit a CU's LDS): the same sort and scans on a
+// scratch block in memory (gkeys: P * 12 bytes) -- DBoW2's transform takes any number of features (TemplatedVocabulary.h:1120-1160)
+template <bool ACC_LDS, bool KEYS_MEM = false>  // word values staged in LDS (P <= 4096) or worked on in place in outW
 __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P,
                                                    const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
                                                    const double* __restrict__ w,
                                                    uint32_t* __restrict__ outWord, double* __restrict__ outW,
                                                    uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
-                                                   int32_t* __restrict__ fvIdx, int32_t* __restrict__ counts)
+                                                   int32_t* __restrict__ fvIdx, int32_t* __restrict__ counts, uint64_t* gkeys = nullptr)
 {
+    static_assert(!(ACC_LDS && KEYS_MEM), "the memory form keeps nothing in LDS");
     extern __shared__ __attribute__((aligned(16))) uint64_t alds[];
-    uint64_t* keys = alds;
-    uint32_t* pos = (uint32_t*)(alds + P);
+    uint64_t* keys; uint32_t* pos;
+    if constexpr (KEYS_MEM) { keys = gkeys; pos = (uint32_t*)(gkeys + P); }
+    else { keys = alds; pos = (uint32_t*)(alds + P); }
     double* accL = ACC_LDS ? (double*)(alds + P + P / 2) : outW;   // P >= 2
     uint64_t* tmp = alds + 2 * P + P / 2;       // ACC_LDS only: the bucket sort's scratch (P keys + 2 P ints)
     int* bcnt = (int*)(tmp + P);
@@ -309,6 +313,16 @@ __device__ __forceinline__ void voc_aggregate_body(const VocDev& v, int n, int P
     ORBV_MARK(6);
 }
 
+__global__ __launch_bounds__(kAggThreads) void k_voc_aggregate_mem(VocDev v, int n, int P,
+                                                                  const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
+                                                                  const double* __restrict__ w,
+                                                                  uint32_t* __restrict__ outWord, double* __restrict__ outW,
+                                                                  uint32_t* __restrict__ fvNode, int32_t* __restrict__ fvStart,
+                                                                  int32_t* __restrict__ fvIdx, int32_t* __restrict__ counts, uint64_t* gkeys)
+{
+    voc_aggregate_body<false, true>(v, n, P, word, node, w, outWord, outW, fvNode, fvStart, fvIdx, counts, gkeys);
+}
+
 template <bool ACC_LDS>
 __global__ __launch_bounds__(kAggThreads) void k_voc_aggregate(VocDev v, int n, int P,
                                                               const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
@@ -327,6 +341,7 @@ struct VocSetArgs {
     uint32_t* word; uint32_t* node; double* w;                    // scratch of the descent
     uint32_t* outWord; double* outW;                              // BowVector
     uint32_t* fvNode; int32_t* fvStart; int32_t* fvIdx; int32_t* counts;  // FeatureVector as CSR, counts = {words, nodes}
+    uint64_t* gkeys;                                              // frames of more than 8192 features: [slot][P * 12 bytes] of sort scratch in memory
 };
 
 __global__ void k_voc_descend_set(VocDev v, VocSetArgs a, int levelsup)
@@ -371,6 +386,20 @@ __global__ __launch_bounds__(kAggThreads) void k_voc_aggregate_set(VocDev v, Voc
     }
     voc_aggregate_body<ACC_LDS>(v, n, a.P, a.word + o, a.node + o, a.w + o, a.outWord + o, a.outW + o, a.fvNode + o,
                                 a.fvStart + (int64_t)slot * (a.cap + 1), a.fvIdx + o, a.counts + 2 * slot);
+}
+
+__global__ __launch_bounds__(kAggThreads) void k_voc_aggregate_set_mem(VocDev v, VocSetArgs a)
+{
+    const int slot = (a.slot0 + blockIdx.x) % a.slotMod;
+    const int n = min(a.n[slot], a.cap);
+    const int64_t o = (int64_t)slot * a.cap;
+    if (n == 0 || v.L == 0) {
+        if (threadIdx.x == 0) { a.counts[2 * slot] = 0; a.counts[2 * slot + 1] = 0; a.fvStart[(int64_t)slot * (a.cap + 1)] = 0; }
+        return;
+    }
+    voc_aggregate_body<false, true>(v, n, a.P, a.word + o, a.node + o, a.w + o, a.outWord + o, a.outW + o, a.fvNode + o,
+                                    a.fvStart + (int64_t)slot * (a.cap + 1), a.fvIdx + o, a.counts + 2 * slot,
+                                    (uint64_t*)((uint8_t*)a.gkeys + (int64_t)slot * a.P * 12));
 }
 
 }  // namespace orbv

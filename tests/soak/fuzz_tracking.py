@@ -39,9 +39,11 @@ def local_map_queries(rng, frames, sf, th, nq_target):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-    nfmax = int(sys.argv[3]) if len(sys.argv) > 3 else 2400   # features per frame below this (above ~4000 the set's BoW sort leaves LDS)
-    rng = np.random.default_rng(seed)
+    nfmax = int(sys.argv[3]) if len(sys.argv) > 3 else 2400   # features per frame below this (above ~4000 the set's BoW sort leaves LDS;
+    rng = np.random.default_rng(seed)                         # above 8192 every search and the frame build take their memory forms)
     shapes = [(640, 480), (1241, 376), (752, 480), (512, 384)]
+    if nfmax > 5000:
+        shapes = [(1920, 1080), (1400, 1000), (1241, 376)]    # frames that can hold that many features
     counts = {"local_points": 0, "projected": 0, "bow_vectors": 0, "bow_pairs": 0}
     t0 = time.time()
     for r in range(rounds):
@@ -66,7 +68,7 @@ def main():
             kc, dc = host[t]
             start, idx = ob.grid_build(gp, kc)
             others = [host[i] for i in range(B) if i != t]
-            th = float(rng.choice([1.0, 3.0, 5.0])); nq = int(rng.integers(1, 5000))
+            th = float(rng.choice([1.0, 3.0, 5.0])); nq = int(rng.integers(1, max(5000, 2 * nf)))
             uvr, ql, qd, qv, qo = local_map_queries(rng, others, sf, th, nq)
             with_occ = bool(rng.integers(0, 2))
             occ = (rng.random(len(kc)) < 0.3).astype(np.uint8) if with_occ else np.zeros(len(kc), np.uint8)

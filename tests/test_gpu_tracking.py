@@ -100,11 +100,10 @@ def test_projection_degenerate_shapes(gpu, oracle):
     a, occ, n = m.SearchByProjection(4, 100, np.zeros((0, 3), np.float32), np.zeros((0, 2), np.int8), np.zeros((0, 32), np.uint8),
                                      np.zeros(0, np.float32), None, None, g, c["tk"], c["td"], c["occ"], np.full(50, -1, np.int32))
     assert n == 0 and (a == -1).all() and np.array_equal(occ, c["occ"])
-    from orbslamm_amd._lib import OrbError
+    # (10 001 train features -- beyond the LDS form -- used to be refused here; since round 6 they are searched from memory:
+    # tests/test_gpu_large_frames.py)
     big = make_proj_case(rng, 10, 10001)
-    with pytest.raises(OrbError):  # the frame's grid must fit one CU's LDS: refused, not silently truncated
-        m.SearchByProjection(4, 100, big["uvr"], big["lvl"], big["qd"], big["qa"], None, None, g, big["tk"], big["td"], big["occ"],
-                             np.full(10001, -1, np.int32))
+    _both(oracle, 4, 100, 0.9, True, big, 10001)
 
 
 def _identity_queries(keys_un, sf, th, bounds):
