@@ -1202,7 +1202,8 @@ def run_rank(args):
             out["roofline"]["mfma"] = mm
             if sq_tab and args.config == "c3":
                 cyc, clk = sq_tab["cycles_per_valu_instr"], sq_tab["clock_ghz"] * 1e9
-                tot = sum(v["valu"] for v in sq_tab["kernels"].values()) * B / sq_tab["frames_per_step"]
+                # (the counter passes also see the clock probe of the per-rank diagnosis: not a kernel of the step)
+                tot = sum(v["valu"] for k, v in sq_tab["kernels"].items() if k != "k_clock_probe") * B / sq_tab["frames_per_step"]
                 out["roofline"]["pipeline_issue_frac"] = tot * cyc / (SIMDS * clk * dt_max / args.steps)
         elif prof:
             out["roofline"] = roofline_of(prof, DOMINANT, steps_bracketed)  # --no-replay: the kernel named by the isolated runs so far

@@ -278,7 +278,11 @@ void orbm_destroy(orbm_t* h);
  * mbCheckOrientation) -- include/ORBmatcher.h:96-97.  The device state a search needs (queue, grow-only scratch, pinned
  * staging block, the pool of frame blocks) therefore belongs to the calling THREAD: this returns the thread's handle for
  * `device`, made at the thread's first call and released when the thread ends (frames made through it keep it alive).  Its
- * queue is one of the device's four shared chain streams, not one more queue per thread.  Never pass it to orbm_destroy. */
+ * queue is one of the device's four shared chain streams, not one more queue per thread (same priority as the latency
+ * extractors' chains: high, or normal under ORBX_LAT_PRIO=0).  The price of sharing: the handle's synchronous entries wait on
+ * a stream that other robots' chains and matcher calls are queued on too -- with more than four robot threads on a device a
+ * call can wait for another robot's work (latency coupling, never a wrong result).  A caller that wants a queue of its own
+ * takes orbm_create.  Never pass the thread handle to orbm_destroy. */
 int orbm_thread_handle(int device, orbm_t** out);
 /* Allocation counters: device allocations (scratch growth + frame blocks) and pinned allocations of handle h (0 for a
  * null h), and the number of matcher handles the process has made.  A steady-state loop leaves all three unchanged. */
@@ -502,6 +506,14 @@ int orbm_track_stats(orbm_frameset_t* fs, int pair, int* rounds, int* candidates
  * K = fx, fy, cx, cy; D = k1, k2, p1, p2, k3.  D[0] == 0: plain copy (:406-410).  Only pt changes. */
 int orbm_undistort_keypoints(orbm_t* h, const OrbxKeyPoint* keys, int n, const float K[4], const float D[5],
                              OrbxKeyPoint* keys_un);
+
+/* void Frame::ComputeStereoFromRGBD(const cv::Mat& imDepth)   src/Frame.cc:641-663 (the RGB-D Frame constructor, :104-142).
+ * depth: the CV_32F depth image (w x hh floats, rows `stride` floats apart, already scaled by mDepthMapFactor as Tracking::
+ * GrabImageRGBD does, src/Tracking.cc:215-216); keys = mvKeys (the lookup uses the DISTORTED position, float -> int by
+ * truncation like Mat::at<float>(v, u)), keys_un = mvKeysUn.  uright[i] = kpU.pt.x - mbf / d and depth_out[i] = d where
+ * d > 0, else both -1.  A keypoint outside the depth image (the reference reads out of bounds) counts as d = 0. */
+int orbm_compute_stereo_from_rgbd(orbm_t* h, const OrbxKeyPoint* keys, const OrbxKeyPoint* keys_un, int n, const float* depth, int w, int hh,
+                                  int stride, float mbf, float* uright, float* depth_out);
 
 /* void MapPoint::ComputeDistinctiveDescriptors()   src/MapPoint.cc:242-307, batched over map points.
  * desc = the observations' descriptors of all points back to back, start[npoints+1] = CSR.

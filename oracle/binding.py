@@ -494,3 +494,15 @@ def undistort_keypoints(keys, K, D, L=None):
     out = np.zeros_like(keys)
     L.orc_undistort_keypoints(_p(keys), keys.shape[0], _p(K), _p(D), _p(out))
     return out
+
+
+def stereo_from_rgbd(keys, keys_un, depth, mbf, L=None):
+    """Frame::ComputeStereoFromRGBD (Frame.cc:641-663) -> (mvuRight, mvDepth)"""
+    L = L or lib()
+    keys = np.ascontiguousarray(keys, dtype=KP_DTYPE)
+    keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    n = keys.shape[0]
+    ur = np.zeros(n, np.float32); dp = np.zeros(n, np.float32)
+    L.orc_stereo_from_rgbd(_p(keys), _p(keys_un), n, _p(depth), depth.shape[1], depth.shape[0], depth.shape[1], C.c_float(mbf), _p(ur), _p(dp))
+    return ur, dp

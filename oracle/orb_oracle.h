@@ -239,6 +239,8 @@ int  orc_compute_stereo_matches(const OrcKeyPoint* keysL, const uint8_t* descL, 
                                 float mb, float mbf, float* mvuRight, float* mvDepth);
 
 /* Frame::UndistortKeyPoints (src/Frame.cc:404-434), OpenCV 3.0 undistortPoints (unpinned) */
+void orc_stereo_from_rgbd(const OrcKeyPoint* keys, const OrcKeyPoint* keysUn, int n, const float* depth, int w, int h, int stride,
+                          float mbf, float* mvuRight, float* mvDepth);
 void orc_undistort_keypoints(const OrcKeyPoint* in, int n, const float K[4], const float D[5], OrcKeyPoint* out);
 
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched */

@@ -133,3 +133,20 @@ int orc_compute_stereo_matches(const OrcKeyPoint* keysL, const uint8_t* descL, i
     free(vDistIdx); free(rowIdx); free(rowStart); free(maxr); free(minr); free(rowCount);
     return nDist;
 }
+
+/* ------------------------------------------------------------------ ref: Frame.cc:641-663 Frame::ComputeStereoFromRGBD
+ * imDepth.at<float>(v, u) with float v, u: the arguments convert to int (truncation).  Deterministic refinement: a keypoint
+ * outside the depth image (out-of-bounds read in the reference) counts as d = 0. */
+void orc_stereo_from_rgbd(const OrcKeyPoint* keys, const OrcKeyPoint* keysUn, int n, const float* depth, int w, int h, int stride,
+                          float mbf, float* mvuRight, float* mvDepth)
+{
+    for (int i = 0; i < n; i++) {
+        mvuRight[i] = -1; mvDepth[i] = -1;                    /* :643-644 */
+        const int v = (int)keys[i].y, u = (int)keys[i].x;     /* :651-654 */
+        const float d = (u >= 0 && u < w && v >= 0 && v < h) ? depth[(size_t)v * stride + u] : 0.f;
+        if (d > 0) {                                          /* :656-660 */
+            mvDepth[i] = d;
+            mvuRight[i] = keysUn[i].x - mbf / d;
+        }
+    }
+}

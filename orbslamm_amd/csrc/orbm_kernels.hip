@@ -1321,6 +1321,22 @@ __global__ void k_octave0_flags(const KeyDev* __restrict__ keys, int n, uint8_t*
     if (i < n) out[i] = keys[i].octave <= 0;
 }
 
+// void Frame::ComputeStereoFromRGBD(const cv::Mat& imDepth)   src/Frame.cc:641-663: the depth under every (distorted) keypoint,
+// imDepth.at<float>(v, u) with the FLOAT coordinates converted to int (truncation); d > 0 -> mvDepth = d, mvuRight =
+// kpU.pt.x - mbf / d (binary32, the division first); else both -1.  A keypoint outside the depth image (the reference would
+// read out of bounds) counts as d = 0.
+__global__ void k_stereo_from_rgbd(const KeyDev* __restrict__ keys, const KeyDev* __restrict__ keysUn, int n, const float* __restrict__ depth,
+                                   int w, int h, int stride, float mbf, float* __restrict__ uRight, float* __restrict__ outDepth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = (int)keys[i].y, u = (int)keys[i].x;
+    const float d = (u >= 0 && u < w && v >= 0 && v < h) ? depth[(int64_t)v * stride + u] : 0.f;
+    const bool ok = d > 0.f;
+    outDepth[i] = ok ? d : -1.f;
+    uRight[i] = ok ? __fsub_rn(keysUn[i].x, __fdiv_rn(mbf, d)) : -1.f;
+}
+
 struct UndistArgs { double fx, fy, cx, cy, k1, k2, p1, p2, k3; };
 __global__ void k_undistort(const KeyDev* __restrict__ in, int n, UndistArgs a, KeyDev* __restrict__ out)
 {

@@ -286,6 +286,17 @@ class ORBmatcher:
         check(self._L.orbm_undistort_keypoints(self._h, ptr(keys), keys.shape[0], ptr(K), ptr(D), ptr(out)))
         return out
 
+    def ComputeStereoFromRGBD(self, keys, keys_un, depth, mbf):
+        """Frame::ComputeStereoFromRGBD (Frame.cc:641-663): depth = float32 image; returns (mvuRight, mvDepth)"""
+        keys = np.ascontiguousarray(keys, dtype=KP_DTYPE)
+        keys_un = np.ascontiguousarray(keys_un, dtype=KP_DTYPE)
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        n = keys.shape[0]
+        ur = np.zeros(n, np.float32); dp = np.zeros(n, np.float32)
+        check(self._L.orbm_compute_stereo_from_rgbd(self._h, ptr(keys), ptr(keys_un), n, ptr(depth), depth.shape[1], depth.shape[0], depth.shape[1],
+                                                    C.c_float(mbf), ptr(ur), ptr(dp)))
+        return ur, dp
+
     def ComputeDistinctiveDescriptors(self, desc, start):
         """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242), batched: desc = all observations'
         descriptors back to back, start = CSR offsets per map point; returns the winning index per point"""

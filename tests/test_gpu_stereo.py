@@ -72,3 +72,31 @@ def test_stereo_argument_errors(gpu):
     # (:628-637) throws every match away -- the reference's behaviour, literally
     u, d = a.compute_stereo_matches(b, 0.1, 40.0)
     assert len(u) > 100 and np.all(u == -1) and np.all(d == -1)
+
+
+def test_compute_stereo_from_rgbd_parity(gpu, oracle):
+    """Frame::ComputeStereoFromRGBD (Frame.cc:641-663, the RGB-D constructor's tail): depth under the DISTORTED keypoint
+    (float -> int by truncation), mvuRight from the UNDISTORTED x; holes (d <= 0, NaN) and keypoints outside the depth
+    image give -1 / -1.  Byte for byte against the oracle."""
+    from orbslamm_amd import ORBextractor, ORBmatcher
+    w, h, nf = 640, 480, 1000
+    K = [517.306408, 516.469215, 318.643040, 255.313989]
+    D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+    fr = frames_for(w, h, 1, stream=12)[0]
+    gex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1, device=0)
+    keys, _ = gex(fr)
+    m = ORBmatcher(0.9, True, device=0)
+    keys_un = m.UndistortKeyPoints(keys, K, D)
+    rng = np.random.default_rng(641)
+    depth = rng.uniform(0.3, 8.0, size=(h, w)).astype(np.float32)
+    depth[rng.random((h, w)) < 0.2] = 0.0          # holes of the sensor
+    depth[rng.random((h, w)) < 0.02] = -1.0
+    depth[rng.random((h, w)) < 0.01] = np.nan
+    for dimg, kk in ((depth, keys), (depth[:300, :500], keys)):      # the second: a depth image smaller than the frame
+        want_u, want_d = oracle.stereo_from_rgbd(kk, keys_un, dimg, 40.0)
+        got_u, got_d = m.ComputeStereoFromRGBD(kk, keys_un, dimg, 40.0)
+        assert got_u.tobytes() == want_u.tobytes() and got_d.tobytes() == want_d.tobytes()
+        assert (got_d > 0).sum() > 200 and (got_d == -1).sum() > 50
+    u0, d0 = m.ComputeStereoFromRGBD(keys[:0], keys_un[:0], depth, 40.0)
+    assert len(u0) == 0 and len(d0) == 0
+    m.close(); gex.close()

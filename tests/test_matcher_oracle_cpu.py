@@ -133,3 +133,17 @@ def test_window_best_and_init_and_triangulation_oracle(oracle):
                                            1 - tc["c"]["tv"], tc["c"]["tfv"], tc["F"], tc["ex"], tc["ey"], tc["sf2"], tc["sigma2"],
                                            False, False)
     assert n == (m >= 0).sum()
+
+
+def test_stereo_from_rgbd_semantics(oracle):
+    """Frame.cc:641-663: depth looked up at the truncated distorted position, uRight from the undistorted x (binary32: the
+    division first), -1 / -1 for holes; outside the image counts as a hole (the reference reads out of bounds)"""
+    k = np.zeros(5, oracle.KP_DTYPE); ku = np.zeros(5, oracle.KP_DTYPE)
+    k["x"] = [3.7, 10.2, 0.9, 50.0, 7.99]; k["y"] = [2.2, 5.9, 0.1, 3.0, 7.99]
+    ku["x"] = [4.0, 11.0, 1.0, 51.0, 8.5]
+    d = (np.arange(20 * 8, dtype=np.float32).reshape(8, 20) - 5)
+    ur, dp = oracle.stereo_from_rgbd(k, ku, d, 40.0)
+    assert dp.tolist() == [38.0, 105.0, -1.0, -1.0, 142.0]           # d[2,3], d[5,10], d[0,0] = -5 (hole), outside, d[7,7]
+    want = [np.float32(4.0) - np.float32(40.0) / np.float32(38.0), np.float32(11.0) - np.float32(40.0) / np.float32(105.0), -1.0, -1.0,
+            np.float32(8.5) - np.float32(40.0) / np.float32(142.0)]
+    assert ur.tolist() == [float(np.float32(x)) for x in want]
