@@ -165,10 +165,24 @@ public:
     // Microseconds the calling thread's last member call spent inside the C ABI (upload, kernels, download, wait).  What a
     // drop-in member costs beyond this is the object-graph walk around it -- the reference's own loop head and write-back.
     static double& lastDeviceUs() { static thread_local double us = 0; return us; }
+    static double& pendingPrepareUs() { static thread_local double us = 0; return us; }   // a PrepareTrain not yet charged to its search
     struct DeviceClock {
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-        ~DeviceClock() { lastDeviceUs() = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+        ~DeviceClock()
+        {
+            lastDeviceUs() = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() + pendingPrepareUs();
+            pendingPrepareUs() = 0;
+        }
     };
+
+    // The train side of the next SearchByProjection goes up and its grid is built while the caller walks its MapPoints
+    // (orbm_projection_prepare: asynchronous, a hint -- the search uploads the frame itself if it was handed other arrays).
+    void PrepareTrain(const OrbmGrid& grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc, int nt)
+    {
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        check(orbm_projection_prepare(handle(), &grid, t_keys_un, tdesc, nt));
+        pendingPrepareUs() += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
 
     // static int DescriptorDistance(const cv::Mat&, const cv::Mat&)  ORBmatcher.cc:1649.
     // One pair per launch: residual callers only; hot callers use the batched members below.
@@ -455,6 +469,8 @@ public:
     int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3)
     {
         FlatCall& c = begin("SearchByProjection(Frame,MapPoints)", 3, TH_HIGH);
+        trainFromFrame(c, F, /*blockOnObservations=*/true);   // first: the frame goes up and its grid is built under the walk below
+        flat_.PrepareTrain(c.grid, c.tkeys, c.tdesc, c.nt);
         const bool bFactor = th != 1.0;
         bool stereo = false;
         for (size_t i = 0; i < F.mvuRight.size() && !stereo; i++) stereo = F.mvuRight[i] > 0;
@@ -470,7 +486,6 @@ public:
                       pMP, 0.f, (int)iMP);
             if (stereo) c.q_ur.push_back(pMP->mTrackProjXR);
         }
-        trainFromFrame(c, F, /*blockOnObservations=*/true);
         runProjection(c, stereo ? F.mvuRight.data() : nullptr);
         for (int t = 0; t < c.nt; t++)
             if (c.assign[t] >= 0) F.mvpMapPoints[t] = vpMapPoints[c.qidx[c.assign[t]]];
@@ -482,6 +497,8 @@ public:
     {
         using namespace cvsem;
         FlatCall& c = begin("SearchByProjection(Frame,Frame)", 4, TH_HIGH);
+        trainFromFrame(c, CurrentFrame, /*blockOnObservations=*/true);   // (under the walk of LastFrame's MapPoints, see mode 3)
+        flat_.PrepareTrain(c.grid, c.tkeys, c.tdesc, c.nt);
         const Mat33 Rcw = mat33(CurrentFrame.mTcw);
         const Vec3 tcw = col3(CurrentFrame.mTcw, 0, 3);
         const Vec3 twc = negTransposeMul(Rcw, tcw);
@@ -514,7 +531,6 @@ public:
             pushQuery(c, u, v, radius, minL, maxL, pMP, LastFrame.mvKeysUn[i].angle, i);
             if (stereo) c.q_ur.push_back(u - CurrentFrame.mbf * invzc);
         }
-        trainFromFrame(c, CurrentFrame, /*blockOnObservations=*/true);
         runProjection(c, stereo ? CurrentFrame.mvuRight.data() : nullptr);
         for (int t = 0; t < c.nt; t++) {
             if (c.assign[t] >= 0) CurrentFrame.mvpMapPoints[t] = LastFrame.mvpMapPoints[c.qidx[c.assign[t]]];
@@ -528,6 +544,8 @@ public:
     {
         using namespace cvsem;
         FlatCall& c = begin("SearchByProjection(Frame,KeyFrame)", 5, ORBdist);
+        trainFromFrame(c, CurrentFrame, /*blockOnObservations=*/false);
+        flat_.PrepareTrain(c.grid, c.tkeys, c.tdesc, c.nt);
         const Mat33 Rcw = mat33(CurrentFrame.mTcw);
         const Vec3 tcw = col3(CurrentFrame.mTcw, 0, 3);
         const Vec3 Ow = negTransposeMul(Rcw, tcw);
@@ -552,7 +570,6 @@ public:
             const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
             pushQuery(c, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, pMP, pKF->mvKeysUn[i].angle, (int)i);
         }
-        trainFromFrame(c, CurrentFrame, /*blockOnObservations=*/false);
         runProjection(c, nullptr);
         for (int t = 0; t < c.nt; t++) {
             if (c.assign[t] >= 0) CurrentFrame.mvpMapPoints[t] = vpMPs[c.qidx[c.assign[t]]];
@@ -568,8 +585,9 @@ public:
         FlatCall& c = begin("SearchByProjection(KeyFrame,Scw)", 6, TH_LOW);
         std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
         spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
-        projectIntoKeyFrame(c, pKF, Scw, vpPoints, spAlreadyFound, (float)th, /*windowMode=*/false);
         trainFromKeyFrame(c, pKF);
+        flat_.PrepareTrain(c.grid, c.tkeys, c.tdesc, c.nt);
+        projectIntoKeyFrame(c, pKF, Scw, vpPoints, spAlreadyFound, (float)th, /*windowMode=*/false);
         c.tocc_in.assign(c.nt, 0);
         for (int t = 0; t < c.nt; t++) c.tocc_in[t] = vpMatched[t] != NULL;
         runProjection(c, nullptr);

@@ -364,6 +364,13 @@ int orbm_search_by_projection_stereo(orbm_t* h, const OrbmProjParams* pp,
                                      const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un,
                                      const uint8_t* tdesc, const float* t_uright, int nt,
                                      uint8_t* t_occ, int32_t* assign, int* nmatches);
+/* Optional hint of the drop-in members (include/ORBmatcher_hip.hpp): the train side of the NEXT orbm_search_by_projection(_stereo)
+ * on this handle -- the very arrays, count and grid that call will pass -- is uploaded and its grid built NOW, asynchronously, so
+ * that the device works while the caller walks its MapPoints (the reference's loop head, ORBmatcher.cc:53-76, :1355-1392: mutex-
+ * guarded getters, ~100 us for a frame's worth).  The search compares pointers, count and grid with what was prepared and does
+ * its own upload when they differ; one search per prepare.  The arrays must not change between the two calls. */
+int orbm_projection_prepare(orbm_t* h, const OrbmGrid* grid, const OrbxKeyPoint* t_keys_un, const uint8_t* tdesc, int nt);
+
 
 /* ---- the remaining ORBmatcher entry points on the same primitive ---- */
 

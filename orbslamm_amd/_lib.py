@@ -69,7 +69,7 @@ EXPORTS = [
     "orbx_pyramid_level", "orbx_compute_stereo_matches", "orbx_level_candidates", "orbx_sync", "orbx_device_alloc", "orbx_device_free", "orbx_upload", "orbx_match_prev_batch_device",
     "orbx_device_matches", "orbx_download_matches", "orbx_reset_stream", "orbx_set_serial", "orbx_profile_enable",
     "orbx_profile_read", "orbx_debug_pair_overlap", "orbx_debug_link_rate", "orbx_debug_stage_rows", "orbx_profile_select", "orbm_create", "orbm_destroy", "orbm_thread_handle", "orbm_alloc_stats", "orbm_distance_matrix", "orbm_match_bruteforce",
-    "orbm_search_by_bow", "orbm_search_by_projection", "orbm_search_by_projection_stereo", "orbm_features_in_area", "orbm_window_best",
+    "orbm_search_by_bow", "orbm_search_by_projection", "orbm_search_by_projection_stereo", "orbm_projection_prepare", "orbm_features_in_area", "orbm_window_best",
     "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_distinctive_descriptors", "orbm_descriptors_to_text", "orbm_descriptors_from_text", "orbm_undistort_keypoints", "orbm_compute_stereo_from_rgbd", "orbm_frame_create", "orbm_frame_destroy", "orbm_frame_size", "orbm_frame_settle",
     "orbm_frame_download_keys_un", "orbm_search_by_projection_frame", "orbm_frame_compute_bow", "orbm_search_by_bow_frames", "orbm_search_for_initialization_frames", "orbm_window_best_frame", "orbm_search_for_triangulation_frames",
     "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_transform",

@@ -113,6 +113,12 @@ class ORBmatcher:
                                                 ptr(tdesc), t_keys_un.shape[0], ptr(t_occ), ptr(assign), C.byref(n)))
         return assign, t_occ, n.value
 
+    def ProjectionPrepare(self, grid, t_keys_un, tdesc):
+        """orbm_projection_prepare: the train side of the next SearchByProjection goes up now (pass the SAME contiguous arrays to
+        that call: the hint is matched by pointer)"""
+        assert t_keys_un.flags["C_CONTIGUOUS"] and t_keys_un.dtype == KP_DTYPE and tdesc.flags["C_CONTIGUOUS"] and tdesc.dtype == np.uint8
+        check(self._L.orbm_projection_prepare(self._h, C.byref(grid), ptr(t_keys_un), ptr(tdesc), t_keys_un.shape[0]))
+
     # ---- SURVEY.md 8(f) rank 3: the Frame's matcher-side state in HBM
     def frame_from_device(self, d_keys, d_desc, n, K, D, grid):
         """Frame::Frame tail (UndistortKeyPoints + AssignFeaturesToGrid) on device-resident extractor output;

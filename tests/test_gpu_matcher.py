@@ -166,6 +166,38 @@ def test_search_by_projection_parity(gpu, oracle, mode, th, ratio):
         assert wn > 0
 
 
+def test_projection_prepare_is_a_hint_not_a_contract(gpu, oracle):
+    """orbm_projection_prepare (the drop-in members upload the train frame under their MapPoint walk): a search that follows
+    with the SAME arrays finds the frame resident, one that follows with OTHER arrays (or another grid, or after a second
+    search) uploads its own -- the results are the oracle's either way, in the LDS form and in the memory form"""
+    from orbslamm_amd import ORBmatcher, make_grid
+    rng = np.random.default_rng(4711)
+    m = ORBmatcher(0.9, True, device=0)
+    for nq, nt in ((1500, 2000), (700, 9000)):
+        c, d = make_proj_case(rng, nq, nt), make_proj_case(rng, nq, nt)
+        g = make_grid(0.0, 0.0, c["w"], c["h"])
+        g2 = make_grid(1.0, 0.0, c["w"], c["h"])
+        a0 = np.full(nt, -1, np.int32)
+
+        def want(cc):
+            return oracle.search_by_projection(4, 0.9, True, 100, cc["uvr"], cc["lvl"], cc["qd"], cc["qa"], cc["qv"], cc["qo"], cc["gp"],
+                                               cc["tk"], cc["start"], cc["idx"], cc["td"], cc["occ"], a0)
+
+        def got(cc):
+            return m.SearchByProjection(4, 100, cc["uvr"], cc["lvl"], cc["qd"], cc["qa"], cc["qv"], cc["qo"], g, cc["tk"], cc["td"], cc["occ"], a0)
+
+        def same(x, y):
+            return x[2] == y[2] and np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+        wc, wd = want(c), want(d)
+        m.ProjectionPrepare(g, c["tk"], c["td"]); assert same(got(c), wc)      # prepared and used
+        assert same(got(c), wc)                                                # the hint is spent: own upload, same result
+        m.ProjectionPrepare(g, c["tk"], c["td"]); assert same(got(d), wd)      # prepared with other arrays: ignored
+        m.ProjectionPrepare(g2, c["tk"], c["td"]); assert same(got(c), wc)     # prepared on another grid: ignored
+        m.ProjectionPrepare(g, c["tk"], c["td"]); m.ProjectionPrepare(g, d["tk"], d["td"]); assert same(got(d), wd)   # the later prepare counts
+        assert wc[2] > 100 and wd[2] > 100
+    m.close()
+
+
 def test_projection_overwrite_semantics(gpu, oracle):
     """mode 4: a MapPoint without observations does not block the feature, a later query
     takes it again and both matches are counted (ORBmatcher.cc:1405-1407, 1430-1431)"""
