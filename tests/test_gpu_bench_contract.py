@@ -119,6 +119,16 @@ def test_default_record_carries_the_side_blocks_under_one_budget(gpu):
     assert d["steady_state"]["none_made"] is True and 0 < d["median_motion_model_frame_ms"] < 1.5 == (c["dropin_classes_tracking_frame_ms_median"] < 1.5) * 1.5
     assert rec["live_streams"]["one_robot"]["track"]["ms_median"] < 0.5
     assert rec["parity_check"]["ok"] is True
+    # round 6: the protocol figure at the top level, the natural-statistics block, the per-rank self-diagnosis
+    assert rec["value_host_inclusive"] == c["host_inclusive_fps_pinned"] and rec["value_host_inclusive_pageable"] == c["host_inclusive_fps_pageable"]
+    nat = rec["natural"]
+    for seq in ("retina_pan", "mosaic", "hubble"):
+        assert nat[seq]["parity_ok"] is True and nat[seq]["fps"] > 50000 and 0 <= nat[seq]["cells_retry"] <= 1 and nat[seq]["k_fast_avg_launch_ms"] > 0
+    assert nat["retina_pan"]["cells_retry"] > 0.9 > 0.01 > nat["synthetic_headline_frames"]["cells_retry"]
+    pr = rec["per_rank"]
+    assert len(pr) == 1 and pr[0]["device"] == 0 and pr[0]["parity_ok"] is True and len(pr[0]["pci_bus_id"]) >= 12
+    assert 1000 < pr[0]["shader_clock_mhz_after_region"] < 3000 and abs(pr[0]["fps"] - rec["value"]) < 1e-6 * rec["value"]
+    assert rec["per_rank_fps"]["distinct_devices"] == 1 and rec["per_rank_fps"]["spread"] == 0
 
 
 @pytest.mark.timeout(300)
