@@ -136,6 +136,10 @@ class ORBmatcher:
         check(self._L.orbm_frame_download_keys_un(frame, ptr(out)))
         return out
 
+    def frame_settle(self, frame):
+        """orbm_frame_settle: returns when the frame's build has read the device arrays it was made from"""
+        check(self._L.orbm_frame_settle(frame))
+
     def frame_destroy(self, frame):
         check(self._L.orbm_frame_destroy(frame))
 

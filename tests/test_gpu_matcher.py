@@ -426,3 +426,34 @@ def test_device_frame_feeds_projection_search(gpu, oracle):
             assert gn == wn == hn and wn > 100
             assert np.array_equal(ga, wa) and np.array_equal(gocc, wocc) and np.array_equal(ga, ha)
             m.frame_destroy(frame)
+
+
+def test_frame_settle_then_the_inputs_may_be_recycled(gpu, oracle):
+    """orbm_frame_create returns with the build enqueued; orbm_frame_settle is what a caller that overwrites d_keys / d_desc
+    at once waits on.  Here: a frame from two device buffers, settle, both buffers overwritten, then the search."""
+    import ctypes as C
+    from orbslamm_amd import ORBextractor, ORBmatcher, make_grid
+    from orbslamm_amd._lib import check, ptr
+    rng = np.random.default_rng(77)
+    nq, nt = 900, 2500
+    c = make_proj_case(rng, nq, nt)
+    g = make_grid(0.0, 0.0, c["w"], c["h"])
+    gex = ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240, max_batch=1, device=0)   # (its handle owns the raw device buffers)
+    kb = np.frombuffer(c["tk"].tobytes(), np.uint8).reshape(1, 1, -1)
+    db = np.ascontiguousarray(c["td"]).reshape(1, 1, -1)
+    dk = gex.upload_frames(kb)[0]
+    dd = gex.upload_frames(db)[0]
+    m = ORBmatcher(0.9, True, device=0)
+    frame = m.frame_from_device(dk, dd, nt, [500.0, 500.0, 320.0, 240.0], [0, 0, 0, 0, 0], g)
+    m.frame_settle(frame)
+    m.frame_settle(frame)   # (a second call returns at once)
+    junk = np.full(max(kb.size, db.size), 0xA5, np.uint8)
+    check(gex._L.orbx_upload(gex._h, C.c_void_p(dk), ptr(junk), C.c_size_t(kb.size)))
+    check(gex._L.orbx_upload(gex._h, C.c_void_p(dd), ptr(junk), C.c_size_t(db.size)))
+    a0 = np.full(nt, -1, np.int32)
+    ga, gocc, gn = m.SearchByProjectionFrame(4, 100, c["uvr"], c["lvl"], c["qd"], c["qa"], c["qv"], c["qo"], frame, c["occ"], a0)
+    wa, wocc, wn = oracle.search_by_projection(4, 0.9, True, 100, c["uvr"], c["lvl"], c["qd"], c["qa"], c["qv"], c["qo"], c["gp"],
+                                               c["tk"], c["start"], c["idx"], c["td"], c["occ"], a0)
+    assert gn == wn and np.array_equal(ga, wa) and np.array_equal(gocc, wocc) and wn > 100
+    m.frame_destroy(frame)
+    m.close(); gex.close()
