@@ -823,10 +823,18 @@ def natural_sequences(W, H, B):
     import numpy as np
     from orbslamm_amd import synth
     path = os.path.join(_ROOT, "tests", "golden", "natural.npz")
-    if not os.path.exists(path) or (W, H) != (1241, 376):
+    if not os.path.exists(path) or (W, H) not in ((1241, 376), (640, 480)):
         return {}
     z = np.load(path)
     seqs = {}
+    if (W, H) == (640, 480):
+        # --config c2 (BASELINE configs[1], the TUM shape of configs[0]): three of the fixture's 640x480 photographs, a static camera
+        # with +-1 sensor noise per frame -- camera (mixed), brick (dense regular texture), grass (dense fine texture, no cell retries)
+        for name, seed in (("camera", 21), ("brick", 22), ("grass", 23)):
+            base = z["c2_" + name].astype(np.int16)
+            rng = np.random.Generator(np.random.PCG64(0x4E41 + seed))
+            seqs[name] = np.stack([np.clip(base + rng.integers(-1, 2, size=base.shape, dtype=np.int16), 0, 255).astype(np.uint8) for _ in range(B)])
+        return seqs
     cv = z["c3_canvas"]
     seqs["retina_pan"] = np.stack([np.ascontiguousarray(cv[synth._tri(t, 16):synth._tri(t, 16) + H, synth._tri(2 * t, 64):synth._tri(2 * t, 64) + W]) for t in range(B)])
     for name, seed in (("mosaic", 11), ("hubble", 12)):

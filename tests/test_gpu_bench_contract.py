@@ -99,6 +99,11 @@ def test_c2_config_has_a_bench_line(gpu):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout)
     assert "640x480" in rec["metric"] and rec["config"]["name"] == "c2" and rec["keypoints_last_frame"][0] > 500
+    # the TUM shape on photographs (the stand-in for configs[0]'s inputs): three 640x480 sequences, each held to the oracle
+    nat = rec["natural"]
+    for seq in ("camera", "brick", "grass"):
+        assert nat[seq]["parity_ok"] is True and nat[seq]["fps"] > 50000 and nat[seq]["keypoints_last_frame"] > 800
+    assert nat["grass"]["cells_retry"] < 0.05 < nat["camera"]["cells_retry"]
 
 
 @pytest.mark.timeout(600)
